@@ -1,0 +1,185 @@
+"""Launcher logic of ART (reference: ARTmain.py at the repository root): merge option dictionaries with the
+defaults, trace each OpticalChain, place/optimise the detector, summarise, optionally archive."""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+
+from . import ModuleAnalysisAndPlots as mplots
+from . import ModuleDetector as mdet
+from . import ModuleOpticalChain as moc
+from . import ModuleProcessing as mp
+
+_NICELINE = "_" * 99
+
+
+def print_banner(i=-1):
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "VERSION"), "r") as f:
+        version = f.read().strip()
+    print(_NICELINE)
+    print("ART - Attosecond Ray Tracing, MI355X-native ray-bundle propagation")
+    print(f"v{version}")
+    print(_NICELINE, flush=True)
+
+
+def load_config(config):
+    """Pick the chain(s) and the three option dictionaries out of an imported CONFIG module (ARTmain.py:56-96)."""
+    print("...setting up and importing optical chain(s)...", end="", flush=True)
+    if hasattr(config, "OpticalChainList"):
+        chains = config.OpticalChainList
+    elif hasattr(config, "OpticalChain"):
+        chains = config.OpticalChain
+    else:
+        raise ValueError("Could not import an optical-chain-object or list thereof with the name OpticalChain or "
+                         "OpticalChainList.")
+    opts = []
+    for name in ("SourceProperties", "DetectorOptions", "AnalysisOptions"):
+        if hasattr(config, name):
+            opts.append(getattr(config, name))
+        else:
+            print(f"No {name}-dictionary provided, will use defaults.")
+            opts.append({})
+    print("\r\033[K", end="", flush=True)
+    return (chains, *opts)
+
+
+def complete_defaults(SourceProperties, DetectorOptions, AnalysisOptions):
+    """User dictionaries on top of the defaults (ARTmain.py:99-110).  Like the reference this updates the
+    module-level default dictionaries in place."""
+    from .DefaultOptions import DefaultAnalysisOptions, DefaultDetectorOptions, DefaultSourceProperties
+    DefaultSourceProperties.update(SourceProperties)
+    DefaultDetectorOptions.update(DetectorOptions)
+    DefaultAnalysisOptions.update(AnalysisOptions)
+    return DefaultSourceProperties, DefaultDetectorOptions, DefaultAnalysisOptions
+
+
+def setup_detector(OpticalChain, DetectorOptions, RayList=None):
+    """ARTmain.py:113-144."""
+    ref = OpticalChain.optical_elements[DetectorOptions["ReflectionNumber"]].position
+    ref = np.asarray(ref, dtype=float)
+    if DetectorOptions["ManualDetector"]:
+        for key in ("DetectorCentre", "DetectorNormal"):
+            if DetectorOptions[key] is None:
+                raise RuntimeError(f'For manual detector placement you need to specify "{key}" in the '
+                                   '"DetectorOptions"-dictionary.')
+        return mdet.Detector(ref, DetectorOptions["DetectorCentre"], DetectorOptions["DetectorNormal"])
+    if DetectorOptions["DistanceDetector"] is None:
+        raise RuntimeError('For automatic detector placement you need to specify "DistanceDetector" in the '
+                           '"DetectorOptions"-dictionary.')
+    if RayList is None:
+        raise RuntimeError("For automatic detector placement you need to add a RayList as an input.")
+    det = mdet.Detector(ref)
+    det.autoplace(RayList, DetectorOptions["DistanceDetector"])
+    return det
+
+
+def optimize_detector(RayListAnalysed, Detector, DetectorOptions, verbose=True, maxRaystoConsider=1000,
+                      IntensityWeighted=False, Amplitude=None, Precision=3):
+    """Autofocus (ARTmain.py:147-190).  The reference sub-samples `maxRaystoConsider` random rays to keep its
+    Python loops affordable; the scan runs on the GPU here, so the sub-sampling is kept only for parity of the
+    search (index sampling replaces np.random.choice on a list of Ray objects)."""
+    rays = RayListAnalysed
+    if maxRaystoConsider is not None and len(rays) > maxRaystoConsider:
+        rays = rays.subset(np.random.choice(len(rays), maxRaystoConsider, replace=False))
+    det, spot, dur = mp.FindOptimalDistance(Detector, rays, DetectorOptions["OptFor"], Amplitude, Precision,
+                                            IntensityWeighted, verbose)
+    if verbose:
+        s = f"The optimal detector distance is {det.get_distance():.3f} mm, with"
+        if IntensityWeighted:
+            s += " intensity-weighted"
+        if DetectorOptions["OptFor"] in ["intensity", "spotsize"]:
+            s += f" spatial std of {spot*1e3:.3g} μm"
+        if DetectorOptions["OptFor"] in ["intensity", "duration"]:
+            s += f" temporal std of {dur:.3g} fs."
+        print(s, flush=True)
+    return det, spot, dur
+
+
+def make_plots(OpticalChain, RayListAnalysed, Detector, SourceProperties, DetectorOptions, AnalysisOptions):
+    """ARTmain.py:193-244 -- plots are out of scope; each selected plot reports once that it is skipped."""
+    A = AnalysisOptions
+    if A["plot_Render"]:
+        mplots.RayRenderGraph(OpticalChain)
+    for kind in ("Delay", "Intensity", "Incidence"):
+        if A[f"plot_{kind}MirrorProjection"]:
+            mplots.MirrorProjection(OpticalChain, DetectorOptions["ReflectionNumber"], Detector, kind)
+    if A["plot_SpotDiagram"]:
+        mplots.SpotDiagram(RayListAnalysed, Detector, A["DrawAiryAndFourier"])
+    for kind in ("Delay", "Intensity", "Incidence"):
+        if A[f"plot_{kind}SpotDiagram"]:
+            mplots.SpotDiagram(RayListAnalysed, Detector, A["DrawAiryAndFourier"], kind)
+    for kind in ("Delay", "Intensity", "Incidence"):
+        if A[f"plot_{kind}Graph"]:
+            mplots.DelayGraph(RayListAnalysed, Detector, SourceProperties["DeltaFT"], A["DrawAiryAndFourier"], kind)
+
+
+def run_ART(OpticalChain, SourceProperties, DetectorOptions, AnalysisOptions, loop=False):
+    """One chain: trace, transmission, detector, summary, plots (ARTmain.py:248-300)."""
+    output_rays = OpticalChain.get_output_rays()
+    RayListAnalysed = output_rays[DetectorOptions["ReflectionNumber"]]
+    ETransmission = mplots.getETransmission(OpticalChain.source_rays, RayListAnalysed)
+    if AnalysisOptions["verbose"]:
+        print(_NICELINE, flush=True)
+        if isinstance(OpticalChain.description, str) and len(OpticalChain.description) > 0:
+            print("***" + OpticalChain.description + "*** :")
+        if OpticalChain.loop_variable_name is not None and OpticalChain.loop_variable_value is not None:
+            print("For " + OpticalChain.loop_variable_name + " = " + "{:f}".format(OpticalChain.loop_variable_value)
+                  + ":\n")
+            print("The optical setup has an energy transmission of " + "{:.1f}".format(ETransmission) + "%.\n")
+    Detector = setup_detector(OpticalChain, DetectorOptions, RayListAnalysed)
+    if DetectorOptions["AutoDetectorDistance"]:
+        Detector, SpotSizeSD, DurationSD = optimize_detector(RayListAnalysed, Detector, DetectorOptions,
+                                                             AnalysisOptions["verbose"], maxRaystoConsider=1000,
+                                                             IntensityWeighted=True)
+    else:
+        SpotSizeSD, DurationSD = mplots.GetResultSummary(Detector, RayListAnalysed, AnalysisOptions["verbose"])
+    if AnalysisOptions["verbose"]:
+        print(_NICELINE + "\n")
+    if any(AnalysisOptions[k] for k in AnalysisOptions if k.startswith("plot_")):
+        make_plots(OpticalChain, RayListAnalysed, Detector, SourceProperties, DetectorOptions, AnalysisOptions)
+    return OpticalChain, Detector, ETransmission, SpotSizeSD, DurationSD
+
+
+def main(OpticalChainList, SourceProperties, DetectorOptions, AnalysisOptions, save_file_name=None):
+    """ARTmain.py:304-342."""
+    SourceProperties, DetectorOptions, AnalysisOptions = complete_defaults(SourceProperties, DetectorOptions,
+                                                                           AnalysisOptions)
+    names = ["OpticalChain", "Detector", "ETransmission", "SpotSizeSD", "DurationSD"]
+    kept_data = {n: [] for n in names}
+    if isinstance(OpticalChainList, moc.OpticalChain):
+        OpticalChainList = [OpticalChainList]
+        loop = False
+    elif not isinstance(OpticalChainList, list):
+        raise ValueError("The supplied OpticalChain is neither an OpticalChain-object, nor a list of those, as it "
+                         "should be.")
+    else:
+        loop = True
+    for i, chain in enumerate(OpticalChainList):
+        print("Optical Chain " + str(i) + "/" + str(len(OpticalChainList)) + " ", end="", flush=True)
+        results = run_ART(chain, SourceProperties, DetectorOptions, AnalysisOptions, loop)
+        for n, v in zip(names, results):
+            kept_data[n].append(v)
+    if AnalysisOptions["save_results"]:
+        print("...saving data...", end="", flush=True)
+        mp.save_compressed(kept_data, save_file_name)
+        print("\r\033[K", end="", flush=True)
+    return kept_data
+
+
+def cli(argv=None):
+    argv = sys.argv if argv is None else argv
+    if len(argv) < 2:
+        print("Usage: python ARTmain.py CONFIG_FILE")
+        return 2
+    print_banner(1)
+    config_file = argv[1]
+    filename = os.path.basename(config_file)
+    spec = importlib.util.spec_from_file_location(filename, config_file)
+    module = importlib.util.module_from_spec(spec)
+    sys.modules[filename] = module
+    spec.loader.exec_module(module)
+    chains, src, det, ana = load_config(module)
+    main(chains, src, det, ana, save_file_name=config_file)
+    return 0

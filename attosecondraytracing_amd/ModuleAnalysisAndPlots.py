@@ -1,0 +1,68 @@
+"""Result summaries, API subset of ART/ModuleAnalysisAndPlots.py.
+
+`getETransmission` and `GetResultSummary` (the two functions ARTmain needs for its numbers) are built on the
+device reductions.  The interactive matplotlib / PyVista plots of the reference are visualisation and out of
+scope for this package: the plot entry points exist so that ARTmain and CONFIG scripts run, and say so."""
+import numpy as np
+
+from . import ModuleGeometry as mgeo
+from . import ModuleProcessing as mp
+from .bundle import RayBundle
+
+_warned = set()
+
+
+def _not_built(name):
+    if name not in _warned:
+        _warned.add(name)
+        print(f"[ART-MI355X] plot '{name}' is not part of this build (visualisation is out of scope); skipped.")
+    return None
+
+
+def _sum_intensity(rays):
+    if isinstance(rays, RayBundle):
+        if rays.intensity is None:
+            raise TypeError("rays carry no intensity")
+        return rays.backend.bundle_sums(rays.view(), rays.intensity, rays.n_slots)[7]
+    return sum(r.intensity for r in rays)
+
+
+def getETransmission(RayListIn, RayListOut) -> float:
+    """Energy transmission in percent (ART/ModuleAnalysisAndPlots.py:62-77)."""
+    return 100 * _sum_intensity(RayListOut) / _sum_intensity(RayListIn)
+
+
+def GetResultSummary(Detector, RayListAnalysed, verbose=False):
+    """Spot-size and duration standard deviations at the detector (ART/ModuleAnalysisAndPlots.py:81-129)."""
+    P = Detector.get_PointList2DCentre(RayListAnalysed)
+    FocalSpotSizeSD = mp.StandardDeviation(P)
+    DelayList = Detector.get_Delays(RayListAnalysed)
+    DurationSD = mp.StandardDeviation(DelayList)
+    if verbose:
+        FocalSpotSize = mgeo.DiameterPointList(P)
+        print("At the detector distance of " + "{:.3f}".format(Detector.get_distance()) + " mm we get:\n"
+              + "Spatial std : " + "{:.3f}".format(FocalSpotSizeSD * 1e3) + " μm and min-max: "
+              + "{:.3f}".format(FocalSpotSize * 1e3) + " μm\n"
+              + "Temporal std : " + "{:.3e}".format(DurationSD) + " fs and min-max : "
+              + "{:.3e}".format(max(DelayList) - min(DelayList)) + " fs")
+    return FocalSpotSizeSD, DurationSD
+
+
+def SpotDiagram(*a, **k):
+    return _not_built("SpotDiagram")
+
+
+def DelayGraph(*a, **k):
+    return _not_built("DelayGraph")
+
+
+def MirrorProjection(*a, **k):
+    return _not_built("MirrorProjection")
+
+
+def RayRenderGraph(*a, **k):
+    return _not_built("RayRenderGraph")
+
+
+def show():
+    return None

@@ -1,0 +1,156 @@
+"""Plane detector, API of ART/ModuleDetector.py.  The read-out (hit points, 2D coordinates, optical paths)
+and its reductions (mean path, bounding box, second moments) run on the GPU for the whole bundle."""
+import numpy as np
+
+from . import _abi
+from . import ModuleGeometry as mgeo
+from . import ModuleProcessing as mp
+from .bundle import RayBundle
+
+LightSpeed = 299792458000  # mm/s
+
+
+def _is_number(x):
+    return type(x) in (int, float, np.float64)
+
+
+class Detector:
+    def __init__(self, RefPoint, Centre=None, Normal=None):
+        self.centre = Centre
+        self.normal = Normal
+        self.refpoint = RefPoint
+
+    @property
+    def centre(self):
+        return self._centre
+
+    @centre.setter
+    def centre(self, Centre):
+        if Centre is not None and not (isinstance(Centre, np.ndarray) and Centre.shape == (3,)):
+            raise TypeError("Detector Centre must be a 3D-vector, given as numpy.ndarray of shape (3,).")
+        self._centre = Centre
+
+    @property
+    def normal(self):
+        return self._normal
+
+    @normal.setter
+    def normal(self, Normal):
+        if Normal is None:
+            self._normal = None
+        elif isinstance(Normal, np.ndarray) and Normal.shape == (3,) and np.linalg.norm(Normal) > 0:
+            self._normal = Normal / np.linalg.norm(Normal)
+        else:
+            raise TypeError("Detector Normal must be a 3D-vector of norm >0, given as numpy.ndarray of shape (3,).")
+
+    @property
+    def refpoint(self):
+        return self._refpoint
+
+    @refpoint.setter
+    def refpoint(self, RefPoint):
+        if not (isinstance(RefPoint, np.ndarray) and RefPoint.shape == (3,)):
+            raise TypeError("Detector RefPoint must a 3D-vector, given as numpy.ndarray of shape (3,).")
+        self._refpoint = RefPoint
+
+    # ------------------------------------------------------------------ placement
+    def copy_detector(self):
+        return Detector(self.refpoint, self.centre, self.normal)
+
+    def autoplace(self, RayList, DistanceDetector: float):
+        """Normal to the central ray of RayList, DistanceDetector away from its origin (ART/ModuleDetector.py:109-137)."""
+        central = mp.FindCentralRay(RayList)
+        normal = -central.vector
+        self.normal = normal
+        self.centre = central.point - normal * DistanceDetector
+        self.refpoint = central.point
+
+    def get_distance(self):
+        """ART/ModuleDetector.py:139-145."""
+        I = mgeo.IntersectionLinePlane(self.refpoint, -self.normal, self.centre, self.normal)
+        return np.linalg.norm(self.refpoint - I)
+
+    def shiftToDistance(self, NewDistance: float):
+        if not _is_number(NewDistance):
+            raise TypeError("The new Detector Distance must be int or float.")
+        self._centre = self._centre - (NewDistance - self.get_distance()) * self.normal
+
+    def shiftByDistance(self, Shift: float):
+        if not _is_number(Shift):
+            raise TypeError("The Detector Distance Shift must be int or float.")
+        self._centre = self.centre - Shift * self.normal
+
+    def _iscomplete(self):
+        if self.centre is None or self.normal is None:
+            raise TypeError("The detector has no centre and normal vectors defined yet.")
+        return True
+
+    # ------------------------------------------------------------------ device read-out
+    def _desc(self):
+        d = _abi.ArtDetectorDesc()
+        d.centre[:] = [float(v) for v in self.centre]
+        d.normal[:] = [float(v) for v in self.normal]
+        d.rot[:] = [float(v) for v in mgeo.rotation_matrix(self.normal, np.array([0.0, 0.0, 1.0])).reshape(9)]
+        return d
+
+    def readout(self, RayList, points3d=False):
+        """Device tensors of the read-out, one entry per slot of the bundle (valid where alive):
+        dict with 'X', 'Y' (detector-plane coordinates about Detector.centre, ART/ModuleDetector.py:212-234),
+        'opl' (optical path to the detector, :272-275), optionally 'P3' (3 tensors, :191-210), and 'stats'
+        (host array of art_detector_stats)."""
+        self._iscomplete()
+        B = RayList if isinstance(RayList, RayBundle) else RayBundle.from_ray_list(RayList)
+        be = B.backend
+        n = B.n_slots
+        X, Y, opl = be.empty(n), be.empty(n), be.empty(n)
+        P3 = [be.empty(n), be.empty(n), be.empty(n)] if points3d else None
+        be.detector(self._desc(), B.view(), n, P3, (X, Y), opl)
+        stats = be.detector_stats(B.alive, X, Y, opl, B.intensity, n)
+        return {"bundle": B, "X": X, "Y": Y, "opl": opl, "P3": P3, "stats": stats}
+
+    def _spot_and_duration(self, RayList, weighted, need_spot=True, need_duration=True):
+        """Std of the centred 2D points and of the delays (ART/ModuleProcessing.py:327-341), on device."""
+        r = self.readout(RayList)
+        B, s = r["bundle"], r["stats"]
+        w = B.intensity if weighted else None
+        wsum = s[8] if weighted else s[0]
+        mx = (s[9] if weighted else s[6]) / wsum
+        my = (s[10] if weighted else s[7]) / wsum
+        mo = (s[11] if weighted else s[1]) / wsum
+        m = B.backend.detector_moments(B.alive, r["X"], r["Y"], r["opl"], w, B.n_slots, mx, my, mo)
+        spot = float(np.sqrt((m[1] + m[2]) / m[0])) if need_spot else np.nan
+        dur = float(np.sqrt(m[3] / m[0]) / LightSpeed * 1e15) if need_duration else np.nan
+        return spot, dur
+
+    # ------------------------------------------------------------------ reference API (host arrays of survivors)
+    def get_PointList3D(self, RayList):
+        """(m,3) hit points of the surviving rays (ART/ModuleDetector.py:191-210)."""
+        r = self.readout(RayList, points3d=True)
+        idx = r["bundle"].index()
+        return np.stack([p.index_select(0, idx).cpu().numpy() for p in r["P3"]], axis=1)
+
+    def get_PointList2D(self, RayList):
+        """(m,2) detector-plane points, origin at Detector.centre (ART/ModuleDetector.py:212-234)."""
+        r = self.readout(RayList)
+        idx = r["bundle"].index()
+        return np.stack([r["X"].index_select(0, idx).cpu().numpy(), r["Y"].index_select(0, idx).cpu().numpy()], axis=1)
+
+    def get_PointList2DCentre(self, RayList):
+        """(m,2) points centred on their bounding box (ART/ModuleDetector.py:236-252; ModuleGeometry.py:222-245)."""
+        r = self.readout(RayList)
+        s = r["stats"]
+        idx = r["bundle"].index()
+        cx, cy = (s[3] + s[2]) * 0.5, (s[5] + s[4]) * 0.5
+        return np.stack([r["X"].index_select(0, idx).cpu().numpy() - cx,
+                         r["Y"].index_select(0, idx).cpu().numpy() - cy], axis=1)
+
+    def get_OpticalPaths(self, RayList):
+        r = self.readout(RayList)
+        return r["opl"].index_select(0, r["bundle"].index()).cpu().numpy()
+
+    def get_Delays(self, RayList):
+        """Delays in fs relative to the mean travel time (ART/ModuleDetector.py:254-279)."""
+        r = self.readout(RayList)
+        s = r["stats"]
+        opl = r["opl"].index_select(0, r["bundle"].index()).cpu().numpy()
+        return (opl - s[1] / s[0]) / LightSpeed * 1e15

@@ -1,0 +1,270 @@
+"""Mirror surfaces, API of ART/ModuleMirror.py.
+
+The classes are parameter holders for the HIP kernels: each exposes `_abi_kind` / `_abi_params()` (layout in
+include/art_hip.h) plus the reference's host-side helpers `get_centre()` and `get_normal(Point)` for a single
+point.  Ray/surface intersection, aperture test and reflection of a *bundle* never run in Python; see
+ModuleProcessing.RayTracingCalculation -> libart_hip.so.  Rendering meshes (`get_grid3D`) are out of scope."""
+import math
+
+import numpy as np
+
+from . import _abi
+from . import ModuleGeometry as mgeo
+
+
+class _Mirror:
+    _abi_kind = None
+
+    def _abi_params(self):
+        raise NotImplementedError
+
+    def __hash__(self):
+        return hash((self.type, hash(self.support)) + tuple(float(v) for v in self._abi_params()))
+
+
+class MirrorPlane(_Mirror):
+    """Plane mirror in the xy-plane of its own frame (ART/ModuleMirror.py:42-113)."""
+    _abi_kind = _abi.ART_PLANE
+
+    def __init__(self, Support):
+        self.support = Support
+        self.type = "Plane Mirror"
+
+    def _abi_params(self):
+        return []
+
+    def get_normal(self, Point):
+        return np.array([0, 0, 1])
+
+    def get_centre(self):
+        return np.array([0, 0, 0])
+
+
+class MirrorSpherical(_Mirror):
+    """Sphere x^2+y^2+z^2 = R^2; negative Radius = convex (ART/ModuleMirror.py:117-208)."""
+    _abi_kind = _abi.ART_SPHERE
+
+    def __init__(self, Radius, Support):
+        if Radius < 0:
+            self.type = "SphericalCX Mirror"
+            self.radius = -Radius
+        else:
+            self.type = "SphericalCC Mirror"
+            self.radius = Radius
+        self.support = Support
+
+    def _abi_params(self):
+        return [self.radius]
+
+    def get_normal(self, Point):
+        return mgeo.Normalize(-np.asarray(Point, dtype=float))
+
+    def get_centre(self):
+        return np.array([0, 0, -self.radius])
+
+
+class MirrorParabolic(_Mirror):
+    """Paraboloid x^2+y^2 = 2 p z with the support centre off-axis (ART/ModuleMirror.py:212-387).
+    `offaxisangle` is given in degrees and stored/returned in radians, like the reference."""
+    _abi_kind = _abi.ART_PARABOLA
+
+    def __init__(self, FocalEffective: float, OffAxisAngle: float, Support):
+        self._offaxisangle = np.deg2rad(OffAxisAngle)
+        self.support = Support
+        self.type = "Parabolic Mirror"
+        self._feff = FocalEffective
+        self._p = FocalEffective * (1 + np.cos(self._offaxisangle))
+
+    @property
+    def offaxisangle(self):
+        return self._offaxisangle
+
+    @offaxisangle.setter
+    def offaxisangle(self, OffAxisAngle):
+        self._offaxisangle = np.deg2rad(OffAxisAngle)
+        self._p = self._feff * (1 + np.cos(self._offaxisangle))
+
+    @property
+    def feff(self):
+        return self._feff
+
+    @feff.setter
+    def feff(self, FocalEffective):
+        self._feff = FocalEffective
+        self._p = self._feff * (1 + np.cos(self._offaxisangle))
+
+    @property
+    def p(self):
+        return self._p
+
+    @p.setter
+    def p(self, SemiLatusRectum):
+        self._p = SemiLatusRectum
+        self._feff = self._p / (1 + np.cos(self._offaxisangle))
+
+    def _abi_params(self):
+        return [self._p]
+
+    def get_normal(self, Point):
+        return mgeo.Normalize(np.array([-Point[0], -Point[1], self._p]))
+
+    def get_centre(self):
+        return np.array([self.feff * np.sin(self.offaxisangle), 0,
+                         self._p * 0.5 - self.feff * np.cos(self.offaxisangle)])
+
+
+class MirrorToroidal(_Mirror):
+    """Torus (sqrt(x^2+z^2) - R)^2 + y^2 = r^2 (ART/ModuleMirror.py:391-527)."""
+    _abi_kind = _abi.ART_TORUS
+
+    def __init__(self, MajorRadius, MinorRadius, Support):
+        self.majorradius = MajorRadius
+        self.minorradius = MinorRadius
+        self.support = Support
+        self.type = "Toroidal Mirror"
+
+    def _abi_params(self):
+        return [self.majorradius, self.minorradius]
+
+    def get_normal(self, Point):
+        x, y, z = Point
+        R2, r2 = self.majorradius ** 2, self.minorradius ** 2
+        S = x * x + y * y + z * z
+        return mgeo.Normalize(-np.array([x * (S - R2 - r2), y * (S + R2 - r2), z * (S - R2 - r2)]))
+
+    def get_centre(self):
+        return np.array([0, 0, -self.majorradius - self.minorradius])
+
+
+def ReturnOptimalToroidalRadii(Focal: float, AngleIncidence: float):
+    """Major/minor radii giving focal length `Focal` at `AngleIncidence` (deg) without astigmatism
+    (ART/ModuleMirror.py:533-561)."""
+    c = np.cos(AngleIncidence * np.pi / 180)
+    return 2 * Focal * (1 / c - c), 2 * Focal * c
+
+
+class MirrorEllipsoidal(_Mirror):
+    """Ellipsoid (x/a)^2 + (y/b)^2 + (z/b)^2 = 1 (ART/ModuleMirror.py:565-751); same ctor variants."""
+    _abi_kind = _abi.ART_ELLIPSOID
+
+    def __init__(self, Support, SemiMajorAxis=None, SemiMinorAxis=None, OffAxisAngle=None, f_object=None,
+                 f_image=None):
+        self.type = "Ellipsoidal Mirror"
+        self.support = Support
+        self.a = None
+        self.b = None
+        self._offaxisangle = None
+        if SemiMajorAxis is not None and SemiMinorAxis is not None:
+            self.a = SemiMajorAxis
+            self.b = SemiMinorAxis
+        have_f = f_object is not None and f_image is not None
+        if OffAxisAngle is not None:
+            self._offaxisangle = np.deg2rad(OffAxisAngle)
+            if have_f:
+                foci_sq = f_object ** 2 + f_image ** 2 - 2 * f_object * f_image * np.cos(self._offaxisangle)
+                self.a = (f_image + f_object) / 2
+                self.b = np.sqrt(self.a ** 2 - foci_sq / 4)
+        elif self.a is not None and self.b is not None:
+            foci = 2 * np.sqrt(self.a ** 2 - self.b ** 2)
+            if have_f:
+                self._offaxisangle = np.arccos((f_image ** 2 + f_object ** 2 - foci ** 2) / (2 * f_image * f_object))
+            else:
+                self._offaxisangle = np.arccos(1 - foci ** 2 / (2 * self.a ** 2))
+        if self.a is None or self.b is None or self._offaxisangle is None:
+            raise ValueError("Invalid mirror parameters")
+
+    def _abi_params(self):
+        return [self.a, self.b]
+
+    def get_normal(self, Point):
+        return mgeo.Normalize(np.array([-Point[0] / self.a ** 2, -Point[1] / self.b ** 2, -Point[2] / self.b ** 2]))
+
+    def get_centre(self):
+        """Point of the surface at the centre of the support (ART/ModuleMirror.py:695-714)."""
+        foci = 2 * np.sqrt(self.a ** 2 - self.b ** 2)
+        h = -foci / 2 / np.tan(self._offaxisangle)
+        R = np.sqrt(foci ** 2 / 4 + h ** 2)
+        sign = 1
+        if math.isclose(self._offaxisangle, np.pi / 2):
+            h = 0
+        elif self._offaxisangle > np.pi / 2:
+            h = -h
+            sign = -1
+        qa = 1 - self.a ** 2 / self.b ** 2
+        qb = -2 * h
+        qc = self.a ** 2 + h ** 2 - R ** 2
+        z = (-qb + sign * np.sqrt(qb ** 2 - 4 * qa * qc)) / (2 * qa)
+        if math.isclose(z ** 2, self.b ** 2):
+            return np.array([0, 0, -self.b])
+        return np.array([self.a * np.sqrt(1 - z ** 2 / self.b ** 2), 0, sign * z])
+
+
+def ReturnOptimalEllipsoidalAxes(Focal: float, AngleIncidence: float):
+    """ART/ModuleMirror.py:755-777."""
+    return Focal, Focal * np.cos(np.deg2rad(AngleIncidence))
+
+
+class MirrorCylindrical(_Mirror):
+    """Cylinder y^2 + z^2 = R^2; negative Radius = convex (ART/ModuleMirror.py:781-874)."""
+    _abi_kind = _abi.ART_CYLINDER
+
+    def __init__(self, Radius, Support):
+        if Radius < 0:
+            self.type = "CylindricalCX Mirror"
+            self.radius = -Radius
+        else:
+            self.type = "CylindricalCC Mirror"
+            self.radius = Radius
+        self.support = Support
+
+    def _abi_params(self):
+        return [self.radius]
+
+    def get_normal(self, Point):
+        return mgeo.Normalize(np.array([0, -Point[1], -Point[2]]))
+
+    def get_centre(self):
+        return np.array([0, 0, -self.radius])
+
+
+class DeformedMirror(_Mirror):
+    """A mirror with surface defects (ART/ModuleMirror.py:945-980).  The defect offset always shifts the hit
+    point; the perturbed normal is used only when tracing with IgnoreDefects=False (reference default: True)."""
+
+    def __init__(self, Mirror, DeformationList):
+        self.Mirror = Mirror
+        self.DeformationList = list(DeformationList)
+        self.type = Mirror.type
+        self.support = self.Mirror.support
+        if len(self.DeformationList) > _abi.ART_MAX_DEFECTS:
+            raise NotImplementedError(f"at most {_abi.ART_MAX_DEFECTS} defects per mirror are supported")
+        for d in self.DeformationList:
+            if not hasattr(d, "_abi_table"):
+                raise NotImplementedError(f"defect type {type(d).__name__} has no device implementation yet")
+
+    @property
+    def _abi_kind(self):
+        return self.Mirror._abi_kind
+
+    def _abi_params(self):
+        return self.Mirror._abi_params()
+
+    def _abi_defect_table(self):
+        return np.concatenate([d._abi_table() for d in self.DeformationList])
+
+    def get_centre(self):
+        return self.Mirror.get_centre()
+
+    def __hash__(self):
+        return hash((hash(self.Mirror),) + tuple(hash(d) for d in self.DeformationList))
+
+
+def ReflectionMirrorRayList(Mirror, ListRay, IgnoreDefects=False):
+    """Reflect a bundle given in the mirror's own frame (ART/ModuleMirror.py:912-939): one identity-pose
+    element on the device."""
+    from . import ModuleProcessing as mp
+    from .ModuleOpticalElement import OpticalElement
+    # position = get_centre() with identity axes makes lab frame == optic frame (P_opt = P - pos + centre)
+    oe = OpticalElement(Mirror, np.asarray(Mirror.get_centre(), dtype=float), np.array([0.0, 0.0, 1.0]),
+                        np.array([1.0, 0.0, 0.0]))
+    return mp.RayTracingCalculation(ListRay, [oe], IgnoreDefects=IgnoreDefects)[0]

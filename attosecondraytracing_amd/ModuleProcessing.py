@@ -1,0 +1,356 @@
+"""Ray-tracing driver and (pre-)alignment helpers, API of ART/ModuleProcessing.py.
+
+`RayTracingCalculation` is the drop-in boundary of this package: same name, arguments and return structure
+as ART/ModuleProcessing.py:250-313, but the per-ray Python loops are replaced by launches of the gfx950
+kernels in libart_hip.so on device-resident SoA bundles (bundle.RayBundle).  There is no CPU path."""
+import copy
+import lzma
+import os
+import pickle
+from datetime import datetime
+from time import perf_counter
+
+import numpy as np
+
+from . import _abi
+from . import _lib
+from . import ModuleGeometry as mgeo
+from . import ModuleMask as mmask
+from . import ModuleOpticalElement as moe
+from . import ModuleOpticalRay as mray
+from . import ModuleSupport as msupp
+from .bundle import RayBundle
+
+# "chain": one fused launch for the whole chain (ray stays in registers, every bundle still written);
+# "element": one launch per optical element.  Results are identical.
+DEFAULT_TRACE_MODE = os.environ.get("ART_TRACE_MODE", "chain")
+
+
+# ------------------------------------------------------------------------------------------- descriptors
+def element_descriptor(oe, IgnoreDefects=True, backend=None):
+    """ArtElementDesc (include/art_hip.h) of one OpticalElement; returns (desc, keepalive) where keepalive
+    holds device tensors the descriptor points to."""
+    optic = oe.type
+    kind = getattr(optic, "_abi_kind", None)
+    tname = getattr(optic, "type", None)
+    if kind is None or not isinstance(tname, str) or not ("Mirror" in tname or tname == "Mask"):
+        raise NameError("I don`t recognize the type of optical element " + str(tname) + ".")
+    d = _abi.ArtElementDesc()
+    d.kind = int(kind)
+    d.support_kind = int(optic.support._abi_kind)
+    fwd, bwd = mgeo.frame_maps(oe.normal, oe.majoraxis)
+    d.fwd[:] = [float(v) for v in fwd.reshape(9)]
+    d.bwd[:] = [float(v) for v in bwd.reshape(9)]
+    d.pos[:] = [float(v) for v in oe.position]          # OEPlacement builds integer-typed positions
+    d.centre[:] = [float(v) for v in optic.get_centre()]
+    sp = [float(v) for v in optic.support._abi_params()]
+    d.sp[:] = sp + [0.0] * (6 - len(sp))
+    mp_ = [float(v) for v in optic._abi_params()]
+    d.mp[:] = mp_ + [0.0] * (4 - len(mp_))
+    keep = None
+    d.n_defects = 0
+    d.flags = 0
+    d.zern = None
+    if hasattr(optic, "DeformationList") and len(optic.DeformationList) > 0:
+        be = backend or _lib.get_backend()
+        keep = be.from_numpy(optic._abi_defect_table())
+        d.zern = keep.data_ptr()
+        d.n_defects = len(optic.DeformationList)
+        if not IgnoreDefects:
+            d.flags = _abi.ART_FLAG_PERTURBED_NORMAL
+    return d, keep
+
+
+def _as_bundle(rays, backend=None):
+    if isinstance(rays, RayBundle):
+        return rays
+    return RayBundle.from_ray_list(rays, backend)
+
+
+# ------------------------------------------------------------------------------------------- the hot path
+def RayTracingCalculation(source_rays, optical_elements, IgnoreDefects=True, mode=None, history=True):
+    """Propagate `source_rays` through `optical_elements` (ART/ModuleProcessing.py:250-313).
+
+    Returns a list with one RayBundle per element: the rays *after* that element, in the lab frame.  Each
+    bundle behaves like the reference's list of surviving Ray objects (len, indexing, iteration) and keeps
+    the full SoA state on the device.  With history=False only the last bundle is materialised (the others
+    are None): an extension for callers that only analyse the final bundle."""
+    src = _as_bundle(source_rays)
+    be = src.backend
+    n = src.n_slots
+    m = len(optical_elements)
+    if m == 0:
+        return []
+    descs, keep = [], []
+    for oe in optical_elements:
+        d, k = element_descriptor(oe, IgnoreDefects, be)
+        descs.append(d)
+        keep.append(k)
+    mode = mode or DEFAULT_TRACE_MODE
+    outs = []
+    prev = src
+    for k in range(m):
+        if history or k == m - 1:
+            b = RayBundle.allocate(n, like=src, backend=be)
+            b.parent = prev
+            b._keepalive = keep
+            prev = b
+            outs.append(b)
+        else:
+            outs.append(None)
+    if mode == "chain":
+        views = [b.view() if b is not None else _abi.ArtBundleView() for b in outs]
+        be.trace_chain(descs, src.view(), views, n)
+    elif mode == "element":
+        if not history and m > 1:
+            # ping-pong through one scratch bundle, in place
+            cur = RayBundle.allocate(n, like=src, backend=be)
+            be.trace_element(descs[0], src.view(), cur.view(), n)
+            for k in range(1, m - 1):
+                be.trace_element(descs[k], cur.view(), cur.view(), n)
+            be.trace_element(descs[m - 1], cur.view(), outs[-1].view(), n)
+        else:
+            vin = src.view()
+            for k in range(m):
+                vout = outs[k].view()
+                be.trace_element(descs[k], vin, vout, n)
+                vin = vout
+    else:
+        raise ValueError("mode must be 'chain' or 'element'")
+    return outs
+
+
+# ------------------------------------------------------------------------------------------- placement
+def _singleOEPlacement(SourceProperties, OpticsList, DistanceList, IncidenceAngleList, IncidencePlaneAngleList,
+                       Description):
+    """Place and align the optics of one chain along the central ray (ART/ModuleProcessing.py:32-130)."""
+    from . import ModuleOpticalChain as moc
+    from . import ModuleSource as msource
+
+    Divergence = SourceProperties["Divergence"]
+    SourceSize = SourceProperties["SourceSize"]
+    RayNumber = SourceProperties["NumberRays"]
+    Wavelength = SourceProperties["Wavelength"]
+
+    plane_angles = [np.deg2rad(a % 360) for a in IncidencePlaneAngleList]
+    inc_angles = [np.deg2rad(a % 360) for a in IncidenceAngleList]
+
+    SourcePosition = np.array([0, 0, 0])
+    SourceDirection = np.array([1, 0, 0])
+    if Divergence == 0:
+        if SourceSize == 0:
+            S0 = OpticsList[0].support
+            radius = 0.5 * min(S0.dimX, S0.dimY) if hasattr(S0, "dimX") else S0.radius
+        else:
+            radius = SourceSize / 2
+        SourceRayList = msource.PlaneWaveDisk(SourcePosition, SourceDirection, radius, RayNumber,
+                                              Wavelength=Wavelength)
+    elif SourceSize == 0:
+        SourceRayList = msource.PointSource(SourcePosition, SourceDirection, Divergence, RayNumber,
+                                            Wavelength=Wavelength)
+    else:
+        SourceRayList = msource.ExtendedSource(SourcePosition, SourceDirection, SourceSize, Divergence, RayNumber,
+                                               Wavelength=Wavelength)
+    SourceRayList = msource.ApplyGaussianIntensityToRayList(SourceRayList, 1 / np.e ** 2)
+
+    # one alignment ray along the bundle axis, traced through the growing chain to find the next direction
+    guide = [mray.Ray(SourcePosition.astype(float), SourceDirection.astype(float))]
+    elements = []
+    guide_elements = []
+    centre = SourcePosition
+    central = SourceDirection
+    rot_axis = np.array([0, 1, 0])  # normal of the incidence plane, initially the x-z plane
+
+    for k, Optic in enumerate(OpticsList):
+        if Optic.type in ("SphericalCX Mirror", "CylindricalCX Mirror"):
+            inc_angles[k] = np.pi - inc_angles[k]  # convex: reflect off the "back side"
+        centre = central * DistanceList[k] + centre
+        if abs(plane_angles[k] - np.pi) < 1e-10:
+            rot_axis = -rot_axis
+        else:
+            rot_axis = mgeo.RotationAroundAxis(central, -plane_angles[k], rot_axis)
+        normal = mgeo.RotationAroundAxis(rot_axis, -np.pi / 2 + inc_angles[k], np.cross(central, rot_axis))
+        major = np.cross(rot_axis, normal)
+        element = moe.OpticalElement(Optic, centre, normal, major)
+        elements.append(element)
+        if "Mirror" in Optic.type:
+            guide_elements.append(element)
+            out = RayTracingCalculation(guide, guide_elements)
+            central = out[-1][0].vector
+        elif Optic.type == "Mask":
+            # the guide ray must always pass: a fully open stand-in mask (only in the guide chain)
+            open_mask = mmask.Mask(msupp.SupportRoundHole(Radius=100, RadiusHole=100, CenterHoleX=0, CenterHoleY=0))
+            guide_elements.append(moe.OpticalElement(open_mask, centre, normal, major))
+        else:
+            raise NameError("I don`t recognize the type of optical element " + Optic.type + ".")
+
+    return moc.OpticalChain(SourceRayList, elements, Description)
+
+
+def _which_indeces(lst):
+    return [i for i, x in enumerate(lst) if isinstance(x, (list, np.ndarray))]
+
+
+def OEPlacement(SourceProperties, OpticsList, DistanceList, IncidenceAngleList, IncidencePlaneAngleList=None,
+                Description="", *_ignored):
+    """Automatic placement of the optics in the lab frame (ART/ModuleProcessing.py:133-246).  One entry of one
+    of the three lists may itself be a list/array: then a list of OpticalChains is returned.
+
+    Extra positional arguments are accepted and ignored: two shipped example configs pass a 7th `render`
+    argument (examples/CONFIG_2toroidals_f-x-f.py:54, CONFIG_2toroidals_twisted.py:52)."""
+    if IncidencePlaneAngleList is None:
+        IncidencePlaneAngleList = np.zeros(len(OpticsList)).tolist()
+    lists = {"incidence": IncidenceAngleList, "incplane": IncidencePlaneAngleList, "distance": DistanceList}
+    nested = {k: _which_indeces(v) for k, v in lists.items()}
+    total = sum(len(v) for v in nested.values())
+    if total > 1:
+        raise ValueError("Only one element of one of the lists IncidenceAngleList, IncidencePlaneAngleList, or "
+                         "DistanceList can be a list or array itself. Otherwise things get too tangled...")
+    if total == 0:
+        return _singleOEPlacement(SourceProperties, OpticsList, DistanceList, IncidenceAngleList,
+                                  IncidencePlaneAngleList, Description)
+    labels = {"incidence": " incidence angle (deg)", "distance": " distance (mm)",
+              "incplane": " incidence-plane angle rotation (deg)"}
+    which = next(k for k in ("incidence", "distance", "incplane") if nested[k])
+    i = nested[which][0]
+    name = OpticsList[i].type + "_idx_" + str(i) + labels[which]
+    loop_list = lists[which]
+    values = copy.deepcopy(loop_list[i])
+    chains = []
+    for x in values:
+        loop_list[i] = x
+        ch = _singleOEPlacement(SourceProperties, OpticsList, DistanceList, IncidenceAngleList,
+                                IncidencePlaneAngleList, Description)
+        ch.loop_variable_name = name
+        ch.loop_variable_value = x
+        chains.append(ch)
+    return chains
+
+
+# ------------------------------------------------------------------------------------------- statistics
+def FindCentralRay(RayList):
+    """Mean point and mean direction of a bundle as a Ray (ART/ModuleProcessing.py:464-482)."""
+    if isinstance(RayList, RayBundle):
+        s = RayList.backend.bundle_sums(RayList.view(), None, RayList.n_slots)
+        cnt = s[0]
+        return mray.Ray(s[1:4] / cnt, s[4:7] / cnt)
+    return mray.Ray(np.mean([x.point for x in RayList], axis=0), np.mean([x.vector for x in RayList], axis=0))
+
+
+def StandardDeviation(List) -> float:
+    """RMS spread of numbers or of points about their mean (ART/ModuleProcessing.py:485-507)."""
+    A = np.asarray(List, dtype=float)
+    if A.ndim == 1:
+        return float(np.std(A))
+    if A.ndim == 2 and A.shape[1] > 1:
+        return float(np.sqrt(np.var(A, axis=0).sum()))
+    raise ValueError("StandardDeviation expects a list of floats or numpy-arrays as input, but got something else.")
+
+
+def WeightedStandardDeviation(List, Weights) -> float:
+    """ART/ModuleProcessing.py:510-532."""
+    A = np.asarray(List, dtype=float)
+    average = np.average(A, axis=0, weights=Weights)
+    variance = np.average((A - average) ** 2, axis=0, weights=Weights)
+    return float(np.sqrt(np.sum(variance)))
+
+
+def ReturnNumericalAperture(RayList, RefractiveIndex: float = 1) -> float:
+    """n sin(theta_max) about the central ray (ART/ModuleProcessing.py:536-566)."""
+    central = FindCentralRay(RayList).vector
+    V = RayList.vectors() if isinstance(RayList, RayBundle) else np.array([r.vector for r in RayList])
+    c = np.linalg.norm(central)
+    a = np.linalg.norm(V * c - central[None, :] * 1.0, axis=1)
+    b = np.linalg.norm(V * c + central[None, :] * 1.0, axis=1)
+    return float(np.sin(np.amax(2 * np.arctan2(a, b))) * RefractiveIndex)
+
+
+def ReturnAiryRadius(Wavelength: float, NumericalAperture: float) -> float:
+    """ART/ModuleProcessing.py:570-593."""
+    if NumericalAperture > 1e-3 and Wavelength is not None:
+        return 1.22 * 0.5 * Wavelength / NumericalAperture
+    return 0
+
+
+# ------------------------------------------------------------------------------------------- autofocus
+def _scan(detector, Amplitude, Step, RayList, OptFor, IntensityWeighted):
+    """One pass of the detector scan (ART/ModuleProcessing.py:317-366): every position is evaluated on the
+    device (detector read-out + two reduction passes), all rays, no Python loop over rays."""
+    sizes, durations, fitness = [], [], []
+    detector.shiftByDistance(-Amplitude)
+    n = int(2 * Amplitude / Step)
+    for _ in range(n):
+        spot, dur = detector._spot_and_duration(RayList, IntensityWeighted, need_spot=OptFor in ("intensity", "spotsize"),
+                                                need_duration=OptFor in ("intensity", "duration"))
+        sizes.append(spot)
+        durations.append(dur)
+        fitness.append(spot ** 2 * dur if OptFor == "intensity" else (dur if OptFor == "duration" else spot))
+        detector.shiftByDistance(Step)
+    ind = int(np.argmin(fitness))
+    detector.shiftByDistance(-(n - ind) * Step)
+    return detector, sizes[ind], durations[ind]
+
+
+def FindOptimalDistance(Detector, RayList, OptFor="intensity", Amplitude: float = None, Precision: int = 3,
+                        IntensityWeighted=False, verbose=False):
+    """Detector distance minimising spot size, duration or spot^2*duration (ART/ModuleProcessing.py:369-460).
+    Note: like the reference, the accepted names are 'intensity', 'size', 'duration' although the scan itself
+    understands 'spotsize' (reference quirk, ModuleProcessing.py:424 vs :328)."""
+    if OptFor not in ["intensity", "size", "duration"]:
+        raise NameError("I don`t recognize what you want to optimize the detector distance for. OptFor must be "
+                        "either 'intensity', 'size' or 'duration'.")
+    FirstDistance = Detector.get_distance()
+    SizeSpot = 2 * StandardDeviation(Detector.get_PointList2DCentre(RayList))
+    NumericalAperture = ReturnNumericalAperture(RayList, 1)
+    if Amplitude is None:
+        Amplitude = min(4 * np.ceil(SizeSpot / np.tan(np.arcsin(NumericalAperture))), FirstDistance)
+    Step = Amplitude / 10
+    if verbose:
+        print(f"Searching optimal detector position for *{OptFor}* within [{FirstDistance-Amplitude:.3f}, "
+              f"{FirstDistance+Amplitude:.3f}] mm...", end="", flush=True)
+    moving = Detector.copy_detector()
+    for k in range(Precision + 1):
+        moving, OptSpotSize, OptDuration = _scan(moving, Amplitude * 0.1 ** k, Step * 0.1 ** k, RayList, OptFor,
+                                                 IntensityWeighted)
+    if not FirstDistance - Amplitude + 10 ** -Precision < moving.get_distance() < FirstDistance + Amplitude - 10 ** -Precision:
+        print("There`s no minimum-size/duration focus in the searched range.")
+    print("\r\033[K", end="", flush=True)
+    if OptFor == "duration":
+        OptSpotSize = np.nan
+    return moving, OptSpotSize, OptDuration
+
+
+# ------------------------------------------------------------------------------------------- misc
+def _hash_list_of_objects(lst):
+    return sum(hash(x) for x in lst)
+
+
+def save_compressed(obj, filename: str = None):
+    """lzma + pickle archive of results (ART/ModuleProcessing.py:612-625).  RayBundles are stored as host arrays."""
+    if not isinstance(filename, str):
+        filename = "kept_data_" + datetime.now().strftime("%Y-%m-%d-%Hh%M")
+    i = 0
+    while os.path.exists(filename + f"_{i}.xz"):
+        i += 1
+    filename = filename + f"_{i}"
+    with lzma.open(filename + ".xz", "wb") as f:
+        pickle.dump(obj, f)
+    print("Saved results to " + filename + ".xz.")
+    print("->To reload from disk do: kept_data = mp.load_compressed('" + filename + "')")
+
+
+def load_compressed(filename: str):
+    """ART/ModuleProcessing.py:628-633."""
+    with lzma.open(filename + ".xz", "rb") as f:
+        return pickle.load(f)
+
+
+_tstart_stack = []
+
+
+def _tic():
+    _tstart_stack.append(perf_counter())
+
+
+def _toc(fmt="Elapsed: %s s"):
+    print(fmt % (perf_counter() - _tstart_stack.pop()))

@@ -1,0 +1,96 @@
+"""ctypes mirror of include/art_hip.h (structs, enums, prototypes).  Keep in sync with ART_ABI_VERSION."""
+import ctypes as C
+
+ART_ABI_VERSION = 1
+
+ART_OK = 0
+ART_ERR_BAD_ARG = -1
+ART_ERR_UNSUPPORTED = -2
+ART_ERR_HIP = -3
+ART_ERR_NO_DEVICE = -4
+
+# enum ArtOpticKind
+ART_PLANE, ART_SPHERE, ART_PARABOLA, ART_TORUS, ART_ELLIPSOID, ART_CYLINDER, ART_MASK = range(7)
+# enum ArtSupportKind
+ART_SUP_ROUND, ART_SUP_ROUNDHOLE, ART_SUP_RECT, ART_SUP_RECTHOLE, ART_SUP_RECTRECTHOLE = range(5)
+
+ART_FLAG_PERTURBED_NORMAL = 1
+
+ART_ZERN_MAX_ORDER = 12
+ART_ZERN_NCOEF = (ART_ZERN_MAX_ORDER + 1) * (ART_ZERN_MAX_ORDER + 2) // 2
+ART_ZERN_STRIDE = 2 + ART_ZERN_NCOEF
+ART_MAX_DEFECTS = 4
+
+c_double_p = C.POINTER(C.c_double)
+c_uint8_p = C.POINTER(C.c_uint8)
+
+
+class ArtElementDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("support_kind", C.c_int32),
+        ("n_defects", C.c_int32),
+        ("flags", C.c_uint32),
+        ("fwd", C.c_double * 9),
+        ("bwd", C.c_double * 9),
+        ("pos", C.c_double * 3),
+        ("centre", C.c_double * 3),
+        ("sp", C.c_double * 6),
+        ("mp", C.c_double * 4),
+        ("zern", C.c_void_p),
+    ]
+
+
+class ArtBundleView(C.Structure):
+    _fields_ = [
+        ("ox", C.c_void_p), ("oy", C.c_void_p), ("oz", C.c_void_p),
+        ("dx", C.c_void_p), ("dy", C.c_void_p), ("dz", C.c_void_p),
+        ("path", C.c_void_p),
+        ("incidence", C.c_void_p),
+        ("alive", C.c_void_p),
+    ]
+
+
+class ArtDetectorDesc(C.Structure):
+    _fields_ = [
+        ("centre", C.c_double * 3),
+        ("normal", C.c_double * 3),
+        ("rot", C.c_double * 9),
+    ]
+
+
+# name -> (restype, argtypes); the loader checks every symbol exists (tests/test_abi.py does too)
+PROTOTYPES = {
+    "art_abi_version": (C.c_int, []),
+    "art_last_error": (C.c_char_p, []),
+    "art_device_count": (C.c_int, []),
+    "art_trace_element": (C.c_int, [C.POINTER(ArtElementDesc), C.POINTER(ArtBundleView), C.POINTER(ArtBundleView),
+                                    C.c_int64, C.c_void_p]),
+    "art_trace_chain": (C.c_int, [C.POINTER(ArtElementDesc), C.c_int32, C.POINTER(ArtBundleView),
+                                  C.POINTER(ArtBundleView), C.c_int64, C.c_void_p]),
+    "art_detector": (C.c_int, [C.POINTER(ArtDetectorDesc), C.POINTER(ArtBundleView), C.c_int64, C.c_void_p,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "art_reduce_scratch_doubles": (C.c_int64, []),
+    "art_detector_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "art_detector_moments": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                       C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "art_bundle_sums": (C.c_int, [C.POINTER(ArtBundleView), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
+    "art_compact_scratch_ints": (C.c_int64, [C.c_int64]),
+    "art_compact": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "art_make_source": (C.c_int, [C.c_int32, C.c_double, c_double_p, c_double_p, C.c_int64, C.c_int64, C.c_int64,
+                                  C.POINTER(ArtBundleView), C.c_void_p]),
+}
+
+
+def bind(lib, prefix="art_"):
+    """Attach restype/argtypes for every exported entry point; raises AttributeError if one is missing."""
+    fns = {}
+    for name, (res, args) in PROTOTYPES.items():
+        sym = name if prefix == "art_" else prefix + name[len("art_"):]
+        f = getattr(lib, sym)
+        f.restype = res
+        f.argtypes = args
+        fns[name] = f
+    return fns

@@ -1,0 +1,151 @@
+"""Loader of libart_hip.so -- the only compute backend of this package.
+
+There is NO CPU fallback: if the shared library was not built (`python -c "import __graft_entry__ as g;
+g.build()"`), or no gfx950 device is visible, the first attempt to trace rays raises RuntimeError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libart_hip.so")
+
+_BACKEND = None
+
+
+class ArtError(RuntimeError):
+    pass
+
+
+class HipBackend:
+    """Thin typed wrapper: torch tensors in, C-ABI calls out.  All calls are asynchronous on torch's
+    current HIP stream of the bundle's device."""
+
+    name = "hip"
+
+    def __init__(self, path=LIB_PATH):
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} not found: the HIP extension has not been built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback.")
+        self.lib = C.CDLL(path)
+        self.fn = _abi.bind(self.lib)
+        v = self.fn["art_abi_version"]()
+        if v != _abi.ART_ABI_VERSION:
+            raise RuntimeError(f"libart_hip.so ABI version {v} != expected {_abi.ART_ABI_VERSION}: rebuild it")
+        if not torch.cuda.is_available():
+            raise RuntimeError("No HIP device visible to PyTorch: ray tracing needs an MI355X (gfx950). "
+                               "There is no CPU fallback.")
+        n = self.fn["art_device_count"]()
+        if n <= 0:
+            raise RuntimeError("libart_hip.so found no gfx950 device (art_device_count() = %d: %s)"
+                               % (n, self.last_error()))
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self._scratch = {}
+
+    # ------------------------------------------------------------------ helpers
+    def last_error(self):
+        return self.fn["art_last_error"]().decode("utf-8", "replace")
+
+    def check(self, rc, what):
+        if rc != 0:
+            raise ArtError(f"{what} failed with code {rc}: {self.last_error()}")
+
+    def stream_ptr(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def synchronize(self):
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def empty(self, n, dtype=torch.float64):
+        return torch.empty(int(n), dtype=dtype, device=self.device)
+
+    def zeros(self, n, dtype=torch.float64):
+        return torch.zeros(int(n), dtype=dtype, device=self.device)
+
+    def from_numpy(self, a, dtype=None):
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.to(self.device)
+
+    def scratch(self, key, n, dtype):
+        t = self._scratch.get(key)
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = torch.empty(int(max(n, 1)), dtype=dtype, device=self.device)
+            self._scratch[key] = t
+        return t
+
+    # ------------------------------------------------------------------ entry points
+    def trace_element(self, desc, view_in, view_out, n):
+        self.check(self.fn["art_trace_element"](C.byref(desc), C.byref(view_in), C.byref(view_out), n,
+                                                self.stream_ptr()), "art_trace_element")
+
+    def trace_chain(self, descs, view_in, views_out, n):
+        m = len(descs)
+        darr = (_abi.ArtElementDesc * m)(*descs)
+        varr = (_abi.ArtBundleView * m)(*views_out)
+        self.check(self.fn["art_trace_chain"](darr, m, C.byref(view_in), varr, n, self.stream_ptr()),
+                   "art_trace_chain")
+
+    def detector(self, ddesc, view, n, p3=None, XY=None, opl=None):
+        p = [t.data_ptr() for t in p3] if p3 is not None else [None, None, None]
+        xy = [t.data_ptr() for t in XY] if XY is not None else [None, None]
+        o = opl.data_ptr() if opl is not None else None
+        self.check(self.fn["art_detector"](C.byref(ddesc), C.byref(view), n, p[0], p[1], p[2], xy[0], xy[1], o,
+                                           self.stream_ptr()), "art_detector")
+
+    def _red_scratch(self):
+        return self.scratch("red", self.fn["art_reduce_scratch_doubles"](), torch.float64)
+
+    def detector_stats(self, alive, X, Y, opl, w, n):
+        out = self.empty(16)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        self.check(self.fn["art_detector_stats"](alive.data_ptr(), ptr(X), ptr(Y), ptr(opl), ptr(w), n,
+                                                 self._red_scratch().data_ptr(), out.data_ptr(), self.stream_ptr()),
+                   "art_detector_stats")
+        return out.cpu().numpy()
+
+    def detector_moments(self, alive, X, Y, opl, w, n, cx, cy, co):
+        out = self.empty(8)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        self.check(self.fn["art_detector_moments"](alive.data_ptr(), ptr(X), ptr(Y), ptr(opl), ptr(w), n,
+                                                   float(cx), float(cy), float(co), self._red_scratch().data_ptr(),
+                                                   out.data_ptr(), self.stream_ptr()), "art_detector_moments")
+        return out.cpu().numpy()
+
+    def bundle_sums(self, view, w, n):
+        out = self.empty(8)
+        self.check(self.fn["art_bundle_sums"](C.byref(view), None if w is None else w.data_ptr(), n,
+                                              self._red_scratch().data_ptr(), out.data_ptr(), self.stream_ptr()),
+                   "art_bundle_sums")
+        return out.cpu().numpy()
+
+    def compact(self, alive, n):
+        """Returns (idx tensor int64 [count], count)."""
+        ints = self.fn["art_compact_scratch_ints"](n)
+        sc = self.scratch("compact", ints, torch.int32)
+        idx = torch.empty(int(max(n, 1)), dtype=torch.int64, device=self.device)
+        cnt = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.check(self.fn["art_compact"](alive.data_ptr(), n, sc.data_ptr(), idx.data_ptr(), cnt.data_ptr(),
+                                          self.stream_ptr()), "art_compact")
+        c = int(cnt.cpu().item())
+        return idx[:c], c
+
+    def make_source(self, kind, size, rot, S, first, n, n_total, view):
+        r = (C.c_double * 9)(*[float(v) for v in np.asarray(rot).reshape(9)])
+        s = (C.c_double * 3)(*[float(v) for v in np.asarray(S).reshape(3)])
+        self.check(self.fn["art_make_source"](kind, float(size), r, s, first, n, n_total, C.byref(view),
+                                              self.stream_ptr()), "art_make_source")
+
+
+def get_backend():
+    """The process-wide backend; created on first use, raises loudly if the HIP path is unavailable."""
+    global _BACKEND
+    if _BACKEND is None:
+        _BACKEND = HipBackend()
+    return _BACKEND

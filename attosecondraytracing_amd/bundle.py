@@ -1,0 +1,218 @@
+"""RayBundle: the structure-of-arrays ray bundle that replaces the reference's `list[Ray]`
+(ART/ModuleOpticalRay.py; survivor lists of ART/ModuleMirror.py:928-939).
+
+Layout in HBM: one contiguous fp64 tensor `data[8, n]` (rows ox, oy, oz, dx, dy, dz, path, incidence; every
+row is a unit-stride stream for the kernels) plus `alive[n]` (uint8).  n is the number of SOURCE rays and
+stays fixed along a chain: slot i of every bundle is source ray i, so `number`, `intensity` and
+`wavelength` are shared, not copied.  The list-of-survivors view the reference API exposes
+(`len()`, indexing, iteration in source order) is produced lazily by a stable device compaction."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+from . import _lib
+from .ModuleOpticalRay import Ray
+
+ROW_OX, ROW_OY, ROW_OZ, ROW_DX, ROW_DY, ROW_DZ, ROW_PATH, ROW_INC = range(8)
+
+
+class RayBundle:
+    def __init__(self, data, alive, number=None, intensity=None, wavelength=None, parent=None, backend=None):
+        self.data = data              # torch float64 [8, n]
+        self.alive = alive            # torch uint8 [n]
+        self.number = number          # torch int64 [n] or None (= slot index)
+        self.intensity = intensity    # torch float64 [n] or None
+        self.wavelength = wavelength  # float or None (uniform, as every reference source produces)
+        self.parent = parent          # bundle this one was traced from (for Ray.path tuples)
+        self.backend = backend or _lib.get_backend()
+        self._index = None
+        self._count = None
+        self.version = 0              # bumped when the arrays are modified in place
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def allocate(cls, n, like=None, backend=None):
+        be = backend or (like.backend if like is not None else _lib.get_backend())
+        data = torch.empty((8, int(n)), dtype=torch.float64, device=be.device)
+        alive = torch.empty(int(n), dtype=torch.uint8, device=be.device)
+        if like is not None:
+            return cls(data, alive, like.number, like.intensity, like.wavelength, like, be)
+        return cls(data, alive, backend=be)
+
+    @classmethod
+    def from_arrays(cls, point, vector, number=None, intensity=None, wavelength=None, path0=None, backend=None):
+        be = backend or _lib.get_backend()
+        point = np.ascontiguousarray(point, dtype=np.float64).reshape(-1, 3)
+        vector = np.ascontiguousarray(vector, dtype=np.float64).reshape(-1, 3)
+        vector = vector / np.linalg.norm(vector, axis=1)[:, None]          # Ray.vector setter
+        n = point.shape[0]
+        host = np.empty((8, n), dtype=np.float64)
+        host[0:3] = point.T
+        host[3:6] = vector.T
+        host[6] = 0.0 if path0 is None else path0
+        host[7] = np.nan
+        data = be.from_numpy(host)
+        alive = torch.ones(n, dtype=torch.uint8, device=be.device)
+        num = None if number is None else be.from_numpy(np.asarray(number, dtype=np.int64))
+        inten = None if intensity is None else be.from_numpy(np.asarray(intensity, dtype=np.float64))
+        return cls(data, alive, num, inten, wavelength, None, be)
+
+    @classmethod
+    def from_ray_list(cls, rays, backend=None):
+        rays = list(rays)
+        pts = np.array([r.point for r in rays], dtype=np.float64).reshape(-1, 3)
+        vec = np.array([r.vector for r in rays], dtype=np.float64).reshape(-1, 3)
+        nums = [r.number for r in rays]
+        number = None if any(v is None for v in nums) else np.array(nums, dtype=np.int64)
+        ints = [r.intensity for r in rays]
+        intensity = None if any(v is None for v in ints) else np.array(ints, dtype=np.float64)
+        path0 = np.array([float(np.sum(r.path)) for r in rays])
+        wl = rays[0].wavelength if rays else None
+        return cls.from_arrays(pts, vec, number, intensity, wl, path0, backend)
+
+    # ------------------------------------------------------------------ raw access
+    @property
+    def n_slots(self):
+        return int(self.alive.numel())
+
+    def view(self):
+        p = self.data.data_ptr()
+        stride = self.n_slots * 8
+        v = _abi.ArtBundleView()
+        v.ox, v.oy, v.oz = p, p + stride, p + 2 * stride
+        v.dx, v.dy, v.dz = p + 3 * stride, p + 4 * stride, p + 5 * stride
+        v.path, v.incidence = p + 6 * stride, p + 7 * stride
+        v.alive = self.alive.data_ptr()
+        return v
+
+    def touch(self):
+        self.version += 1
+        self._index = None
+        self._count = None
+
+    def index(self):
+        """int64 tensor of the slots of surviving rays, in source order."""
+        if self._index is None:
+            self._index, self._count = self.backend.compact(self.alive, self.n_slots)
+        return self._index
+
+    def __len__(self):
+        if self._count is None:
+            self.index()
+        return self._count
+
+    # ------------------------------------------------------------------ survivor arrays on the host
+    def _gather(self, row):
+        return self.data[row].index_select(0, self.index()).cpu().numpy()
+
+    def points(self):
+        idx = self.index()
+        return self.data[0:3].index_select(1, idx).cpu().numpy().T.copy()
+
+    def vectors(self):
+        idx = self.index()
+        return self.data[3:6].index_select(1, idx).cpu().numpy().T.copy()
+
+    def paths_total(self):
+        return self._gather(ROW_PATH)
+
+    def incidences(self):
+        return self._gather(ROW_INC)
+
+    def numbers(self):
+        idx = self.index()
+        if self.number is None:
+            return idx.cpu().numpy()
+        return self.number.index_select(0, idx).cpu().numpy()
+
+    def intensities(self):
+        if self.intensity is None:
+            return None
+        return self.intensity.index_select(0, self.index()).cpu().numpy()
+
+    def path_segments(self):
+        """(m, k+1) per-segment lengths of the survivors: the reference's Ray.path tuples
+        (ModuleMirror.py:904, ModuleMask.py:100), rebuilt from the cumulative paths along the parent links."""
+        idx = self.index()
+        cum = []
+        b = self
+        while b is not None:
+            cum.append(b.data[ROW_PATH].index_select(0, idx).cpu().numpy())
+            b = b.parent
+        cum = cum[::-1]
+        segs = [cum[0]] + [cum[j] - cum[j - 1] for j in range(1, len(cum))]
+        return np.stack(segs, axis=1)
+
+    # ------------------------------------------------------------------ list-of-Ray protocol
+    def _ray_at(self, slots):
+        slots = np.atleast_1d(np.asarray(slots, dtype=np.int64))
+        st = torch.from_numpy(slots).to(self.backend.device)
+        cols = self.data.index_select(1, st).cpu().numpy()
+        nums = slots if self.number is None else self.number.index_select(0, st).cpu().numpy()
+        ints = None if self.intensity is None else self.intensity.index_select(0, st).cpu().numpy()
+        cum = []
+        b = self
+        while b is not None:
+            cum.append(b.data[ROW_PATH].index_select(0, st).cpu().numpy())
+            b = b.parent
+        cum = cum[::-1]
+        rays = []
+        for j in range(len(slots)):
+            path = (float(cum[0][j]),) + tuple(float(cum[k][j] - cum[k - 1][j]) for k in range(1, len(cum)))
+            inc = cols[ROW_INC, j]
+            rays.append(Ray(cols[0:3, j].copy(), cols[3:6, j].copy(), path, int(nums[j]), self.wavelength,
+                            None if np.isnan(inc) else np.float64(inc),
+                            None if ints is None else np.float64(ints[j])))
+        return rays
+
+    def __getitem__(self, i):
+        idx = self.index()
+        if isinstance(i, slice):
+            sel = idx[i].cpu().numpy()
+            return self._ray_at(sel) if len(sel) else []
+        m = len(self)
+        if i < 0:
+            i += m
+        if not 0 <= i < m:
+            raise IndexError("list index out of range")
+        return self._ray_at([int(idx[i].item())])[0]
+
+    def __iter__(self):
+        idx = self.index().cpu().numpy()
+        for lo in range(0, len(idx), 4096):
+            for r in self._ray_at(idx[lo:lo + 4096]):
+                yield r
+
+    def subset(self, positions):
+        """New bundle in which only the survivors at the given positions stay alive (replaces
+        `np.random.choice(RayList, k)`, ARTmain.py:168-171)."""
+        idx = self.index()
+        pos = torch.as_tensor(np.asarray(positions, dtype=np.int64), device=self.backend.device)
+        alive = torch.zeros_like(self.alive)
+        alive[idx.index_select(0, pos)] = 1
+        return RayBundle(self.data, alive, self.number, self.intensity, self.wavelength, self.parent, self.backend)
+
+    def transformed(self, M, T, rotate_points=True):
+        """Affine map of the whole bundle (scene-manipulation helper, not on the tracing path):
+        point' = M point + T (or point + T), vector' = M vector."""
+        M = torch.as_tensor(np.asarray(M, dtype=np.float64), device=self.backend.device)
+        Tt = torch.as_tensor(np.asarray(T, dtype=np.float64), device=self.backend.device)
+        data = self.data.clone()
+        if rotate_points:
+            data[0:3] = M @ self.data[0:3]
+        data[0:3] += Tt[:, None]
+        data[3:6] = M @ self.data[3:6]
+        return RayBundle(data, self.alive.clone(), self.number, self.intensity, self.wavelength, self.parent,
+                         self.backend)
+
+    def copy(self):
+        return RayBundle(self.data.clone(), self.alive.clone(), self.number, self.intensity, self.wavelength,
+                         self.parent, self.backend)
+
+    def __deepcopy__(self, memo):
+        return self.copy()
+
+    def __hash__(self):
+        return hash((id(self.data), self.version))

@@ -1,0 +1,509 @@
+// art_device.h -- per-ray math of the ART hot path, one ray per lane.
+//
+// Written for gfx950 (wave64, fp64 VALU); the same functions compile with g++ (-DART_HOST_TWIN) into the
+// CPU twin that tests/ use to check the kernel math in a container without a GPU (oracle/twin/).
+// Every function cites the reference lines whose result it reproduces (paths relative to /root/reference).
+//
+// Differences from the reference that are deliberate (all far inside the 1e-10 parity tolerance):
+//   * the four per-ray frame rotations of ModuleProcessing.py:289-295/:306-309 are two constant 3x3 maps;
+//   * quadrics are solved in closed form (cancellation-free) instead of np.roots;
+//   * the torus is NOT solved through its expanded quartic (coefficients ~1e15): candidates with
+//     z < -R lie on the outer half-tube, which is part of the boundary of the convex body
+//     K = disk(R) (+) ball(r); a line meets it at most twice, and H(t) = dist(P(t), disk)^2 - r^2 is
+//     convex in t, so monotone Newton from the bounding sphere finds exactly the reference's candidates.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/art_hip.h"
+
+#if defined(__HIPCC__) && !defined(ART_HOST_TWIN)
+#define ART_HD __host__ __device__ __forceinline__
+#define ART_DEVICE_CODE 1
+#else
+#define ART_HD inline
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// wave64 ballot: keep the whole wavefront in the Newton loop until every lane has converged
+#define ART_WAVE_ANY(pred) (__ballot(pred) != 0ull)
+#else
+#define ART_WAVE_ANY(pred) (pred)
+#endif
+
+namespace art {
+
+struct Ray {
+  double ox, oy, oz, dx, dy, dz, path, inc;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// small helpers
+ART_HD double dot3(double ax, double ay, double az, double bx, double by, double bz) {
+  return fma(ax, bx, fma(ay, by, az * bz));
+}
+
+ART_HD void mat3_apply(const double* M, double x, double y, double z, double& rx, double& ry, double& rz) {
+  rx = fma(M[0], x, fma(M[1], y, M[2] * z));
+  ry = fma(M[3], x, fma(M[4], y, M[5] * z));
+  rz = fma(M[6], x, fma(M[7], y, M[8] * z));
+}
+
+// Kahan angle between two UNIT vectors, ART/ModuleGeometry.py:40-44: 2*atan2(|U-V|, |U+V|).
+// (the reference scales by the two norms first; they are 1 +- 1e-16 here.)
+ART_HD double kahan_angle_unit(double ux, double uy, double uz, double vx, double vy, double vz) {
+  double ax = ux - vx, ay = uy - vy, az = uz - vz;
+  double bx = ux + vx, by = uy + vy, bz = uz + vz;
+  double a2 = dot3(ax, ay, az, ax, ay, az);
+  double b2 = dot3(bx, by, bz, bx, by, bz);
+  return 2.0 * atan2(sqrt(a2), sqrt(b2));
+}
+
+// ART/ModuleGeometry.py:249-268, ART/ModuleSupport.py:68-70,:151-155,:228-230,:322-326,:431-435
+ART_HD bool in_disk(double R, double x, double y) { return fma(x, x, y * y) <= R * R; }
+ART_HD bool in_rect(double X, double Y, double x, double y) {
+  return fabs(x) <= fabs(X * 0.5) && fabs(y) <= fabs(Y * 0.5);
+}
+ART_HD bool include_support(int kind, const double* sp, double x, double y) {
+  switch (kind) {
+    case ART_SUP_ROUND: return in_disk(sp[0], x, y);
+    case ART_SUP_ROUNDHOLE: return in_disk(sp[0], x, y) && !in_disk(sp[1], x - sp[2], y - sp[3]);
+    case ART_SUP_RECT: return in_rect(sp[0], sp[1], x, y);
+    case ART_SUP_RECTHOLE: return in_rect(sp[0], sp[1], x, y) && !in_disk(sp[2], x - sp[3], y - sp[4]);
+    default: return in_rect(sp[0], sp[1], x, y) && !in_rect(sp[2], sp[3], x - sp[4], y - sp[5]);
+  }
+}
+
+// Real roots of a t^2 + b t + c (SolverQuadratic, ART/ModuleGeometry.py:80-91).  np.roots drops an exactly
+// zero leading coefficient (-> one root -c/b); for tiny a it returns the accurate small root plus a huge
+// one -- reproduced by the cancellation-free form.  Returns the number of real roots (0, 1 or 2).
+ART_HD int quadratic_roots(double a, double b, double c, double& t1, double& t2) {
+  if (a == 0.0) {
+    if (b == 0.0) return 0;
+    t1 = -c / b;
+    t2 = t1;
+    return 1;
+  }
+  double disc = fma(b, b, -4.0 * a * c);
+  if (!(disc >= 0.0)) return 0;
+  double q = -0.5 * (b + copysign(sqrt(disc), b));
+  if (q == 0.0) {  // b == 0 and c == 0: double root at 0
+    t1 = 0.0;
+    t2 = 0.0;
+    return 2;
+  }
+  t1 = q / a;
+  t2 = c / q;
+  return 2;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Zernike defects (ART/ModuleDefects.py:149-174; recurrences ART/recursive_zernike_generator.py:35-254).
+// Evaluates h = sum c_nm Z_nm, gx = sum c_nm dZ_nm/dx, gy = sum c_nm dZ_nm/dy at (x, y) with x, y already
+// divided by R.  Rows n-1 and n-2 live in registers (loops fully unrolled for the template order N).
+template <int N>
+ART_HD void zernike_eval(const double* coef, double x, double y, double& val, double& gx, double& gy) {
+  double Zp[N + 1], Zpp[N + 1], GXpp[N + 1], GYpp[N + 1], GXp[N + 1], GYp[N + 1];
+#pragma unroll
+  for (int i = 0; i <= N; ++i) Zp[i] = Zpp[i] = GXpp[i] = GYpp[i] = GXp[i] = GYp[i] = 0.0;
+  // seeds (:51-62): Z00 = 1, Z10 = y, Z11 = x
+  Zpp[0] = 1.0;
+  Zp[0] = y;
+  Zp[1] = x;
+  GXp[1] = 1.0;
+  GYp[0] = 1.0;
+  val = coef[0] + coef[1] * y + coef[2] * x;
+  gx = coef[2];
+  gy = coef[1];
+#pragma unroll
+  for (int n = 2; n <= N; ++n) {
+    double Zn[N + 1], GXn[N + 1], GYn[N + 1];
+#pragma unroll
+    for (int m = 0; m <= N; ++m) {
+      if (m > n) {
+        Zn[m] = GXn[m] = GYn[m] = 0.0;
+        continue;
+      }
+      double z, dx_, dy_;
+      const double dn = (double)n;
+      if (m == 0) {  // :79-95
+        z = x * Zp[0] + y * Zp[n - 1];
+        dx_ = dn * Zp[0];
+        dy_ = dn * Zp[n - 1];
+      } else if (m == n) {  // :97-110
+        z = x * Zp[n - 1] - y * Zp[0];
+        dx_ = dn * Zp[n - 1];
+        dy_ = -1.0 * dn * Zp[0];
+      } else if ((n % 2 != 0) && (2 * m == n - 1)) {  // :112-145
+        z = y * Zp[n - 1 - m] + x * Zp[m - 1] - y * Zp[n - m] - Zpp[m - 1];
+        dx_ = dn * Zp[m - 1] + GXpp[m - 1];
+        dy_ = dn * Zp[n - 1 - m] - dn * Zp[n - m] + GYpp[m - 1];
+      } else if ((n % 2 != 0) && (2 * m == n + 1)) {  // :147-177
+        z = x * Zp[m] + y * Zp[n - 1 - m] + x * Zp[m - 1] - Zpp[m - 1];
+        dx_ = dn * Zp[m] + dn * Zp[m - 1] + GXpp[m - 1];
+        dy_ = dn * Zp[n - 1 - m] + GYpp[m - 1];
+      } else if ((n % 2 == 0) && (2 * m == n)) {  // :179-209
+        z = 2.0 * x * Zp[m] + 2.0 * y * Zp[m - 1] - Zpp[m - 1];
+        dx_ = 2.0 * dn * Zp[m] + GXpp[m - 1];
+        dy_ = 2.0 * dn * Zp[n - 1 - m] + GYpp[m - 1];
+      } else {  // :211-246
+        z = x * Zp[m] + y * Zp[n - 1 - m] + x * Zp[m - 1] - y * Zp[n - m] - Zpp[m - 1];
+        dx_ = dn * Zp[m] + dn * Zp[m - 1] + GXpp[m - 1];
+        dy_ = dn * Zp[n - 1 - m] - dn * Zp[n - m] + GYpp[m - 1];
+      }
+      Zn[m] = z;
+      GXn[m] = dx_;
+      GYn[m] = dy_;
+      const double c = coef[n * (n + 1) / 2 + m];
+      val = fma(c, z, val);
+      gx = fma(c, dx_, gx);
+      gy = fma(c, dy_, gy);
+    }
+#pragma unroll
+    for (int m = 0; m <= N; ++m) {
+      Zpp[m] = Zp[m];
+      GXpp[m] = GXp[m];
+      GYpp[m] = GYp[m];
+      Zp[m] = Zn[m];
+      GXp[m] = GXn[m];
+      GYp[m] = GYn[m];
+    }
+  }
+}
+
+// table layout: art_hip.h (ART_ZERN_STRIDE per defect).  x, y relative to the mirror centre, in mm.
+ART_HD void zernike_defect(const double* tab, double px, double py, double& h, double& gX, double& gY) {
+  const double R = tab[0];
+  const int order = (int)tab[1];
+  const double* coef = tab + 2;
+  const double x = px / R, y = py / R;
+  double v, gx, gy;
+  if (order <= 2) zernike_eval<2>(coef, x, y, v, gx, gy);
+  else if (order <= 4) zernike_eval<4>(coef, x, y, v, gx, gy);
+  else if (order <= 6) zernike_eval<6>(coef, x, y, v, gx, gy);
+  else if (order <= 8) zernike_eval<8>(coef, x, y, v, gx, gy);
+  else if (order <= 10) zernike_eval<10>(coef, x, y, v, gx, gy);
+  else zernike_eval<12>(coef, x, y, v, gx, gy);
+  h = v;          // get_offset  :168-174
+  gX = gx / R;    // get_normal  :159-166 returns (-gX, -gY, 1)
+  gY = gy / R;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// undeformed normals, get_normal of each mirror class
+template <int KIND>
+ART_HD void base_normal(const ArtElementDesc& e, double x, double y, double z, double& nx, double& ny, double& nz) {
+  if (KIND == ART_PLANE || KIND == ART_MASK) {  // ModuleMirror.py:84-87, ModuleMask.py:63-66
+    nx = 0.0; ny = 0.0; nz = 1.0;
+    return;
+  }
+  double gx, gy, gz;
+  if (KIND == ART_SPHERE) {  // :180-183  normalize(-P)
+    gx = -x; gy = -y; gz = -z;
+  } else if (KIND == ART_PARABOLA) {  // :349-355  normalize(-x, -y, p)
+    gx = -x; gy = -y; gz = e.mp[0];
+  } else if (KIND == ART_TORUS) {  // :480-498  -grad of the quartic form, 4x(S + A) - 8xR^2 = 4x(S - R^2 - r^2)
+    const double R2 = e.mp[0] * e.mp[0], r2 = e.mp[1] * e.mp[1];
+    const double S = dot3(x, y, z, x, y, z);
+    const double kxz = S - R2 - r2, ky = S + R2 - r2;
+    gx = -x * kxz; gy = -y * ky; gz = -z * kxz;
+  } else if (KIND == ART_ELLIPSOID) {  // :685-693
+    const double ia2 = 1.0 / (e.mp[0] * e.mp[0]), ib2 = 1.0 / (e.mp[1] * e.mp[1]);
+    gx = -x * ia2; gy = -y * ib2; gz = -z * ib2;
+  } else {  // cylinder :846-849
+    gx = 0.0; gy = -y; gz = -z;
+  }
+  const double inv = 1.0 / sqrt(dot3(gx, gy, gz, gx, gy, gz));
+  nx = gx * inv; ny = gy * inv; nz = gz * inv;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// torus.  The reference's quartic (ModuleMirror.py:450-465) is the product of two factors,
+//   [(rho - R)^2 + y^2 - r^2] * [(rho + R)^2 + y^2 - r^2] = 0,   rho = sqrt(x^2 + z^2):
+// the torus proper and, only when r > R, a spurious inner "lemon" rho = sqrt(r^2 - y^2) - R that np.roots
+// also returns (and that the reference therefore reflects off).  Both are handled through convex functions
+// of the ray parameter:
+//   SIDE = -1:  H(t) = dist(P, disk(R))^2 - r^2          (body K = disk(R) (+) ball(r); outer half-tube)
+//   SIDE = +1:  G(t) = maxdist(P, circle(R))^2 - r^2     (body L = intersection of balls B(c, r), c on the circle)
+template <int SIDE>
+ART_HD void torus_F(double R, double r2, double x, double y, double z, double ux, double uy, double uz,
+                    double& F, double& dF) {
+  const double rho2 = fma(x, x, z * z);
+  const double rho = sqrt(rho2);
+  if (SIDE < 0) {
+    const double a = rho - R;
+    if (a > 0.0) {
+      F = fma(a, a, fma(y, y, -r2));
+      dF = 2.0 * fma(a / rho, fma(x, ux, z * uz), y * uy);
+    } else {  // above/below the flat disk: distance is |y|
+      F = fma(y, y, -r2);
+      dF = 2.0 * y * uy;
+    }
+  } else {
+    const double a = rho + R;
+    F = fma(a, a, fma(y, y, -r2));
+    const double drho = (rho > 0.0) ? fma(x, ux, z * uz) / rho : 0.0;
+    dF = 2.0 * fma(a, drho, y * uy);
+  }
+}
+
+// Monotone Newton on the convex F from `t` towards the root on the side given by `dir`
+// (+1: start right of the exit root, move left; -1: start left of the entry root, move right).
+// Returns true and the root in t, or false when the line misses the body.
+template <int SIDE>
+ART_HD bool torus_newton(double R, double r2, double Ax, double Ay, double Az, double ux, double uy, double uz,
+                         double dir, bool want, double& t) {
+  bool active = want, found = false;
+  int it = 0;
+  while (ART_WAVE_ANY(active)) {
+    if (active) {
+      double F, dF;
+      torus_F<SIDE>(R, r2, fma(t, ux, Ax), fma(t, uy, Ay), fma(t, uz, Az), ux, uy, uz, F, dF);
+      if (!(dF * dir > 0.0)) {
+        // slope has the wrong sign: we are past the minimum of a convex function without having met a
+        // root on this side -> no intersection
+        active = false;
+      } else {
+        const double dt = F / dF;
+        t -= dt;
+        if (fabs(dt) <= 1e-9 * (1.0 + fabs(t)) || ++it >= 60) {
+          // quadratic convergence: the step just taken leaves an error ~ (dt^2) * F''/(2F') << 1 ulp
+          found = true;
+          active = false;
+        }
+      }
+    }
+  }
+  return found;
+}
+
+// Positive-side roots (entry, exit) of the line with one of the two convex bodies; `rb` = radius of a sphere
+// about the origin that contains the body (R + r for K, r - R for L).  Returns the number of roots found.
+template <int SIDE>
+ART_HD int torus_body_roots(double R, double r2, double rb, double Ax, double Ay, double Az, double ux, double uy,
+                            double uz, double& ta, double& tb) {
+  const double b = 2.0 * dot3(Ax, Ay, Az, ux, uy, uz);
+  const double uu = dot3(ux, uy, uz, ux, uy, uz);
+  const double c = dot3(Ax, Ay, Az, Ax, Ay, Az) - rb * rb;
+  const double disc = fma(b, b, -4.0 * uu * c);
+  bool any = disc >= 0.0;
+  const double sq = any ? sqrt(disc) : 0.0;
+  const double ts1 = (-b - sq) / (2.0 * uu), ts2 = (-b + sq) / (2.0 * uu);
+  any = any && (ts2 > 1e-12);
+  double F0, dF0;
+  torus_F<SIDE>(R, r2, Ax, Ay, Az, ux, uy, uz, F0, dF0);
+  const bool origin_inside = F0 < 0.0;
+  // origin outside the body and moving away from it: both roots (if any) are behind the origin
+  any = any && (origin_inside || dF0 < 0.0);
+  // exit root: start just outside the sphere exit, walk left
+  double t_out = ts2 + 1e-9 * (1.0 + fabs(ts2));
+  const bool has_out = torus_newton<SIDE>(R, r2, Ax, Ay, Az, ux, uy, uz, +1.0, any, t_out);
+  // entry root only when the origin is outside the body: start at max(ts1, 0), walk right
+  double t_in = (ts1 > 0.0 ? ts1 - 1e-9 * (1.0 + fabs(ts1)) : 0.0);
+  const bool has_in = torus_newton<SIDE>(R, r2, Ax, Ay, Az, ux, uy, uz, -1.0, any && has_out && !origin_inside, t_in);
+  int n = 0;
+  if (has_in) { ta = t_in; n = 1; }
+  if (has_out) { if (n) tb = t_out; else ta = t_out; ++n; }
+  return n;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// `_get_intersection` of the undeformed optic in the optic frame.  A = origin, u = unit direction.
+// Returns hit and the ray parameter t (P = A + t u).
+template <int KIND>
+ART_HD bool intersect(const ArtElementDesc& e, double Ax, double Ay, double Az, double ux, double uy, double uz,
+                      double& t_hit) {
+  const int sk = e.support_kind;
+  if (KIND == ART_PLANE || KIND == ART_MASK) {
+    // ModuleMirror.py:73-82 (t > 0, no epsilon) ; ModuleMask.py:51-61 (passes where the support is NOT hit)
+    const double t = -Az / uz;
+    const bool inside = include_support(sk, e.sp, fma(t, ux, Ax), fma(t, uy, Ay));
+    t_hit = t;
+    return (t > 0.0) && (KIND == ART_PLANE ? inside : !inside);
+  }
+  double tc[4] = {0.0, 0.0, 0.0, 0.0};
+  int nroots = 0;
+  if (KIND == ART_TORUS) {
+    const double R = e.mp[0], r = e.mp[1], r2 = r * r;
+    nroots = torus_body_roots<-1>(R, r2, R + r, Ax, Ay, Az, ux, uy, uz, tc[0], tc[1]);
+    if (r > R) {  // self-intersecting torus: the quartic's second factor has real roots too
+      double t2a = 0.0, t2b = 0.0;
+      const int n2 = torus_body_roots<+1>(R, r2, r - R, Ax, Ay, Az, ux, uy, uz, t2a, t2b);
+      if (n2 > 0) tc[nroots++] = t2a;
+      if (n2 > 1) tc[nroots++] = t2b;
+    }
+  } else {
+    double qa, qb, qc;
+    if (KIND == ART_SPHERE) {  // :163-170
+      qa = dot3(ux, uy, uz, ux, uy, uz);
+      qb = 2.0 * dot3(ux, uy, uz, Ax, Ay, Az);
+      qc = dot3(Ax, Ay, Az, Ax, Ay, Az) - e.mp[0] * e.mp[0];
+    } else if (KIND == ART_PARABOLA) {  // :334-336
+      const double p = e.mp[0];
+      qa = fma(ux, ux, uy * uy);
+      qb = 2.0 * fma(ux, Ax, uy * Ay) - 2.0 * p * uz;
+      qc = fma(Ax, Ax, Ay * Ay) - 2.0 * p * Az;
+    } else if (KIND == ART_ELLIPSOID) {  // :667-669
+      const double ia2 = 1.0 / (e.mp[0] * e.mp[0]), ib2 = 1.0 / (e.mp[1] * e.mp[1]);
+      qa = fma(uy, uy, uz * uz) * ib2 + ux * ux * ia2;
+      qb = 2.0 * (fma(uy, Ay, uz * Az) * ib2 + ux * Ax * ia2);
+      qc = fma(Ay, Ay, Az * Az) * ib2 + Ax * Ax * ia2 - 1.0;
+    } else {  // cylinder :831-833
+      qa = fma(uy, uy, uz * uz);
+      qb = 2.0 * fma(uy, Ay, uz * Az);
+      qc = fma(Ay, Ay, Az * Az) - e.mp[0] * e.mp[0];
+    }
+    nroots = quadratic_roots(qa, qb, qc, tc[0], tc[1]);
+  }
+  // KeepPositiveSolution (ModuleGeometry.py:110-120), side-of-surface rule and support test per class,
+  // then _IntersectionRayMirror (ModuleMirror.py:27-38): one candidate -> it, two -> the closer one,
+  // none or more than two -> the ray is lost.
+  int cnt = 0;
+  double best = 0.0;
+#pragma unroll
+  for (int k = 0; k < (KIND == ART_TORUS ? 4 : 2); ++k) {
+    if (k >= nroots) break;
+    const double t = tc[k];
+    if (!(t > 1e-12)) continue;
+    const double x = fma(t, ux, Ax), y = fma(t, uy, Ay), z = fma(t, uz, Az);
+    bool ok;
+    if (KIND == ART_SPHERE || KIND == ART_CYLINDER) ok = (z < 0.0) && include_support(sk, e.sp, x, y);      // :175, :841
+    else if (KIND == ART_PARABOLA) ok = include_support(sk, e.sp, x - e.centre[0], y - e.centre[1]);        // :344
+    else if (KIND == ART_ELLIPSOID) ok = (z < 0.0) && include_support(sk, e.sp, x - e.centre[0], y - e.centre[1]);  // :678
+    else ok = (z < -e.mp[0]) && include_support(sk, e.sp, x, y);                                              // :473
+    if (ok) {
+      // ClosestPoint (ModuleGeometry.py:138-147): strictly closer first candidate wins, otherwise the second
+      if (cnt == 0 || !(best < t)) best = t;
+      ++cnt;
+    }
+  }
+  t_hit = best;
+  return cnt == 1 || cnt == 2;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// One element acting on one ray (ART/ModuleProcessing.py:284-311 for a single ray).
+// Returns false when the ray is lost (missed the optic / blocked by the mask).
+template <int KIND, bool DEFECT>
+ART_HD bool trace_ray(const ArtElementDesc& e, const double* zern, Ray& r) {
+  // lab -> optic frame (:289-295)
+  double Ax, Ay, Az, ux, uy, uz;
+  mat3_apply(e.fwd, r.ox - e.pos[0], r.oy - e.pos[1], r.oz - e.pos[2], Ax, Ay, Az);
+  Ax += e.centre[0]; Ay += e.centre[1]; Az += e.centre[2];
+  mat3_apply(e.fwd, r.dx, r.dy, r.dz, ux, uy, uz);
+
+  double t;
+  if (!intersect<KIND>(e, Ax, Ay, Az, ux, uy, uz, t)) return false;
+  double Px = fma(t, ux, Ax), Py = fma(t, uy, Ay), Pz = fma(t, uz, Az);
+
+  double vx, vy, vz, inc;
+  if (KIND == ART_MASK) {
+    // _TransmitMaskRay, ModuleMask.py:93-108: direction unchanged, incidence = angle(v, ez)
+    vx = ux; vy = uy; vz = uz;
+    inc = kahan_angle_unit(ux, uy, uz, 0.0, 0.0, 1.0);
+  } else {
+    double nx, ny, nz;
+    base_normal<KIND>(e, Px, Py, Pz, nx, ny, nz);
+    if (DEFECT && e.n_defects > 0) {
+      // DeformedMirror._get_intersection, ModuleMirror.py:969-980: slide the hit point along the ray by
+      // h / cos(alpha), h = summed defect offsets at (P - centre), alpha = angle(-u, base normal)
+      double h = 0.0;
+      for (int d = 0; d < e.n_defects; ++d) {
+        double hd, gX, gY;
+        zernike_defect(zern + d * ART_ZERN_STRIDE, Px - e.centre[0], Py - e.centre[1], hd, gX, gY);
+        h += hd;
+      }
+      const double cosa = -dot3(ux, uy, uz, nx, ny, nz);
+      const double s = h / cosa;
+      t -= s;
+      Px = fma(-s, ux, Px); Py = fma(-s, uy, Py); Pz = fma(-s, uz, Pz);
+      base_normal<KIND>(e, Px, Py, Pz, nx, ny, nz);
+      if (e.flags & ART_FLAG_PERTURBED_NORMAL) {
+        // DeformedMirror.get_normal, ModuleMirror.py:952-961 with normal_add (ModuleGeometry.py:394-407):
+        // surface slopes add up
+        double gXs = -nx / nz, gYs = -ny / nz;
+        for (int d = 0; d < e.n_defects; ++d) {
+          double hd, gX, gY;
+          zernike_defect(zern + d * ART_ZERN_STRIDE, Px - e.centre[0], Py - e.centre[1], hd, gX, gY);
+          gXs += gX; gYs += gY;
+        }
+        const double inv = 1.0 / sqrt(fma(gXs, gXs, fma(gYs, gYs, 1.0)));
+        nx = -gXs * inv; ny = -gYs * inv; nz = inv;
+      }
+    }
+    // _ReflectionMirrorRay, ModuleMirror.py:878-906: v' = rot(n, pi) applied to -v  ==  v - 2 (n.v) n
+    const double dn = dot3(ux, uy, uz, nx, ny, nz);
+    vx = fma(-2.0 * dn, nx, ux); vy = fma(-2.0 * dn, ny, uy); vz = fma(-2.0 * dn, nz, uz);
+    inc = kahan_angle_unit(-ux, -uy, -uz, nx, ny, nz);
+  }
+  // optic -> lab frame (:306-309)
+  double ox, oy, oz, dx, dy, dz;
+  mat3_apply(e.bwd, Px - e.centre[0], Py - e.centre[1], Pz - e.centre[2], ox, oy, oz);
+  mat3_apply(e.bwd, vx, vy, vz, dx, dy, dz);
+  // Ray.vector setter renormalises (ModuleOpticalRay.py:85-90): one Newton step of 1/sqrt on |d|^2 ~ 1
+  const double s2 = dot3(dx, dy, dz, dx, dy, dz);
+  const double k = fma(-0.5, s2, 1.5);
+  r.ox = ox + e.pos[0]; r.oy = oy + e.pos[1]; r.oz = oz + e.pos[2];
+  r.dx = dx * k; r.dy = dy * k; r.dz = dz * k;
+  r.path += t;  // |P - A| with |u| = 1 (ModuleMirror.py:904, ModuleMask.py:100)
+  r.inc = inc;
+  return true;
+}
+
+// runtime dispatch on the optic kind (wave-uniform)
+template <bool DEFECT>
+ART_HD bool trace_ray_dyn(const ArtElementDesc& e, const double* zern, Ray& r) {
+  switch (e.kind) {
+    case ART_PLANE: return trace_ray<ART_PLANE, DEFECT>(e, zern, r);
+    case ART_SPHERE: return trace_ray<ART_SPHERE, DEFECT>(e, zern, r);
+    case ART_PARABOLA: return trace_ray<ART_PARABOLA, DEFECT>(e, zern, r);
+    case ART_TORUS: return trace_ray<ART_TORUS, DEFECT>(e, zern, r);
+    case ART_ELLIPSOID: return trace_ray<ART_ELLIPSOID, DEFECT>(e, zern, r);
+    case ART_CYLINDER: return trace_ray<ART_CYLINDER, DEFECT>(e, zern, r);
+    default: return trace_ray<ART_MASK, false>(e, zern, r);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Detector read-out for one ray (ART/ModuleDetector.py:191-234, :272-275; ModuleGeometry.py:48-57)
+ART_HD void detector_ray(const ArtDetectorDesc& d, const Ray& r, double& Ix, double& Iy, double& Iz, double& X,
+                         double& Y, double& opl) {
+  const double num = dot3(d.normal[0], d.normal[1], d.normal[2], d.centre[0] - r.ox, d.centre[1] - r.oy,
+                          d.centre[2] - r.oz);
+  const double den = dot3(r.dx, r.dy, r.dz, d.normal[0], d.normal[1], d.normal[2]);
+  const double t = num / den;
+  Ix = fma(t, r.dx, r.ox); Iy = fma(t, r.dy, r.oy); Iz = fma(t, r.dz, r.oz);
+  double rx, ry, rz;
+  mat3_apply(d.rot, Ix - d.centre[0], Iy - d.centre[1], Iz - d.centre[2], rx, ry, rz);
+  X = rx; Y = ry;
+  opl = fabs(t) * sqrt(dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz)) + r.path;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Sources (ART/ModuleSource.py:23-81, :135-169; SpiralVogel ART/ModuleGeometry.py:61-76) for ray index k
+ART_HD void source_ray(int kind, double size, const double* rot, const double* S, int64_t k, int64_t n_total,
+                       Ray& r) {
+  const double golden = 3.14159265358979323846 * (3.0 - sqrt(5.0));
+  const double radius = (kind == 0) ? tan(size) : size;  // _Cone: Height = 1, Radius = tan(Angle)
+  const double rr = sqrt((double)k / (double)n_total) * radius;
+  const double theta = golden * (double)k;
+  const double x = cos(theta) * rr, y = sin(theta) * rr;
+  double px, py, pz, vx, vy, vz;
+  if (kind == 0) {
+    px = py = pz = 0.0;
+    const double inv = 1.0 / sqrt(fma(x, x, fma(y, y, 1.0)));
+    vx = x * inv; vy = y * inv; vz = inv;
+  } else {
+    px = x; py = y; pz = 0.0;
+    vx = 0.0; vy = 0.0; vz = 1.0;
+  }
+  double ox, oy, oz, dx, dy, dz;
+  mat3_apply(rot, px, py, pz, ox, oy, oz);
+  mat3_apply(rot, vx, vy, vz, dx, dy, dz);
+  r.ox = ox + S[0]; r.oy = oy + S[1]; r.oz = oz + S[2];
+  r.dx = dx; r.dy = dy; r.dz = dz;
+  r.path = 0.0;
+  r.inc = NAN;
+}
+
+}  // namespace art

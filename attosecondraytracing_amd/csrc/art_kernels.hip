@@ -1,0 +1,541 @@
+// art_kernels.hip -- gfx950 kernels + the C ABI of libart_hip.so (include/art_hip.h).
+//
+// One ray per lane, SoA fp64 streams read and written with coalesced 8-byte accesses (64 lanes x 8 B =
+// 512 B per wave instruction and per array), element descriptors in kernel arguments (scalar loads ->
+// SGPRs, broadcast for free), Zernike coefficient tables staged once per workgroup in LDS, wavefront
+// ballot on the torus Newton loop.  No MFMA: the path is streaming fp64 VALU work against HBM.
+#include <hip/hip_runtime.h>
+
+#include <stdio.h>
+#include <string.h>
+
+#include "art_device.h"
+
+namespace {
+
+constexpr int kBlock = 256;          // 4 waves per workgroup
+constexpr int kMaxBlocks = 256 * 8;  // 256 CUs x 8 workgroups: grid-stride beyond that
+constexpr int kChainMax = 8;         // elements per fused launch (kernel-argument budget)
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+int fail_hip(hipError_t e, const char* what) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+  return ART_ERR_HIP;
+}
+
+inline int grid_for(int64_t n) {
+  int64_t b = (n + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  return (int)b;
+}
+
+__device__ __forceinline__ void load_ray(const ArtBundleView& v, int64_t i, art::Ray& r) {
+  r.ox = v.ox[i]; r.oy = v.oy[i]; r.oz = v.oz[i];
+  r.dx = v.dx[i]; r.dy = v.dy[i]; r.dz = v.dz[i];
+  r.path = v.path[i];
+}
+__device__ __forceinline__ void store_ray(const ArtBundleView& v, int64_t i, const art::Ray& r) {
+  v.ox[i] = r.ox; v.oy[i] = r.oy; v.oz[i] = r.oz;
+  v.dx[i] = r.dx; v.dy[i] = r.dy; v.dz[i] = r.dz;
+  v.path[i] = r.path;
+  v.incidence[i] = r.inc;
+}
+
+// ------------------------------------------------------------------------------------------- trace kernels
+template <int KIND, bool DEFECT>
+__global__ __launch_bounds__(kBlock) void k_trace_element(const ArtElementDesc e, const ArtBundleView in,
+                                                          const ArtBundleView out, const int64_t n) {
+  __shared__ double s_zern[DEFECT ? ART_MAX_DEFECTS * ART_ZERN_STRIDE : 1];
+  const double* zern = nullptr;
+  if (DEFECT) {
+    const int cnt = e.n_defects * ART_ZERN_STRIDE;
+    for (int j = threadIdx.x; j < cnt; j += kBlock) s_zern[j] = e.zern[j];
+    __syncthreads();
+    zern = s_zern;
+  }
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    bool ok = in.alive[i] != 0;
+    art::Ray r;
+    if (ok) {
+      load_ray(in, i, r);
+      ok = art::trace_ray<KIND, DEFECT>(e, zern, r);
+    }
+    if (ok) store_ray(out, i, r);
+    out.alive[i] = ok ? 1 : 0;
+  }
+}
+
+struct ChainArgs {
+  ArtElementDesc e[kChainMax];
+  ArtBundleView out[kChainMax];
+  int32_t zoff[kChainMax];  // offset (doubles) of element k's Zernike table in dynamic LDS
+  int32_t n_elems;
+  int32_t zern_doubles;     // total dynamic LDS doubles (0 when no element carries defects)
+};
+
+// whole chain, ray resident in registers; history written for every element whose view is non-null
+template <bool DEFECT>
+__global__ __launch_bounds__(kBlock) void k_trace_chain(const ChainArgs a, const ArtBundleView in, const int64_t n) {
+  extern __shared__ double s_zern[];  // Zernike tables of all elements, staged once per workgroup
+  if (DEFECT) {
+    for (int k = 0; k < a.n_elems; ++k) {
+      const int cnt = a.e[k].n_defects * ART_ZERN_STRIDE;
+      for (int j = threadIdx.x; j < cnt; j += kBlock) s_zern[a.zoff[k] + j] = a.e[k].zern[j];
+    }
+    __syncthreads();
+  }
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    bool ok = in.alive[i] != 0;
+    art::Ray r;
+    if (ok) load_ray(in, i, r);
+    for (int k = 0; k < a.n_elems; ++k) {
+      if (ok) ok = art::trace_ray_dyn<DEFECT>(a.e[k], s_zern + a.zoff[k], r);
+      if (a.out[k].alive != nullptr) {
+        if (ok) store_ray(a.out[k], i, r);
+        a.out[k].alive[i] = ok ? 1 : 0;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- detector
+__global__ __launch_bounds__(kBlock) void k_detector(const ArtDetectorDesc d, const ArtBundleView b, const int64_t n,
+                                                     double* p3x, double* p3y, double* p3z, double* X, double* Y,
+                                                     double* opl) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    if (b.alive[i] == 0) continue;
+    art::Ray r;
+    load_ray(b, i, r);
+    double Ix, Iy, Iz, x, y, o;
+    art::detector_ray(d, r, Ix, Iy, Iz, x, y, o);
+    if (p3x) { p3x[i] = Ix; p3y[i] = Iy; p3z[i] = Iz; }
+    if (X) { X[i] = x; Y[i] = y; }
+    if (opl) opl[i] = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------- reductions
+// Deterministic: fixed grid, each lane accumulates its grid-stride slice, wave shuffle tree, LDS across the
+// 4 waves, one partial per workgroup into `scratch`, then a single workgroup folds the partials in order.
+constexpr int kRedBlocks = 1024;
+constexpr int kRedSlots = 16;
+
+enum RedOp { RSUM = 0, RMIN = 1, RMAX = 2 };
+
+__device__ __forceinline__ double wave_reduce(double v, int op) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_down(v, off, 64);
+    v = (op == RSUM) ? v + o : (op == RMIN ? fmin(v, o) : fmax(v, o));
+  }
+  return v;
+}
+
+template <int NS>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[NS], const int (&ops)[NS], double* dst) {
+  __shared__ double s[kBlock / 64][NS];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const double v = wave_reduce(acc[k], ops[k]);
+    if (lane == 0) s[w][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NS) {
+    const int k = threadIdx.x;
+    double v = s[0][k];
+    for (int j = 1; j < kBlock / 64; ++j)
+      v = (ops[k] == RSUM) ? v + s[j][k] : (ops[k] == RMIN ? fmin(v, s[j][k]) : fmax(v, s[j][k]));
+    dst[k] = v;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_stats_partial(const uint8_t* alive, const double* X, const double* Y,
+                                                          const double* opl, const double* w, const int64_t n,
+                                                          double* scratch) {
+  const int ops[kRedSlots] = {RSUM, RSUM, RMIN, RMAX, RMIN, RMAX, RSUM, RSUM,
+                              RSUM, RSUM, RSUM, RSUM, RMIN, RMAX, RSUM, RSUM};
+  double acc[kRedSlots];
+#pragma unroll
+  for (int k = 0; k < kRedSlots; ++k) acc[k] = (ops[k] == RSUM) ? 0.0 : (ops[k] == RMIN ? INFINITY : -INFINITY);
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    if (alive[i] == 0) continue;
+    const double x = X ? X[i] : 0.0, y = Y ? Y[i] : 0.0, o = opl ? opl[i] : 0.0, ww = w ? w[i] : 1.0;
+    acc[0] += 1.0; acc[1] += o;
+    acc[2] = fmin(acc[2], x); acc[3] = fmax(acc[3], x);
+    acc[4] = fmin(acc[4], y); acc[5] = fmax(acc[5], y);
+    acc[6] += x; acc[7] += y;
+    acc[8] += ww; acc[9] = fma(ww, x, acc[9]); acc[10] = fma(ww, y, acc[10]); acc[11] = fma(ww, o, acc[11]);
+    acc[12] = fmin(acc[12], o); acc[13] = fmax(acc[13], o);
+  }
+  block_reduce_store<kRedSlots>(acc, ops, scratch + (int64_t)blockIdx.x * kRedSlots);
+}
+
+__global__ __launch_bounds__(kBlock) void k_stats_final(const double* scratch, const int nblocks, double* out) {
+  const int ops[kRedSlots] = {RSUM, RSUM, RMIN, RMAX, RMIN, RMAX, RSUM, RSUM,
+                              RSUM, RSUM, RSUM, RSUM, RMIN, RMAX, RSUM, RSUM};
+  double acc[kRedSlots];
+#pragma unroll
+  for (int k = 0; k < kRedSlots; ++k) acc[k] = (ops[k] == RSUM) ? 0.0 : (ops[k] == RMIN ? INFINITY : -INFINITY);
+  for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+#pragma unroll
+    for (int k = 0; k < kRedSlots; ++k) {
+      const double v = scratch[(int64_t)b * kRedSlots + k];
+      acc[k] = (ops[k] == RSUM) ? acc[k] + v : (ops[k] == RMIN ? fmin(acc[k], v) : fmax(acc[k], v));
+    }
+  }
+  block_reduce_store<kRedSlots>(acc, ops, out);
+}
+
+constexpr int kSumSlots = 8;
+
+__global__ __launch_bounds__(kBlock) void k_moments_partial(const uint8_t* alive, const double* X, const double* Y,
+                                                            const double* opl, const double* w, const int64_t n,
+                                                            const double cx, const double cy, const double co,
+                                                            double* scratch) {
+  const int ops[kSumSlots] = {RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM};
+  double acc[kSumSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    if (alive[i] == 0) continue;
+    const double ww = w ? w[i] : 1.0;
+    const double ex = X ? X[i] - cx : 0.0, ey = Y ? Y[i] - cy : 0.0, eo = opl ? opl[i] - co : 0.0;
+    acc[0] += ww;
+    acc[1] = fma(ww * ex, ex, acc[1]);
+    acc[2] = fma(ww * ey, ey, acc[2]);
+    acc[3] = fma(ww * eo, eo, acc[3]);
+    acc[4] += 1.0;
+  }
+  block_reduce_store<kSumSlots>(acc, ops, scratch + (int64_t)blockIdx.x * kSumSlots);
+}
+
+__global__ __launch_bounds__(kBlock) void k_bundle_sums_partial(const ArtBundleView b, const double* w,
+                                                                const int64_t n, double* scratch) {
+  const int ops[kSumSlots] = {RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM};
+  double acc[kSumSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    if (b.alive[i] == 0) continue;
+    acc[0] += 1.0;
+    acc[1] += b.ox[i]; acc[2] += b.oy[i]; acc[3] += b.oz[i];
+    acc[4] += b.dx[i]; acc[5] += b.dy[i]; acc[6] += b.dz[i];
+    acc[7] += w ? w[i] : 0.0;
+  }
+  block_reduce_store<kSumSlots>(acc, ops, scratch + (int64_t)blockIdx.x * kSumSlots);
+}
+
+__global__ __launch_bounds__(kBlock) void k_sums_final(const double* scratch, const int nblocks, double* out) {
+  const int ops[kSumSlots] = {RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM};
+  double acc[kSumSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+#pragma unroll
+    for (int k = 0; k < kSumSlots; ++k) acc[k] += scratch[(int64_t)b * kSumSlots + k];
+  }
+  block_reduce_store<kSumSlots>(acc, ops, out);
+}
+
+// ------------------------------------------------------------------------------------------- compaction
+// Stable stream compaction of the alive mask in three passes: per-tile counts, exclusive scan of the tile
+// counts by one workgroup, scatter with an intra-wave ballot/popcount rank.
+constexpr int kTile = 2048;  // slots per workgroup: 8 per lane
+
+__global__ __launch_bounds__(kBlock) void k_compact_count(const uint8_t* alive, const int64_t n, int32_t* counts) {
+  __shared__ int s[kBlock / 64];
+  const int64_t base = (int64_t)blockIdx.x * kTile;
+  int c = 0;
+  for (int j = 0; j < kTile / kBlock; ++j) {
+    const int64_t i = base + j * kBlock + threadIdx.x;
+    c += (i < n && alive[i] != 0) ? 1 : 0;
+  }
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+__global__ __launch_bounds__(1024) void k_compact_scan(int32_t* counts, const int64_t ntiles, int64_t* total,
+                                                       int64_t* tile_offsets) {
+  // single workgroup; each lane owns a contiguous chunk -> local sums -> LDS scan -> write back
+  __shared__ int64_t s[1024];
+  const int64_t per = (ntiles + 1023) / 1024;
+  const int64_t lo = (int64_t)threadIdx.x * per;
+  const int64_t hi = (lo + per < ntiles) ? lo + per : ntiles;
+  int64_t sum = 0;
+  for (int64_t k = lo; k < hi; ++k) sum += counts[k];
+  s[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int64_t v = (threadIdx.x >= (unsigned)off) ? s[threadIdx.x - off] : 0;
+    __syncthreads();
+    s[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int64_t run = s[threadIdx.x] - sum;  // exclusive prefix of this chunk
+  for (int64_t k = lo; k < hi; ++k) {
+    tile_offsets[k] = run;
+    run += counts[k];
+  }
+  if (threadIdx.x == 1023) *total = s[1023];
+}
+
+__global__ __launch_bounds__(kBlock) void k_compact_scatter(const uint8_t* alive, const int64_t n,
+                                                            const int64_t* tile_offsets, int64_t* idx_out) {
+  __shared__ int s_wave[kBlock / 64];
+  const int64_t base = (int64_t)blockIdx.x * kTile;
+  int64_t run = tile_offsets[blockIdx.x];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int j = 0; j < kTile / kBlock; ++j) {
+    const int64_t i = base + j * kBlock + threadIdx.x;
+    const bool a = (i < n) && alive[i] != 0;
+    const unsigned long long m = __ballot(a);
+    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wv] = __popcll(m);
+    __syncthreads();
+    int before = 0, tot = 0;
+    for (int k = 0; k < kBlock / 64; ++k) {
+      if (k < wv) before += s_wave[k];
+      tot += s_wave[k];
+    }
+    if (a) idx_out[run + before + rank] = i;
+    run += tot;
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------- sources
+__global__ __launch_bounds__(kBlock) void k_make_source(const int32_t kind, const double size, const ArtDetectorDesc rs,
+                                                        const int64_t first, const int64_t n, const int64_t n_total,
+                                                        const ArtBundleView out) {
+  // rs.rot = rotation ez -> axis, rs.centre = S (ArtDetectorDesc reused as a POD carrier)
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    art::Ray r;
+    art::source_ray(kind, size, rs.rot, rs.centre, first + i, n_total, r);
+    store_ray(out, i, r);
+    out.alive[i] = 1;
+  }
+}
+
+bool view_ok(const ArtBundleView* v) {
+  return v && v->ox && v->oy && v->oz && v->dx && v->dy && v->dz && v->path && v->incidence && v->alive;
+}
+
+int check_elem(const ArtElementDesc* e) {
+  if (!e) return fail(ART_ERR_BAD_ARG, "element descriptor is NULL");
+  if (e->kind < 0 || e->kind >= ART_NUM_KINDS) return fail(ART_ERR_BAD_ARG, "unknown optic kind");
+  if (e->support_kind < 0 || e->support_kind > ART_SUP_RECTRECTHOLE) return fail(ART_ERR_BAD_ARG, "unknown support kind");
+  if (e->n_defects < 0 || e->n_defects > ART_MAX_DEFECTS) return fail(ART_ERR_UNSUPPORTED, "too many defects on one mirror");
+  if (e->n_defects > 0 && e->kind == ART_MASK) return fail(ART_ERR_BAD_ARG, "a mask cannot carry defects");
+  if (e->n_defects > 0 && !e->zern) return fail(ART_ERR_BAD_ARG, "n_defects > 0 but zern table is NULL");
+  return ART_OK;
+}
+
+template <int KIND>
+void launch_element(const ArtElementDesc& e, const ArtBundleView& in, const ArtBundleView& out, int64_t n,
+                    hipStream_t s) {
+  const int grid = grid_for(n);
+  if (e.n_defects > 0)
+    hipLaunchKernelGGL((k_trace_element<KIND, true>), dim3(grid), dim3(kBlock), 0, s, e, in, out, n);
+  else
+    hipLaunchKernelGGL((k_trace_element<KIND, false>), dim3(grid), dim3(kBlock), 0, s, e, in, out, n);
+}
+
+}  // namespace
+
+// =================================================================================================== C ABI
+extern "C" {
+
+int art_abi_version(void) { return ART_ABI_VERSION; }
+
+const char* art_last_error(void) { return g_err; }
+
+int art_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail_hip(e, "hipGetDeviceCount");
+  }
+  int good = 0;
+  for (int i = 0; i < n; ++i) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ++good;
+  }
+  return good;
+}
+
+int art_trace_element(const ArtElementDesc* e, const ArtBundleView* in, const ArtBundleView* out, int64_t n,
+                      void* stream) {
+  int rc = check_elem(e);
+  if (rc) return rc;
+  if (!view_ok(in) || !view_ok(out)) return fail(ART_ERR_BAD_ARG, "bundle view has a NULL array");
+  if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
+  if (n == 0) return ART_OK;
+  hipStream_t s = (hipStream_t)stream;
+  switch (e->kind) {
+    case ART_PLANE: launch_element<ART_PLANE>(*e, *in, *out, n, s); break;
+    case ART_SPHERE: launch_element<ART_SPHERE>(*e, *in, *out, n, s); break;
+    case ART_PARABOLA: launch_element<ART_PARABOLA>(*e, *in, *out, n, s); break;
+    case ART_TORUS: launch_element<ART_TORUS>(*e, *in, *out, n, s); break;
+    case ART_ELLIPSOID: launch_element<ART_ELLIPSOID>(*e, *in, *out, n, s); break;
+    case ART_CYLINDER: launch_element<ART_CYLINDER>(*e, *in, *out, n, s); break;
+    default: launch_element<ART_MASK>(*e, *in, *out, n, s); break;
+  }
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail_hip(err, "art_trace_element launch");
+  return ART_OK;
+}
+
+int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundleView* in, const ArtBundleView* outs,
+                    int64_t n, void* stream) {
+  if (!elems || !outs || n_elems <= 0) return fail(ART_ERR_BAD_ARG, "empty chain");
+  if (!view_ok(in)) return fail(ART_ERR_BAD_ARG, "input bundle view has a NULL array");
+  if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
+  for (int k = 0; k < n_elems; ++k) {
+    int rc = check_elem(&elems[k]);
+    if (rc) return rc;
+    if (outs[k].alive != nullptr && !view_ok(&outs[k])) return fail(ART_ERR_BAD_ARG, "history view partially NULL");
+  }
+  if (!view_ok(&outs[n_elems - 1])) return fail(ART_ERR_BAD_ARG, "the last output view is mandatory");
+  if (n == 0) return ART_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const ArtBundleView* cur = in;
+  for (int k0 = 0; k0 < n_elems; k0 += kChainMax) {
+    ChainArgs a;
+    memset(&a, 0, sizeof(a));
+    const int m = (n_elems - k0 < kChainMax) ? n_elems - k0 : kChainMax;
+    a.n_elems = m;
+    for (int k = 0; k < m; ++k) {
+      a.e[k] = elems[k0 + k];
+      a.out[k] = outs[k0 + k];
+      a.zoff[k] = a.zern_doubles;
+      a.zern_doubles += a.e[k].n_defects * ART_ZERN_STRIDE;
+    }
+    // the chunk's last bundle is the next chunk's input: it must exist
+    if (!view_ok(&a.out[m - 1])) return fail(ART_ERR_BAD_ARG, "chains longer than 8 need a view every 8th element");
+    if (a.zern_doubles > 0)
+      hipLaunchKernelGGL(k_trace_chain<true>, dim3(grid_for(n)), dim3(kBlock), (size_t)a.zern_doubles * sizeof(double),
+                         s, a, *cur, n);
+    else
+      hipLaunchKernelGGL(k_trace_chain<false>, dim3(grid_for(n)), dim3(kBlock), 0, s, a, *cur, n);
+    cur = &outs[k0 + m - 1];
+  }
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail_hip(err, "art_trace_chain launch");
+  return ART_OK;
+}
+
+int art_detector(const ArtDetectorDesc* d, const ArtBundleView* b, int64_t n, double* p3x, double* p3y, double* p3z,
+                 double* X, double* Y, double* opl, void* stream) {
+  if (!d) return fail(ART_ERR_BAD_ARG, "detector descriptor is NULL");
+  if (!view_ok(b)) return fail(ART_ERR_BAD_ARG, "bundle view has a NULL array");
+  if ((p3x || p3y || p3z) && !(p3x && p3y && p3z)) return fail(ART_ERR_BAD_ARG, "p3x/p3y/p3z must be all set or all NULL");
+  if ((X || Y) && !(X && Y)) return fail(ART_ERR_BAD_ARG, "X/Y must be both set or both NULL");
+  if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
+  if (n == 0) return ART_OK;
+  hipLaunchKernelGGL(k_detector, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, *d, *b, n, p3x, p3y, p3z, X,
+                     Y, opl);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail_hip(err, "art_detector launch");
+  return ART_OK;
+}
+
+int64_t art_reduce_scratch_doubles(void) { return (int64_t)kRedBlocks * kRedSlots; }
+
+int art_detector_stats(const uint8_t* alive, const double* X, const double* Y, const double* opl, const double* w,
+                       int64_t n, double* scratch, double* out16, void* stream) {
+  if (!alive || !scratch || !out16) return fail(ART_ERR_BAD_ARG, "alive/scratch/out16 must not be NULL");
+  if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
+  hipStream_t s = (hipStream_t)stream;
+  int64_t b = (n + kBlock - 1) / kBlock;
+  const int nb = (int)(b < 1 ? 1 : (b > kRedBlocks ? kRedBlocks : b));
+  hipLaunchKernelGGL(k_stats_partial, dim3(nb), dim3(kBlock), 0, s, alive, X, Y, opl, w, n, scratch);
+  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(kBlock), 0, s, scratch, nb, out16);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail_hip(err, "art_detector_stats launch");
+  return ART_OK;
+}
+
+int art_detector_moments(const uint8_t* alive, const double* X, const double* Y, const double* opl, const double* w,
+                         int64_t n, double cx, double cy, double co, double* scratch, double* out8, void* stream) {
+  if (!alive || !scratch || !out8) return fail(ART_ERR_BAD_ARG, "alive/scratch/out8 must not be NULL");
+  if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
+  hipStream_t s = (hipStream_t)stream;
+  int64_t b = (n + kBlock - 1) / kBlock;
+  const int nb = (int)(b < 1 ? 1 : (b > kRedBlocks ? kRedBlocks : b));
+  hipLaunchKernelGGL(k_moments_partial, dim3(nb), dim3(kBlock), 0, s, alive, X, Y, opl, w, n, cx, cy, co, scratch);
+  hipLaunchKernelGGL(k_sums_final, dim3(1), dim3(kBlock), 0, s, scratch, nb, out8);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail_hip(err, "art_detector_moments launch");
+  return ART_OK;
+}
+
+int art_bundle_sums(const ArtBundleView* bv, const double* w, int64_t n, double* scratch, double* out8, void* stream) {
+  if (!view_ok(bv) || !scratch || !out8) return fail(ART_ERR_BAD_ARG, "bundle/scratch/out8 must not be NULL");
+  if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
+  hipStream_t s = (hipStream_t)stream;
+  int64_t b = (n + kBlock - 1) / kBlock;
+  const int nb = (int)(b < 1 ? 1 : (b > kRedBlocks ? kRedBlocks : b));
+  hipLaunchKernelGGL(k_bundle_sums_partial, dim3(nb), dim3(kBlock), 0, s, *bv, w, n, scratch);
+  hipLaunchKernelGGL(k_sums_final, dim3(1), dim3(kBlock), 0, s, scratch, nb, out8);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail_hip(err, "art_bundle_sums launch");
+  return ART_OK;
+}
+
+int64_t art_compact_scratch_ints(int64_t n) {
+  const int64_t tiles = (n + kTile - 1) / kTile;
+  // int32 counts [tiles] followed by int64 offsets [tiles] (8-byte aligned: round counts up to even)
+  const int64_t c = (tiles + 1) & ~1ll;
+  return c + 2 * tiles + 2;
+}
+
+int art_compact(const uint8_t* alive, int64_t n, int32_t* block_counts, int64_t* idx_out, int64_t* count_out,
+                void* stream) {
+  if (!alive || !block_counts || !idx_out || !count_out) return fail(ART_ERR_BAD_ARG, "NULL argument");
+  if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    hipError_t e0 = hipMemsetAsync(count_out, 0, sizeof(int64_t), s);
+    if (e0 != hipSuccess) return fail_hip(e0, "hipMemsetAsync");
+    return ART_OK;
+  }
+  const int64_t tiles = (n + kTile - 1) / kTile;
+  const int64_t c = (tiles + 1) & ~1ll;
+  int64_t* offsets = reinterpret_cast<int64_t*>(block_counts + c);
+  hipLaunchKernelGGL(k_compact_count, dim3((unsigned)tiles), dim3(kBlock), 0, s, alive, n, block_counts);
+  hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, s, block_counts, tiles, count_out, offsets);
+  hipLaunchKernelGGL(k_compact_scatter, dim3((unsigned)tiles), dim3(kBlock), 0, s, alive, n, offsets, idx_out);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail_hip(err, "art_compact launch");
+  return ART_OK;
+}
+
+int art_make_source(int32_t kind, double size, const double rot[9], const double S[3], int64_t first, int64_t n,
+                    int64_t n_total, const ArtBundleView* out, void* stream) {
+  if (kind != 0 && kind != 1) return fail(ART_ERR_BAD_ARG, "source kind must be 0 (point) or 1 (plane-wave disk)");
+  if (!rot || !S || !view_ok(out)) return fail(ART_ERR_BAD_ARG, "NULL argument");
+  if (n < 0 || first < 0 || n_total <= 0 || first + n > n_total) return fail(ART_ERR_BAD_ARG, "bad index range");
+  if (n == 0) return ART_OK;
+  ArtDetectorDesc rs;
+  memset(&rs, 0, sizeof(rs));
+  memcpy(rs.rot, rot, 9 * sizeof(double));
+  memcpy(rs.centre, S, 3 * sizeof(double));
+  hipLaunchKernelGGL(k_make_source, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, kind, size, rs, first, n,
+                     n_total, *out);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail_hip(err, "art_make_source launch");
+  return ART_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,54 @@
+"""Multi-GPU: rays shard embarrassingly by contiguous index ranges, one process per GPU (torch.distributed,
+backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests).  Every rank keeps its shard resident for the whole
+chain; the only exchange is at the detector: one all-reduce of 16 statistics (mean path, bounding box, weights)
+and ONE gather of the per-ray read-out (X, Y, optical path, alive) to rank 0 -- a gather, not a ring collective:
+on the xGMI mesh every peer has its own link into the root."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+# slots of art_detector_stats (include/art_hip.h) by reduction operator
+_SUM = [0, 1, 6, 7, 8, 9, 10, 11]
+_MIN = [2, 4, 12]
+_MAX = [3, 5, 13]
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous global index range [lo, hi) of `rank`; concatenating ranks restores the global ray order."""
+    return (n_total * rank) // world, (n_total * (rank + 1)) // world
+
+
+def allreduce_stats(stats16, device):
+    """Combine per-shard art_detector_stats vectors into the global one (same layout)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return np.asarray(stats16, dtype=np.float64)
+    t = torch.as_tensor(np.asarray(stats16, dtype=np.float64), device=device)
+    s, mn, mx = t[_SUM].clone(), t[_MIN].clone(), t[_MAX].clone()
+    dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    out = torch.zeros(16, dtype=torch.float64, device=device)
+    out[_SUM], out[_MIN], out[_MAX] = s, mn, mx
+    return out.cpu().numpy()
+
+
+def gather_readout(X, Y, opl, alive, dst=0, pack=None):
+    """Gather the detector read-out of every shard to rank `dst` (rank order = global ray order).
+    Returns (XYO [3, n_total] float64, alive [n_total] uint8) on dst, (None, None) elsewhere.
+    `pack` may hold preallocated {'send': [3,n], 'recv': [list of [3,n]], 'arecv': [list of [n]]} buffers."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return torch.stack([X, Y, opl]), alive
+    rank = dist.get_rank()
+    n = X.numel()
+    send = pack["send"] if pack else torch.empty((3, n), dtype=torch.float64, device=X.device)
+    send[0], send[1], send[2] = X, Y, opl
+    if rank == dst:
+        recv = pack["recv"] if pack else [torch.empty_like(send) for _ in range(world)]
+        arecv = pack["arecv"] if pack else [torch.empty_like(alive) for _ in range(world)]
+        dist.gather(send, recv, dst=dst)
+        dist.gather(alive, arecv, dst=dst)
+        return torch.cat(recv, dim=1), torch.cat(arecv)
+    dist.gather(send, None, dst=dst)
+    dist.gather(alive, None, dst=dst)
+    return None, None

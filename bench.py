@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: ray-surface intersections/s on MI355X (BASELINE.json metric).
+
+Workload at N=1 ("relay4"): a point source (half-angle 20 mrad) of 1e7 rays through 4 toroidal mirrors
+(two f-x-f relays with the C3 scene's toroid: f = 600 mm, 80 deg incidence, 200x30 mm aperture), then the
+detector read-out -- 1e7 rays x 4 mirrors = 4e7 ray-surface intersections per step, every ray surviving.
+A step = one pass of the hot path over one resident bundle:
+    RayTracingCalculation(source, elements)  -> all 4 per-element bundles written (full history, as the API returns)
+    Detector.readout(last)                   -> X, Y, optical path per ray + the 16 global statistics
+    (N > 1) all-reduce of the statistics + ONE gather of the read-out to rank 0 over RCCL
+Inputs are resident in HBM before the timed region.  N > 1 is weak scaling: every rank traces its own 1e7-ray
+shard (index range of a N*1e7-ray source), no collective on the tracing path.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_INTERSECTION = 128.0   # read 48+8+4, write 48+8+8+4
+HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_scene(n_mirrors, small_n=1000):
+    """Element poses through the product's own OEPlacement (1-ray alignment traces on the GPU)."""
+    import ART.ModuleMirror as mmirror
+    import ART.ModuleSupport as msupp
+    import ART.ModuleProcessing as mp
+    R, r = mmirror.ReturnOptimalToroidalRadii(600, 80)
+    Tor = mmirror.MirrorToroidal(R, r, msupp.SupportRectangle(200, 30))
+    optics = [Tor] * n_mirrors
+    dist_ = [600 if (k % 2 == 1 or k == 0) else 1200 for k in range(n_mirrors)]
+    inc = [80 if k % 2 == 0 else -80 for k in range(n_mirrors)]
+    SP = {"Divergence": 0.02, "SourceSize": 0, "Wavelength": 50e-6, "DeltaFT": 0.5, "NumberRays": small_n}
+    chain = mp.OEPlacement(SP, optics, dist_, inc, [0] * n_mirrors, "relay%d" % n_mirrors)
+    return chain, (R, r)
+
+
+def device_source(n, first, n_total, be):
+    """Shard [first, first+n) of an n_total-ray point source, generated on the device."""
+    from attosecondraytracing_amd.bundle import RayBundle
+    b = RayBundle.allocate(n, backend=be)
+    b.wavelength = 50e-6
+    rot = np.array([[0.0, 0.0, 1.0], [0.0, 1.0, 0.0], [-1.0, 0.0, 0.0]])  # ez -> ex
+    from attosecondraytracing_amd import ModuleGeometry as mgeo
+    rot = mgeo.rotation_matrix(np.array([0.0, 0.0, 1.0]), np.array([1.0, 0.0, 0.0]))
+    be.make_source(0, 0.02, rot, np.zeros(3), first, n, n_total, b.view())
+    b.intensity = torch.ones(n, dtype=torch.float64, device=be.device)
+    return b
+
+
+def cpu_baseline(chain, Rr, n_sample):
+    """The CPU oracle (NumPy port of the reference algorithm) on a bounded sample of the same workload."""
+    from oracle import art_oracle as orc
+    R, r = Rr
+    B = orc.point_source([0.0, 0.0, 0.0], [1.0, 0.0, 0.0], 0.02, n_sample, 50e-6)
+    els = [orc.Element(orc.Optic("torus", orc.Support("rect", [200, 30]), {"R": R, "r": r}, [], "Toroidal Mirror"),
+                       np.asarray(oe.position, float), oe.normal, oe.majoraxis) for oe in chain.optical_elements]
+    t0 = time.perf_counter()
+    out = orc.ray_tracing_calculation(B, els)
+    D = orc.detector_autoplace(out[-1], 600.0)
+    orc.detector_delays(D, out[-1])
+    dt = time.perf_counter() - t0
+    inter = n_sample + sum(len(o) for o in out[:-1])
+    return inter / dt, inter, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rays", type=int, default=10_000_000, help="rays per GPU")
+    ap.add_argument("--mirrors", type=int, default=4)
+    ap.add_argument("--mode", default=None, choices=[None, "chain", "element"])
+    ap.add_argument("--cpu-sample", type=int, default=500_000, help="rays of the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if world != args.gpus and rank == 0:
+        log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+
+    from attosecondraytracing_amd import _lib, sharding
+    import ART.ModuleProcessing as mp
+    import ART.ModuleDetector as mdet
+    be = _lib.get_backend()
+    mode = args.mode or mp.DEFAULT_TRACE_MODE
+
+    chain, Rr = build_scene(args.mirrors)
+    els = chain.optical_elements
+    n = args.rays
+    n_total = n * world
+    lo, hi = sharding.shard_range(n_total, rank, world)
+    src = device_source(hi - lo, lo, n_total, be)
+
+    # detector: placed once (untimed) from the mean ray of the last bundle, like ARTmain.setup_detector
+    out = mp.RayTracingCalculation(src, els, mode=mode)
+    det = mdet.Detector(np.asarray(els[-1].position, dtype=float))
+    det.autoplace(out[-1], 600.0)
+    entering = [n] + [len(o) for o in out[:-1]]
+    inter_per_step_rank = int(sum(entering))
+    del out
+
+    pack = None
+    if world > 1:
+        import torch.distributed as dist
+        pack = {"send": torch.empty((3, n), dtype=torch.float64, device=be.device)}
+        if rank == 0:
+            pack["recv"] = [torch.empty((3, n), dtype=torch.float64, device=be.device) for _ in range(world)]
+            pack["arecv"] = [torch.empty(n, dtype=torch.uint8, device=be.device) for _ in range(world)]
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev[i][0].record()
+        o = mp.RayTracingCalculation(src, els, mode=mode)
+        if i is not None:
+            ev[i][1].record()
+        r = det.readout(o[-1])
+        if world > 1:
+            sharding.allreduce_stats(r["stats"], be.device)
+            sharding.gather_readout(r["X"], r["Y"], r["opl"], o[-1].alive, 0, pack)
+        return o, r
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        o, r = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=be.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    trace_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # HIP events on the launch stream
+    launches = 1 if mode == "chain" else args.mirrors
+    kernel_ms = trace_ms / launches
+    inter_per_launch = inter_per_step_rank / launches
+    achieved = ALGO_BYTES_PER_INTERSECTION * inter_per_launch / (kernel_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        value = inter_per_step_rank * world * args.steps / dt
+        res = {
+            "metric": "ray-surface intersections/s", "value": value, "unit": "intersections/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"relay{args.mirrors}: point source 20 mrad -> {args.mirrors} toroidal mirrors "
+                                   f"(f=600 mm, 80 deg, 200x30 mm) -> detector; {n} rays/GPU x {args.mirrors} mirrors "
+                                   f"= {inter_per_step_rank} intersections/GPU/step; full per-element history",
+                       "rays_per_gpu": n, "mirrors": args.mirrors, "trace_mode": mode,
+                       "step": "RayTracingCalculation + Detector.readout" + (" + RCCL gather to rank 0" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_trace_chain<false>" if mode == "chain" else "k_trace_element<ART_TORUS,false>",
+                         "kernel_ms": kernel_ms, "intersections_per_launch": inter_per_launch,
+                         "algorithmic_bytes_per_intersection": ALGO_BYTES_PER_INTERSECTION},
+            "trace_only_intersections_per_s": inter_per_step_rank / (trace_ms * 1e-3),
+        }
+        if world == 1 and args.cpu_sample > 0:
+            v, inter, secs = cpu_baseline(chain, Rr, args.cpu_sample)
+            res["cpu_baseline"] = {"value": v, "unit": "intersections/s", "cores": 1, "kind": "port",
+                                   "sample": f"oracle/art_oracle.py (NumPy, batched LAPACK eigvals; single thread) on "
+                                             f"{args.cpu_sample} rays x {args.mirrors} mirrors + detector = {inter} "
+                                             f"intersections in {secs:.1f} s; host has {os.cpu_count()} cores"}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

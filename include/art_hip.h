@@ -1,0 +1,175 @@
+/*
+ * art_hip.h -- C ABI of libart_hip.so: MI355X (gfx950) ray-bundle propagation for ART.
+ *
+ * The reference (mightymightys/AttosecondRaytracing, pure Python) has no FFI layer; its boundary for
+ * this path is the Python call
+ *     ModuleProcessing.RayTracingCalculation(source_rays, optical_elements, IgnoreDefects)
+ *         ART/ModuleProcessing.py:250-313, sole call site ART/ModuleOpticalChain.py:194
+ * plus the Detector read-out methods ART/ModuleDetector.py:191-279.  The entry points below are what a
+ * ctypes binding on the reference side would call instead of those Python loops (INTEGRATION.md shows
+ * the stub).  Conventions:
+ *   - plain C: pointers, sizes, POD structs; no C++/torch types cross the boundary;
+ *   - every ray array is a DEVICE pointer owned by the caller (fp64 SoA, one entry per source ray, fixed
+ *     length n for the whole chain; rays that missed an element keep their slot with alive = 0);
+ *   - descriptors (ArtElementDesc, ArtDetectorDesc) are HOST structs, copied into kernel arguments;
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*; NULL = default);
+ *   - return value 0 = ART_OK, negative = error; art_last_error() gives a thread-local message;
+ *   - no mutable global state, re-entrant, current HIP device is used.
+ */
+#ifndef ART_HIP_H
+#define ART_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ART_ABI_VERSION 1
+
+/* error codes */
+#define ART_OK 0
+#define ART_ERR_BAD_ARG (-1)      /* null pointer, negative size, unknown kind                      */
+#define ART_ERR_UNSUPPORTED (-2)  /* e.g. Zernike order above ART_ZERN_MAX_ORDER                    */
+#define ART_ERR_HIP (-3)          /* a HIP runtime call failed (message holds hipGetErrorString)     */
+#define ART_ERR_NO_DEVICE (-4)    /* no gfx950 device visible                                        */
+
+/* optic kinds: ART/ModuleMirror.py classes + ART/ModuleMask.py                                       */
+enum ArtOpticKind {
+  ART_PLANE = 0,      /* MirrorPlane        ModuleMirror.py:42-113   */
+  ART_SPHERE = 1,     /* MirrorSpherical    ModuleMirror.py:117-208  mp[0]=|R|                        */
+  ART_PARABOLA = 2,   /* MirrorParabolic    ModuleMirror.py:212-387  mp[0]=p (semi latus rectum)      */
+  ART_TORUS = 3,      /* MirrorToroidal     ModuleMirror.py:391-527  mp[0]=R major, mp[1]=r minor     */
+  ART_ELLIPSOID = 4,  /* MirrorEllipsoidal  ModuleMirror.py:565-751  mp[0]=a, mp[1]=b                 */
+  ART_CYLINDER = 5,   /* MirrorCylindrical  ModuleMirror.py:781-874  mp[0]=|R|                        */
+  ART_MASK = 6,       /* Mask               ModuleMask.py:24-136                                      */
+  ART_NUM_KINDS = 7
+};
+
+/* aperture kinds: ART/ModuleSupport.py `_IncludeSupport` predicates                                  */
+enum ArtSupportKind {
+  ART_SUP_ROUND = 0,        /* :68-70    sp = {R}                         */
+  ART_SUP_ROUNDHOLE = 1,    /* :151-155  sp = {R, Rhole, cx, cy}          */
+  ART_SUP_RECT = 2,         /* :228-230  sp = {X, Y}                      */
+  ART_SUP_RECTHOLE = 3,     /* :322-326  sp = {X, Y, Rhole, cx, cy}       */
+  ART_SUP_RECTRECTHOLE = 4  /* :431-435  sp = {X, Y, hx, hy, cx, cy}      */
+};
+
+/* element flags */
+#define ART_FLAG_PERTURBED_NORMAL 1u /* IgnoreDefects=False: reflect off the defect-perturbed normal (ModuleMirror.py:933-936) */
+
+/* Zernike defect table (ART/ModuleDefects.py:149-174), a DEVICE array of doubles per element:
+ *   for defect d in [0, n_defects):  base = d * ART_ZERN_STRIDE
+ *     [base+0] = R  (Support._CircumCirc()),  [base+1] = max radial order N (2..ART_ZERN_MAX_ORDER)
+ *     [base+2 + n(n+1)/2 + m] = coefficient of (n, m), m = 0..n, 0 where absent                       */
+#define ART_ZERN_MAX_ORDER 12
+#define ART_ZERN_NCOEF ((ART_ZERN_MAX_ORDER + 1) * (ART_ZERN_MAX_ORDER + 2) / 2) /* 91 */
+#define ART_ZERN_STRIDE (2 + ART_ZERN_NCOEF)                                       /* 93 */
+#define ART_MAX_DEFECTS 4
+
+/* One optical element = optic + pose.  Replaces the per-ray frame changes of
+ * ART/ModuleProcessing.py:289-295, :306-309 by two constant 3x3 maps built on the host with the
+ * reference's own RotationPoint special cases (ART/ModuleGeometry.py:333-343):
+ *     P_optic = fwd * (P_lab - pos) + centre        u_optic = fwd * u_lab
+ *     P_lab   = bwd * (P_optic - centre) + pos      u_lab   = bwd * u_optic                          */
+typedef struct ArtElementDesc {
+  int32_t kind;          /* ArtOpticKind                                    */
+  int32_t support_kind;  /* ArtSupportKind                                  */
+  int32_t n_defects;     /* 0..ART_MAX_DEFECTS Zernike defects on a mirror  */
+  uint32_t flags;        /* ART_FLAG_*                                      */
+  double fwd[9];         /* row-major                                       */
+  double bwd[9];
+  double pos[3];         /* OpticalElement.position                         */
+  double centre[3];      /* optic.get_centre() in the optic frame           */
+  double sp[6];          /* support parameters                              */
+  double mp[4];          /* mirror parameters                               */
+  const double* zern;    /* DEVICE pointer, n_defects * ART_ZERN_STRIDE doubles, or NULL */
+} ArtElementDesc;
+
+/* SoA view of one ray bundle (all DEVICE pointers, length n).  `path` is the running optical path
+ * (sum of the reference's Ray.path tuple); `incidence` the incidence angle on the element the ray
+ * comes from (Ray.incidence).  Ray.number / intensity / wavelength never change along a chain and are
+ * therefore not part of the per-element state (slot i of every bundle is source ray i).               */
+typedef struct ArtBundleView {
+  double* ox; double* oy; double* oz;   /* Ray.point  */
+  double* dx; double* dy; double* dz;   /* Ray.vector */
+  double* path;
+  double* incidence;
+  uint8_t* alive;                       /* 1 = ray still propagating */
+} ArtBundleView;
+
+/* Plane detector (ART/ModuleDetector.py:25-62).  rot = RotationPoint(., normal, ez) as a 3x3 map
+ * (ModuleDetector.py:231), built on the host like fwd/bwd.                                            */
+typedef struct ArtDetectorDesc {
+  double centre[3];
+  double normal[3];
+  double rot[9];
+} ArtDetectorDesc;
+
+int art_abi_version(void);
+const char* art_last_error(void);
+/* number of visible HIP devices whose architecture is gfx950 (>= 0), or a negative error code */
+int art_device_count(void);
+
+/* One element of RayTracingCalculation (ART/ModuleProcessing.py:277-311): frame change, intersection
+ * (`_get_intersection` of the optic's class incl. DeformedMirror, ModuleMirror.py:969-980), support test,
+ * reflection / mask transmission (ModuleMirror.py:878-939, ModuleMask.py:93-136), frame change back.
+ * Reads bundle `in`, writes bundle `out` (may alias `in`).  Slots with in->alive == 0 and rays that
+ * miss get out->alive = 0 and their other outputs are left untouched.                                  */
+int art_trace_element(const ArtElementDesc* e, const ArtBundleView* in, const ArtBundleView* out,
+                      int64_t n, void* stream);
+
+/* Whole chain in ONE launch: the ray stays in registers from element to element.  outs[k] receives the
+ * bundle after element k for every k with outs[k].alive != NULL (pass zeroed views to skip history);
+ * outs[n_elems-1] is mandatory.  Same results as n_elems calls of art_trace_element.                   */
+int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundleView* in,
+                    const ArtBundleView* outs, int64_t n, void* stream);
+
+/* Detector read-out (ART/ModuleDetector.py:191-234, :272-275): for every alive ray
+ *   I = IntersectionLinePlane (ModuleGeometry.py:48-57);  (X,Y) = first two components of rot*(I-centre);
+ *   opl = |A - I| + path.  Any of p3x..p3z / X,Y / opl may be NULL to skip that output.               */
+int art_detector(const ArtDetectorDesc* d, const ArtBundleView* b, int64_t n,
+                 double* p3x, double* p3y, double* p3z, double* X, double* Y, double* opl, void* stream);
+
+/* Masked reductions over alive rays, deterministic (fixed two-level tree, no float atomics).
+ * out16 (DEVICE, 16 doubles):
+ *   [0] count  [1] sum opl  [2] min X [3] max X [4] min Y [5] max Y  [6] sum X [7] sum Y
+ *   [8] sum w  [9] sum w*X [10] sum w*Y [11] sum w*opl  [12] min opl [13] max opl [14..15] 0
+ * w = weights (DEVICE) or NULL (then w = 1).  X, Y, opl may be NULL (their entries are then 0).
+ * scratch: DEVICE, at least art_reduce_scratch_doubles() doubles.
+ * Feeds get_Delays' mean (ModuleDetector.py:277), CentrePointList (ModuleGeometry.py:235-236),
+ * getETransmission (ModuleAnalysisAndPlots.py:76).                                                     */
+int64_t art_reduce_scratch_doubles(void);
+int art_detector_stats(const uint8_t* alive, const double* X, const double* Y, const double* opl,
+                       const double* w, int64_t n, double* scratch, double* out16, void* stream);
+
+/* Second moments about given centres (two-pass variance; ModuleProcessing.py:485-532):
+ * out8: [0] sum w [1] sum w (X-cx)^2 [2] sum w (Y-cy)^2 [3] sum w (opl-co)^2 [4] count [5..7] 0         */
+int art_detector_moments(const uint8_t* alive, const double* X, const double* Y, const double* opl,
+                         const double* w, int64_t n, double cx, double cy, double co,
+                         double* scratch, double* out8, void* stream);
+
+/* Mean ray of a bundle (FindCentralRay, ModuleProcessing.py:464-482) + sum of intensities:
+ * out8: [0] count [1..3] sum point [4..6] sum vector [7] sum w                                          */
+int art_bundle_sums(const ArtBundleView* b, const double* w, int64_t n, double* scratch, double* out8,
+                    void* stream);
+
+/* Stable compaction: idx_out[j] = slot of the j-th alive ray (source order kept, as the reference's
+ * survivor lists ModuleMirror.py:928-939), *count_out = number alive.  block_counts: DEVICE scratch of
+ * art_compact_scratch_ints(n) int32.                                                                    */
+int64_t art_compact_scratch_ints(int64_t n);
+int art_compact(const uint8_t* alive, int64_t n, int32_t* block_counts, int64_t* idx_out,
+                int64_t* count_out, void* stream);
+
+/* Deterministic sources on device (ART/ModuleSource.py:23-81, :135-169; Vogel spiral
+ * ModuleGeometry.py:61-76) for global ray indices [first, first+n) of a bundle of n_total rays:
+ *   kind 0: point source, half-angle `size` (rad);  kind 1: plane-wave disk of radius `size` (mm).
+ * rot = RotationPoint(., ez, axis) as a 3x3 map, S = source point / disk centre.
+ * Writes origin, direction, path = 0, incidence = NaN, alive = 1.                                        */
+int art_make_source(int32_t kind, double size, const double rot[9], const double S[3], int64_t first,
+                    int64_t n, int64_t n_total, const ArtBundleView* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ART_HIP_H */

@@ -1,0 +1,85 @@
+// art_twin.cpp -- CPU twin of the gfx950 kernels.  TEST INFRASTRUCTURE ONLY (lives under oracle/).
+//
+// Compiles the SAME per-ray functions as the HIP kernels (attosecondraytracing_amd/csrc/art_device.h,
+// -DART_HOST_TWIN) with g++ and runs them in plain host loops over HOST arrays, so that the kernel math
+// (closed-form quadrics, convex-Newton torus solver, Zernike recurrences, 3x3 frame maps) can be checked
+// against the oracle and the golden vectors in a container without a GPU.  The product never loads it.
+#define ART_HOST_TWIN 1
+#include "../../attosecondraytracing_amd/csrc/art_device.h"
+
+#include <string.h>
+
+namespace {
+inline void load_ray(const ArtBundleView& v, int64_t i, art::Ray& r) {
+  r.ox = v.ox[i]; r.oy = v.oy[i]; r.oz = v.oz[i];
+  r.dx = v.dx[i]; r.dy = v.dy[i]; r.dz = v.dz[i];
+  r.path = v.path[i];
+}
+inline void store_ray(const ArtBundleView& v, int64_t i, const art::Ray& r) {
+  v.ox[i] = r.ox; v.oy[i] = r.oy; v.oz[i] = r.oz;
+  v.dx[i] = r.dx; v.dy[i] = r.dy; v.dz[i] = r.dz;
+  v.path[i] = r.path;
+  v.incidence[i] = r.inc;
+}
+}  // namespace
+
+extern "C" {
+
+int art_cpu_trace_element(const ArtElementDesc* e, const ArtBundleView* in, const ArtBundleView* out, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) {
+    bool ok = in->alive[i] != 0;
+    art::Ray r;
+    if (ok) {
+      load_ray(*in, i, r);
+      ok = art::trace_ray_dyn<true>(*e, e->zern, r);
+    }
+    if (ok) store_ray(*out, i, r);
+    out->alive[i] = ok ? 1 : 0;
+  }
+  return 0;
+}
+
+int art_cpu_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundleView* in,
+                        const ArtBundleView* outs, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) {
+    bool ok = in->alive[i] != 0;
+    art::Ray r;
+    if (ok) load_ray(*in, i, r);
+    for (int k = 0; k < n_elems; ++k) {
+      if (ok) ok = art::trace_ray_dyn<true>(elems[k], elems[k].zern, r);
+      if (outs[k].alive != nullptr) {
+        if (ok) store_ray(outs[k], i, r);
+        outs[k].alive[i] = ok ? 1 : 0;
+      }
+    }
+  }
+  return 0;
+}
+
+int art_cpu_detector(const ArtDetectorDesc* d, const ArtBundleView* b, int64_t n, double* p3x, double* p3y,
+                     double* p3z, double* X, double* Y, double* opl) {
+  for (int64_t i = 0; i < n; ++i) {
+    if (b->alive[i] == 0) continue;
+    art::Ray r;
+    load_ray(*b, i, r);
+    double Ix, Iy, Iz, x, y, o;
+    art::detector_ray(*d, r, Ix, Iy, Iz, x, y, o);
+    if (p3x) { p3x[i] = Ix; p3y[i] = Iy; p3z[i] = Iz; }
+    if (X) { X[i] = x; Y[i] = y; }
+    if (opl) opl[i] = o;
+  }
+  return 0;
+}
+
+int art_cpu_make_source(int32_t kind, double size, const double* rot, const double* S, int64_t first, int64_t n,
+                        int64_t n_total, const ArtBundleView* out) {
+  for (int64_t i = 0; i < n; ++i) {
+    art::Ray r;
+    art::source_ray(kind, size, rot, S, first + i, n_total, r);
+    store_ray(*out, i, r);
+    out->alive[i] = 1;
+  }
+  return 0;
+}
+
+}  // extern "C"

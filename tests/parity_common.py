@@ -1,0 +1,97 @@
+"""Shared by the CPU-twin tests (-m "not gpu") and the GPU parity tests (-m gpu): rebuild a golden scene with
+the product's own classes, trace it through whatever backend is active, compare with the reference's output.
+
+Tolerances (BASELINE.json north_star): survivor indices bit-exact; positions / directions / optical paths
+within 1e-10 relative (positions and paths normalised by the scene scale resp. the mean optical path);
+delays within 1e-10 of the mean travel time."""
+import numpy as np
+
+import ART.ModuleDefects as mdef
+import ART.ModuleMask as mmask
+import ART.ModuleMirror as mmirror
+import ART.ModuleOpticalElement as moe
+import ART.ModuleSupport as msupp
+from attosecondraytracing_amd.bundle import RayBundle
+
+REL_TOL = 1e-10
+
+
+def build_support(d):
+    cls = {"round": msupp.SupportRound, "roundhole": msupp.SupportRoundHole, "rect": msupp.SupportRectangle,
+           "recthole": msupp.SupportRectangleHole, "rectrecthole": msupp.SupportRectangleRectHole}[d["kind"]]
+    return cls(*d["p"])
+
+
+def build_optic(e):
+    S = build_support(e["support"])
+    k = e["kind"]
+    if k == "plane":
+        O = mmirror.MirrorPlane(S)
+    elif k == "sphere":
+        O = mmirror.MirrorSpherical(-e["R"] if "CX" in e["type"] else e["R"], S)
+    elif k == "cylinder":
+        O = mmirror.MirrorCylindrical(-e["R"] if "CX" in e["type"] else e["R"], S)
+    elif k == "parabola":
+        O = mmirror.MirrorParabolic(e["feff"], np.rad2deg(e["offaxis_rad"]), S)
+    elif k == "torus":
+        O = mmirror.MirrorToroidal(e["R"], e["r"], S)
+    elif k == "ellipsoid":
+        O = mmirror.MirrorEllipsoidal(S, SemiMajorAxis=e["a"], SemiMinorAxis=e["b"],
+                                      OffAxisAngle=np.rad2deg(e["offaxis_rad"]))
+    elif k == "mask":
+        O = mmask.Mask(S)
+    else:
+        raise ValueError(k)
+    if e.get("defects"):
+        defs = [mdef.Zernike(S, {(int(c[0]), int(c[1])): float(c[2]) for c in z["coeffs"]}) for z in e["defects"]]
+        O = mmirror.DeformedMirror(O, defs)
+    return O
+
+
+def build_elements(scene):
+    els = []
+    for e in scene["elements"]:
+        O = build_optic(e)
+        assert O.type == e["type"]
+        c = np.asarray(O.get_centre(), dtype=float)
+        assert np.abs(c - np.array(e["centre"])).max() <= 1e-12 * max(1.0, np.abs(c).max())
+        els.append(moe.OpticalElement(O, np.array(e["position"], float), np.array(e["normal"], float),
+                                      np.array(e["majoraxis"], float)))
+    return els
+
+
+def source_bundle(a, scene):
+    inten = a["src_intensity"]
+    return RayBundle.from_arrays(a["src_point"], a["src_vector"], a["src_number"],
+                                 None if np.isnan(inten).all() else inten, scene.get("wavelength"))
+
+
+def scene_scale(a, scene):
+    return max(1.0, np.abs(a["src_point"]).max(), *(np.abs(np.array(e["position"])).max() for e in scene["elements"]))
+
+
+def check_outputs(out, a, scene, report=None):
+    """Compare the product's bundles with the reference's; returns the worst relative errors."""
+    scale = scene_scale(a, scene)
+    worst = {"pos": 0.0, "dir": 0.0, "path": 0.0, "inc": 0.0}
+    assert [len(o) for o in out] == scene["n_out"], ([len(o) for o in out], scene["n_out"])
+    for k, o in enumerate(out):
+        assert np.array_equal(o.numbers(), a[f"out{k}_number"]), f"survivor indices differ after element {k}"
+        if len(o) == 0:
+            continue
+        ref_path = a[f"out{k}_path"]
+        mean_path = max(np.mean(np.sum(ref_path, axis=1)), 1e-300)
+        e_pos = np.abs(o.points() - a[f"out{k}_point"]).max() / scale
+        e_dir = np.abs(o.vectors() - a[f"out{k}_vector"]).max()
+        e_path = np.abs(o.paths_total() - np.sum(ref_path, axis=1)).max() / max(mean_path, 1.0)
+        e_inc = np.abs(o.incidences() - a[f"out{k}_incidence"]).max()
+        seg = o.path_segments()
+        assert seg.shape == ref_path.shape
+        e_seg = np.abs(seg - ref_path).max() / max(mean_path, 1.0)
+        for key, v in (("pos", e_pos), ("dir", e_dir), ("path", max(e_path, e_seg)), ("inc", e_inc)):
+            worst[key] = max(worst[key], float(v))
+        assert e_pos <= REL_TOL, f"element {k}: position error {e_pos:.3e}"
+        assert e_dir <= REL_TOL, f"element {k}: direction error {e_dir:.3e}"
+        assert max(e_path, e_seg) <= REL_TOL, f"element {k}: path error {max(e_path, e_seg):.3e}"
+        assert e_inc <= 1e-9, f"element {k}: incidence error {e_inc:.3e}"
+    return worst

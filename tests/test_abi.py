@@ -1,0 +1,84 @@
+"""CPU: the C-ABI library loads and exports every symbol include/art_hip.h declares; the ctypes mirror matches
+the C struct sizes; the product refuses to trace without a GPU (no silent CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    if g._stale(g.HIP_LIB, g.HIP_DEPS):
+        g.build()
+    return C.CDLL(g.HIP_LIB)
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from attosecondraytracing_amd import _abi
+    hdr = open(os.path.join(ROOT, "include", "art_hip.h")).read()
+    declared = set(re.findall(r"\b(art_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_abi.PROTOTYPES), declared ^ set(_abi.PROTOTYPES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    _abi.bind(lib)
+    assert lib.art_abi_version() == _abi.ART_ABI_VERSION
+
+
+def test_struct_layout_matches_header():
+    """Compile a tiny C program against the header and compare sizeof/offsetof with the ctypes mirror."""
+    import subprocess
+    import tempfile
+    from attosecondraytracing_amd import _abi
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "art_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(ArtElementDesc), offsetof(ArtElementDesc, fwd),
+         offsetof(ArtElementDesc, sp), offsetof(ArtElementDesc, zern), sizeof(ArtBundleView),
+         sizeof(ArtDetectorDesc), (size_t)ART_ZERN_STRIDE);
+  return 0;
+}'''
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(td, "t")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", exe, c])
+        vals = [int(v) for v in subprocess.check_output([exe]).split()]
+    E = _abi.ArtElementDesc
+    assert vals == [C.sizeof(E), E.fwd.offset, E.sp.offset, E.zern.offset, C.sizeof(_abi.ArtBundleView),
+                    C.sizeof(_abi.ArtDetectorDesc), _abi.ART_ZERN_STRIDE]
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product path must fail loudly."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from attosecondraytracing_amd import _lib
+    old = _lib._BACKEND
+    _lib._BACKEND = None
+    try:
+        with pytest.raises(RuntimeError, match="no CPU fallback|No HIP device"):
+            _lib.get_backend()
+        import numpy as np
+        import ART.ModuleOpticalRay as mray
+        import ART.ModuleProcessing as mp
+        with pytest.raises(RuntimeError):
+            mp.RayTracingCalculation([mray.Ray(np.zeros(3), np.array([1.0, 0, 0]))], [])
+    finally:
+        _lib._BACKEND = old
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "attosecondraytracing_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+                assert "_twin" not in txt and "art_cpu_" not in txt, f

@@ -1,0 +1,212 @@
+"""GPU (-m gpu): the HIP kernels, called through the C ABI (libart_hip.so via ctypes), against (i) the golden
+vectors the reference produced and (ii) the CPU oracle on seeded inputs, plus size-independent properties at
+BASELINE sizes.  Tolerances: survivor indices bit-exact; positions, directions, optical paths 1e-10 relative;
+delays 1e-10 of the mean travel time (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from conftest import chain_golden_names, load_golden
+import parity_common as pc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    from attosecondraytracing_amd import _lib
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    _lib._BACKEND = None
+    be = _lib.get_backend()
+    assert be.name == "hip"
+    return be
+
+
+@pytest.mark.parametrize("mode", ["element", "chain"])
+@pytest.mark.parametrize("name", chain_golden_names())
+def test_gpu_chain_matches_reference(hip, name, mode):
+    import ART.ModuleProcessing as mp
+    scene, a = load_golden(name)
+    els = pc.build_elements(scene)
+    src = pc.source_bundle(a, scene)
+    out = mp.RayTracingCalculation(src, els, IgnoreDefects=scene.get("IgnoreDefects", True), mode=mode)
+    pc.check_outputs(out, a, scene)
+
+
+@pytest.mark.parametrize("name", [n for n in chain_golden_names() if not n.startswith("frame_")])
+def test_gpu_detector_matches_reference(hip, name):
+    import ART.ModuleProcessing as mp
+    import ART.ModuleDetector as mdet
+    import ART.ModuleAnalysisAndPlots as mplots
+    scene, a = load_golden(name)
+    if "detector" not in scene:
+        pytest.skip("no detector in fixture")
+    els = pc.build_elements(scene)
+    src = pc.source_bundle(a, scene)
+    last = mp.RayTracingCalculation(src, els, IgnoreDefects=scene.get("IgnoreDefects", True))[-1]
+    d = scene["detector"]
+    scale = max(1.0, np.abs(a["det_points3d"]).max())
+    if name != "autofocus_c3":
+        D = mdet.Detector(np.array(els[-1].position, float))
+        D.autoplace(last, d["distance"])
+        assert np.abs(D.centre - d["centre"]).max() <= 1e-10 * scale
+        assert np.abs(D.normal - d["normal"]).max() <= 1e-10
+    D = mdet.Detector(np.array(d["refpoint"]), np.array(d["centre"]), np.array(d["normal"]))
+    assert np.abs(D.get_PointList3D(last) - a["det_points3d"]).max() <= 1e-10 * scale
+    assert np.abs(D.get_PointList2D(last) - a["det_points2d"]).max() <= 1e-10 * scale
+    assert np.abs(D.get_PointList2DCentre(last) - a["det_points2dcentre"]).max() <= 1e-10 * scale
+    mean_t_fs = np.mean(D.get_OpticalPaths(last)) / mdet.LightSpeed * 1e15
+    assert np.abs(D.get_Delays(last) - a["det_delays"]).max() <= 1e-10 * mean_t_fs
+    spot, dur = mplots.GetResultSummary(D, last, False)
+    assert abs(spot - scene["SpotSizeSD"]) <= 1e-9 * scale
+    assert abs(dur - scene["DurationSD"]) <= 1e-10 * mean_t_fs
+    assert abs(mplots.getETransmission(src, last) - scene["ETransmission"]) <= 1e-9
+
+
+def _c3_chain(n, twist=30.0):
+    import ART.ModuleMirror as mmirror
+    import ART.ModuleMask as mmask
+    import ART.ModuleSupport as msupp
+    import ART.ModuleProcessing as mp
+    SourceProperties = {"Divergence": 50e-3 / 2, "SourceSize": 0, "Wavelength": 50e-6, "DeltaFT": 0.5,
+                        "NumberRays": n}
+    Mask = mmask.Mask(msupp.SupportRoundHole(30, 41e-3 / 2 * 500, 0, 0))
+    R, r = mmirror.ReturnOptimalToroidalRadii(600, 80)
+    Tor = mmirror.MirrorToroidal(R, r, msupp.SupportRectangle(200, 30))
+    return mp.OEPlacement(SourceProperties, [Mask, Tor, Tor], [500, 100, 600], [0, 80, -80], [0, 0, twist], "c3")
+
+
+def test_gpu_vs_oracle_seeded_c3(hip):
+    """1e5 seeded rays through the C3 scene: HIP vs the CPU oracle (same inputs)."""
+    from oracle import art_oracle as orc
+    n = 100_000
+    chain = _c3_chain(n)
+    out = chain.get_output_rays()
+    src = chain.source_rays
+    B = orc.make_bundle(src.data[0:3].cpu().numpy().T, src.data[3:6].cpu().numpy().T, np.arange(n),
+                        src.intensity.cpu().numpy(), 50e-6)
+    els = []
+    for oe in chain.optical_elements:
+        o = oe.type
+        kind = "mask" if o.type == "Mask" else "torus"
+        params = {"R": o.majorradius, "r": o.minorradius} if kind == "torus" else {}
+        sk = {1: "roundhole", 2: "rect"}[o.support._abi_kind]
+        els.append(orc.Element(orc.Optic(kind, orc.Support(sk, o.support._abi_params()), params, [], o.type),
+                               np.asarray(oe.position, float), oe.normal, oe.majoraxis))
+    ref = orc.ray_tracing_calculation(B, els)
+    for o, q in zip(out, ref):
+        assert np.array_equal(o.numbers(), q.number)
+        assert np.abs(o.points() - q.point).max() <= 1e-10 * 2000
+        assert np.abs(o.vectors() - q.vector).max() <= 1e-10
+        assert np.abs(o.paths_total() - q.path.sum(axis=1)).max() <= 1e-10 * q.path.sum(axis=1).mean()
+
+
+def test_gpu_full_size_properties(hip):
+    """BASELINE size (1e7 rays, C3 scene): size-independent properties instead of a CPU comparison.
+    (a) a contiguous sub-range traced alone gives bit-identical results to the same slots of the full run
+        (rays are independent: sharding is exact); (b) survivors' directions are unit vectors; (c) every hit
+        point of the last toroid lies on the torus implicit surface; (d) chain mode == element mode bitwise."""
+    import torch
+    import ART.ModuleProcessing as mp
+    from attosecondraytracing_amd.bundle import RayBundle
+    n = 10_000_000
+    chain = _c3_chain(n)
+    src = chain.source_rays
+    els = chain.optical_elements
+    out_c = mp.RayTracingCalculation(src, els, mode="chain")
+    out_e = mp.RayTracingCalculation(src, els, mode="element")
+    for a, b in zip(out_c, out_e):
+        assert torch.equal(a.alive, b.alive)
+        m = a.alive.bool()
+        assert torch.equal(a.data[:, m], b.data[:, m])
+    last = out_c[-1]
+    m = last.alive.bool()
+    assert abs(int(m.sum().item()) / n - 0.673) < 0.01      # SURVEY: mask passes 67.3 %
+    d = last.data[3:6, m]
+    assert float((d.pow(2).sum(0) - 1).abs().max()) < 1e-14
+    # (a) shard [3e6, 4e6)
+    lo, hi = 3_000_000, 4_000_000
+    sub = RayBundle(src.data[:, lo:hi].contiguous(), src.alive[lo:hi].contiguous(), None,
+                    src.intensity[lo:hi].contiguous(), src.wavelength, None, src.backend)
+    out_s = mp.RayTracingCalculation(sub, els)
+    assert torch.equal(out_s[-1].alive, last.alive[lo:hi])
+    ms = out_s[-1].alive.bool()
+    assert torch.equal(out_s[-1].data[:, ms], last.data[:, lo:hi][:, ms])
+    # (c) implicit surface residual in the optic frame of the last toroid
+    from attosecondraytracing_amd import ModuleGeometry as mgeo
+    oe = els[-1]
+    fwd, _ = mgeo.frame_maps(oe.normal, oe.majoraxis)
+    P = last.data[0:3, m][:, ::97].cpu().numpy().T
+    Po = (P - np.asarray(oe.position, float)) @ fwd.T + oe.type.get_centre()
+    R, r = oe.type.majorradius, oe.type.minorradius
+    res = (np.sqrt(Po[:, 0] ** 2 + Po[:, 2] ** 2) - R) ** 2 + Po[:, 1] ** 2 - r ** 2
+    assert np.abs(res).max() <= 1e-8        # ~ r * 2e-11 mm normal distance
+
+
+def test_gpu_compaction_and_reductions(hip):
+    import torch
+    be = hip
+    g = torch.Generator().manual_seed(3)
+    for n in (1, 63, 64, 2048, 2049, 1_000_003):
+        alive = (torch.rand(n, generator=g) < 0.37).to(torch.uint8).to(be.device)
+        idx, c = be.compact(alive, n)
+        ref = torch.nonzero(alive, as_tuple=False).reshape(-1)
+        assert c == ref.numel()
+        assert torch.equal(idx, ref)
+    n = 1_000_003
+    X = torch.randn(n, generator=g, dtype=torch.float64).to(be.device)
+    Y = torch.randn(n, generator=g, dtype=torch.float64).to(be.device)
+    O = (torch.rand(n, generator=g, dtype=torch.float64) + 1000).to(be.device)
+    W = torch.rand(n, generator=g, dtype=torch.float64).to(be.device)
+    s = be.detector_stats(alive, X, Y, O, W, n)
+    m = alive.bool()
+    assert s[0] == int(m.sum())
+    assert abs(s[1] - float(O[m].sum())) <= 1e-12 * abs(float(O[m].sum()))
+    assert s[2] == float(X[m].min()) and s[3] == float(X[m].max())
+    assert s[4] == float(Y[m].min()) and s[5] == float(Y[m].max())
+    assert abs(s[9] - float((W * X)[m].sum())) <= 1e-10 * float((W * X.abs())[m].sum())
+    assert abs(s[11] - float((W * O)[m].sum())) <= 1e-12 * float((W * O)[m].sum())
+    mo = be.detector_moments(alive, X, Y, O, W, n, 0.1, -0.2, 1000.5)
+    assert abs(mo[1] - float((W * (X - 0.1) ** 2)[m].sum())) <= 1e-11 * mo[1]
+    assert abs(mo[3] - float((W * (O - 1000.5) ** 2)[m].sum())) <= 1e-11 * mo[3]
+    s2 = be.detector_stats(alive, X, Y, O, W, n)
+    assert np.array_equal(s, s2), "reductions must be deterministic"
+
+
+def test_gpu_sources_match_oracle(hip):
+    import ART.ModuleSource as msource
+    from oracle import art_oracle as orc
+    n = 20000
+    S = np.array([1.0, -2.0, 3.0])
+    ax = np.array([0.3, -0.2, 0.9])
+    b = msource.ApplyGaussianIntensityToRayList(msource.PointSource(S, ax, 0.05, n, 50e-6))
+    q = orc.apply_gaussian_intensity(orc.point_source(S, ax, 0.05, n))
+    assert np.abs(b.points() - q.point).max() <= 1e-12
+    assert np.abs(b.vectors() - q.vector).max() <= 1e-12
+    assert np.abs(b.intensities() - q.intensity).max() <= 1e-10
+    b = msource.ApplyGaussianIntensityToRayList(msource.PlaneWaveDisk(S, ax, 12.0, n, 50e-6))
+    q = orc.apply_gaussian_intensity(orc.plane_wave_disk(S, ax, 12.0, n))
+    assert len(b) == n - 1
+    assert np.abs(b.points() - q.point).max() <= 1e-10 * 12
+    assert np.abs(b.vectors() - q.vector).max() <= 1e-12
+    assert np.abs(b.intensities() - q.intensity).max() <= 1e-10
+
+
+def test_gpu_error_paths(hip):
+    """Bad arguments come back as error codes with a message, never as a crash."""
+    import ctypes as C
+    from attosecondraytracing_amd import _abi
+    be = hip
+    d = _abi.ArtElementDesc()
+    d.kind = 99
+    v = _abi.ArtBundleView()
+    rc = be.fn["art_trace_element"](C.byref(d), C.byref(v), C.byref(v), 10, None)
+    assert rc == _abi.ART_ERR_BAD_ARG and b"kind" in be.fn["art_last_error"]()
+    d.kind = 0
+    rc = be.fn["art_trace_element"](C.byref(d), C.byref(v), C.byref(v), 10, None)
+    assert rc == _abi.ART_ERR_BAD_ARG
+
+
+def test_gpu_smoke_entry(hip):
+    import __graft_entry__ as g
+    g.smoke()

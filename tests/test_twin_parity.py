@@ -1,0 +1,60 @@
+"""CPU (-m "not gpu"): the product's host shell + the kernels' per-ray device functions (compiled by g++ as the
+CPU twin) against the reference's golden vectors.  Exercises descriptor packing, frame maps, the closed-form /
+convex-Newton solvers and the Zernike recurrences exactly as the GPU runs them."""
+import numpy as np
+import pytest
+
+from conftest import chain_golden_names, load_golden
+import parity_common as pc
+
+
+@pytest.fixture(scope="module")
+def twin():
+    from twin_backend import TwinBackend
+    from attosecondraytracing_amd import _lib
+    old = _lib._BACKEND
+    _lib._BACKEND = TwinBackend()
+    yield _lib._BACKEND
+    _lib._BACKEND = old
+
+
+@pytest.mark.parametrize("mode", ["element", "chain"])
+@pytest.mark.parametrize("name", chain_golden_names())
+def test_twin_chain_matches_reference(twin, name, mode):
+    import ART.ModuleProcessing as mp
+    scene, a = load_golden(name)
+    els = pc.build_elements(scene)
+    src = pc.source_bundle(a, scene)
+    out = mp.RayTracingCalculation(src, els, IgnoreDefects=scene.get("IgnoreDefects", True), mode=mode)
+    pc.check_outputs(out, a, scene)
+
+
+@pytest.mark.parametrize("name", [n for n in chain_golden_names() if not n.startswith("frame_")])
+def test_twin_detector_matches_reference(twin, name):
+    import ART.ModuleProcessing as mp
+    import ART.ModuleDetector as mdet
+    import ART.ModuleAnalysisAndPlots as mplots
+    scene, a = load_golden(name)
+    if "detector" not in scene:
+        pytest.skip("no detector in fixture")
+    els = pc.build_elements(scene)
+    src = pc.source_bundle(a, scene)
+    last = mp.RayTracingCalculation(src, els, IgnoreDefects=scene.get("IgnoreDefects", True))[-1]
+    d = scene["detector"]
+    scale = max(1.0, np.abs(a["det_points3d"]).max())
+    if name != "autofocus_c3":
+        D = mdet.Detector(np.array(els[-1].position, float))
+        D.autoplace(last, d["distance"])
+        assert np.abs(D.centre - d["centre"]).max() <= 1e-10 * scale
+        assert np.abs(D.normal - d["normal"]).max() <= 1e-10
+        assert abs(D.get_distance() - d["distance"]) <= 1e-10 * max(1.0, d["distance"])
+    D = mdet.Detector(np.array(d["refpoint"]), np.array(d["centre"]), np.array(d["normal"]))
+    assert np.abs(D.get_PointList3D(last) - a["det_points3d"]).max() <= 1e-10 * scale
+    assert np.abs(D.get_PointList2D(last) - a["det_points2d"]).max() <= 1e-10 * scale
+    assert np.abs(D.get_PointList2DCentre(last) - a["det_points2dcentre"]).max() <= 1e-10 * scale
+    mean_t_fs = np.mean(D.get_OpticalPaths(last)) / mdet.LightSpeed * 1e15
+    assert np.abs(D.get_Delays(last) - a["det_delays"]).max() <= 1e-10 * mean_t_fs
+    spot, dur = mplots.GetResultSummary(D, last, False)
+    assert abs(spot - scene["SpotSizeSD"]) <= 1e-9 * scale
+    assert abs(dur - scene["DurationSD"]) <= 1e-10 * mean_t_fs
+    assert abs(mplots.getETransmission(src, last) - scene["ETransmission"]) <= 1e-9

@@ -1,0 +1,120 @@
+"""TEST-ONLY backend: runs the host-side package against the CPU twin of the kernels (oracle/_twin/libart_twin.so,
+same per-ray device functions compiled by g++) so that the API shell, descriptor packing and the kernel math can
+be exercised in a container without a GPU.  The product never imports this; GPU tests use the real HipBackend."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+from attosecondraytracing_amd import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TWIN = os.path.join(ROOT, "oracle", "_twin", "libart_twin.so")
+
+
+def build_twin():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL,
+                          stderr=subprocess.DEVNULL)
+    return TWIN
+
+
+class TwinBackend:
+    name = "twin"
+
+    def __init__(self):
+        build_twin()
+        self.lib = C.CDLL(TWIN)
+        self.device = torch.device("cpu")
+        self.lib.art_cpu_trace_element.restype = C.c_int
+        self.lib.art_cpu_trace_element.argtypes = [C.POINTER(_abi.ArtElementDesc), C.POINTER(_abi.ArtBundleView),
+                                                   C.POINTER(_abi.ArtBundleView), C.c_int64]
+        self.lib.art_cpu_trace_chain.restype = C.c_int
+        self.lib.art_cpu_trace_chain.argtypes = [C.POINTER(_abi.ArtElementDesc), C.c_int32,
+                                                 C.POINTER(_abi.ArtBundleView), C.POINTER(_abi.ArtBundleView),
+                                                 C.c_int64]
+        self.lib.art_cpu_detector.restype = C.c_int
+        self.lib.art_cpu_detector.argtypes = [C.POINTER(_abi.ArtDetectorDesc), C.POINTER(_abi.ArtBundleView),
+                                              C.c_int64] + [C.c_void_p] * 6
+        self.lib.art_cpu_make_source.restype = C.c_int
+        self.lib.art_cpu_make_source.argtypes = [C.c_int32, C.c_double, _abi.c_double_p, _abi.c_double_p, C.c_int64,
+                                                 C.c_int64, C.c_int64, C.POINTER(_abi.ArtBundleView)]
+
+    def synchronize(self):
+        pass
+
+    def empty(self, n, dtype=torch.float64):
+        return torch.empty(int(n), dtype=dtype)
+
+    def zeros(self, n, dtype=torch.float64):
+        return torch.zeros(int(n), dtype=dtype)
+
+    def from_numpy(self, a, dtype=None):
+        t = torch.from_numpy(np.array(a, copy=True))
+        return t if dtype is None else t.to(dtype)
+
+    def trace_element(self, desc, vin, vout, n):
+        assert self.lib.art_cpu_trace_element(C.byref(desc), C.byref(vin), C.byref(vout), n) == 0
+
+    def trace_chain(self, descs, vin, vouts, n):
+        m = len(descs)
+        darr = (_abi.ArtElementDesc * m)(*descs)
+        varr = (_abi.ArtBundleView * m)(*vouts)
+        assert self.lib.art_cpu_trace_chain(darr, m, C.byref(vin), varr, n) == 0
+
+    def detector(self, ddesc, view, n, p3=None, XY=None, opl=None):
+        p = [t.data_ptr() for t in p3] if p3 is not None else [None, None, None]
+        xy = [t.data_ptr() for t in XY] if XY is not None else [None, None]
+        o = opl.data_ptr() if opl is not None else None
+        assert self.lib.art_cpu_detector(C.byref(ddesc), C.byref(view), n, p[0], p[1], p[2], xy[0], xy[1], o) == 0
+
+    @staticmethod
+    def _np(t):
+        return None if t is None else t.numpy()
+
+    def detector_stats(self, alive, X, Y, opl, w, n):
+        a = alive.numpy().astype(bool)
+        X, Y, opl, w = (self._np(t) for t in (X, Y, opl, w))
+        z = np.zeros(int(a.sum()))
+        x = X[a] if X is not None else z
+        y = Y[a] if Y is not None else z
+        o = opl[a] if opl is not None else z
+        ww = w[a] if w is not None else np.ones_like(z)
+        out = np.zeros(16)
+        if len(z):
+            out[:14] = [len(z), o.sum(), x.min(), x.max(), y.min(), y.max(), x.sum(), y.sum(), ww.sum(),
+                        (ww * x).sum(), (ww * y).sum(), (ww * o).sum(), o.min(), o.max()]
+        return out
+
+    def detector_moments(self, alive, X, Y, opl, w, n, cx, cy, co):
+        a = alive.numpy().astype(bool)
+        X, Y, opl, w = (self._np(t) for t in (X, Y, opl, w))
+        ww = w[a] if w is not None else np.ones(int(a.sum()))
+        out = np.zeros(8)
+        out[0] = ww.sum()
+        out[1] = (ww * (X[a] - cx) ** 2).sum() if X is not None else 0
+        out[2] = (ww * (Y[a] - cy) ** 2).sum() if Y is not None else 0
+        out[3] = (ww * (opl[a] - co) ** 2).sum() if opl is not None else 0
+        out[4] = a.sum()
+        return out
+
+    def bundle_sums(self, view, w, n):
+        def arr(ptr, ty=C.c_double):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ty)), shape=(n,))
+        a = arr(view.alive, C.c_uint8).astype(bool)
+        out = np.zeros(8)
+        out[0] = a.sum()
+        for j, f in enumerate(("ox", "oy", "oz", "dx", "dy", "dz")):
+            out[1 + j] = arr(getattr(view, f))[a].sum()
+        out[7] = w.numpy()[a].sum() if w is not None else 0.0
+        return out
+
+    def compact(self, alive, n):
+        idx = torch.nonzero(alive, as_tuple=False).reshape(-1)
+        return idx, int(idx.numel())
+
+    def make_source(self, kind, size, rot, S, first, n, n_total, view):
+        r = (C.c_double * 9)(*[float(v) for v in np.asarray(rot).reshape(9)])
+        s = (C.c_double * 3)(*[float(v) for v in np.asarray(S).reshape(3)])
+        assert self.lib.art_cpu_make_source(kind, float(size), r, s, first, n, n_total, C.byref(view)) == 0
