@@ -93,11 +93,11 @@ class Detector:
         d.rot[:] = [float(v) for v in mgeo.rotation_matrix(self.normal, np.array([0.0, 0.0, 1.0])).reshape(9)]
         return d
 
-    def readout(self, RayList, points3d=False):
+    def readout(self, RayList, points3d=False, sync=True):
         """Device tensors of the read-out, one entry per slot of the bundle (valid where alive):
         dict with 'X', 'Y' (detector-plane coordinates about Detector.centre, ART/ModuleDetector.py:212-234),
         'opl' (optical path to the detector, :272-275), optionally 'P3' (3 tensors, :191-210), and 'stats'
-        (host array of art_detector_stats)."""
+        (art_detector_stats: host array, or with sync=False a device tensor 'stats_dev' so that nothing blocks)."""
         self._iscomplete()
         B = RayList if isinstance(RayList, RayBundle) else RayBundle.from_ray_list(RayList)
         be = B.backend
@@ -105,8 +105,8 @@ class Detector:
         X, Y, opl = be.empty(n), be.empty(n), be.empty(n)
         P3 = [be.empty(n), be.empty(n), be.empty(n)] if points3d else None
         be.detector(self._desc(), B.view(), n, P3, (X, Y), opl)
-        stats = be.detector_stats(B.alive, X, Y, opl, B.intensity, n)
-        return {"bundle": B, "X": X, "Y": Y, "opl": opl, "P3": P3, "stats": stats}
+        stats = be.detector_stats(B.alive, X, Y, opl, B.intensity, n, to_host=sync)
+        return {"bundle": B, "X": X, "Y": Y, "opl": opl, "P3": P3, ("stats" if sync else "stats_dev"): stats}
 
     def _spot_and_duration(self, RayList, weighted, need_spot=True, need_duration=True):
         """Std of the centred 2D points and of the delays (ART/ModuleProcessing.py:327-341), on device."""

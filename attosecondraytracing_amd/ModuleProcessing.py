@@ -27,9 +27,25 @@ DEFAULT_TRACE_MODE = os.environ.get("ART_TRACE_MODE", "chain")
 
 
 # ------------------------------------------------------------------------------------------- descriptors
+_DESC_CACHE = {}
+
+
 def element_descriptor(oe, IgnoreDefects=True, backend=None):
     """ArtElementDesc (include/art_hip.h) of one OpticalElement; returns (desc, keepalive) where keepalive
-    holds device tensors the descriptor points to."""
+    holds device tensors the descriptor points to.  Cached per element object until its pose/parameters change."""
+    key = (id(oe), bool(IgnoreDefects))
+    h = hash(oe)
+    hit = _DESC_CACHE.get(key)
+    if hit is not None and hit[0] == h and hit[3] is oe:
+        return hit[1], hit[2]
+    d, keep = _build_descriptor(oe, IgnoreDefects, backend)
+    if len(_DESC_CACHE) > 4096:
+        _DESC_CACHE.clear()
+    _DESC_CACHE[key] = (h, d, keep, oe)
+    return d, keep
+
+
+def _build_descriptor(oe, IgnoreDefects, backend):
     optic = oe.type
     kind = getattr(optic, "_abi_kind", None)
     tname = getattr(optic, "type", None)

@@ -46,6 +46,7 @@ class HipBackend:
                                % (n, self.last_error()))
         self.device = torch.device("cuda", torch.cuda.current_device())
         self._scratch = {}
+        self.trace_events = None   # set to a list to collect (start, end) HIP events around each trace launch
 
     # ------------------------------------------------------------------ helpers
     def last_error(self):
@@ -81,15 +82,28 @@ class HipBackend:
         return t
 
     # ------------------------------------------------------------------ entry points
+    def _timed(self, call):
+        """Run one launch; when trace_events is a list, bracket it with HIP events recorded on the launch stream."""
+        if self.trace_events is None:
+            return call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = call()
+        e1.record()
+        self.trace_events.append((e0, e1))
+        return rc
+
     def trace_element(self, desc, view_in, view_out, n):
-        self.check(self.fn["art_trace_element"](C.byref(desc), C.byref(view_in), C.byref(view_out), n,
-                                                self.stream_ptr()), "art_trace_element")
+        sp = self.stream_ptr()
+        self.check(self._timed(lambda: self.fn["art_trace_element"](C.byref(desc), C.byref(view_in),
+                                                                    C.byref(view_out), n, sp)), "art_trace_element")
 
     def trace_chain(self, descs, view_in, views_out, n):
         m = len(descs)
         darr = (_abi.ArtElementDesc * m)(*descs)
         varr = (_abi.ArtBundleView * m)(*views_out)
-        self.check(self.fn["art_trace_chain"](darr, m, C.byref(view_in), varr, n, self.stream_ptr()),
+        sp = self.stream_ptr()
+        self.check(self._timed(lambda: self.fn["art_trace_chain"](darr, m, C.byref(view_in), varr, n, sp)),
                    "art_trace_chain")
 
     def detector(self, ddesc, view, n, p3=None, XY=None, opl=None):
@@ -102,13 +116,13 @@ class HipBackend:
     def _red_scratch(self):
         return self.scratch("red", self.fn["art_reduce_scratch_doubles"](), torch.float64)
 
-    def detector_stats(self, alive, X, Y, opl, w, n):
+    def detector_stats(self, alive, X, Y, opl, w, n, to_host=True):
         out = self.empty(16)
         ptr = lambda t: None if t is None else t.data_ptr()
         self.check(self.fn["art_detector_stats"](alive.data_ptr(), ptr(X), ptr(Y), ptr(opl), ptr(w), n,
                                                  self._red_scratch().data_ptr(), out.data_ptr(), self.stream_ptr()),
                    "art_detector_stats")
-        return out.cpu().numpy()
+        return out.cpu().numpy() if to_host else out
 
     def detector_moments(self, alive, X, Y, opl, w, n, cx, cy, co):
         out = self.empty(8)

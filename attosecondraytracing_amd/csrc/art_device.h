@@ -49,14 +49,110 @@ ART_HD void mat3_apply(const double* M, double x, double y, double z, double& rx
   rz = fma(M[6], x, fma(M[7], y, M[8] * z));
 }
 
+ART_HD void mat3t_apply(const double* M, double x, double y, double z, double& rx, double& ry, double& rz) {
+  // transpose of M: the frame maps are orthogonal (rotations and the point inversion -I), so the way back
+  // is the transpose of the way in
+  rx = fma(M[0], x, fma(M[3], y, M[6] * z));
+  ry = fma(M[1], x, fma(M[4], y, M[7] * z));
+  rz = fma(M[2], x, fma(M[5], y, M[8] * z));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fp64 reciprocal / reciprocal square root built on the gfx950 hardware seeds (v_rcp_f64 / v_rsq_f64, ~2^-23
+// relative) and fused Newton-Raphson steps.  Operands on this path are ordinary magnitudes (mm-scale lengths,
+// unit-vector dot products): no denormal/overflow scaling is needed, which is what makes these sequences a
+// third of the instruction count of the IEEE division / square root expansions.
+ART_HD double rcp_seed(double x) {  // ~1e-7 relative: enough for a Newton STEP (the iteration self-corrects)
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcp(x);
+#else
+  return 1.0 / x;
+#endif
+}
+ART_HD double rcp_full(double x) {  // <= 1 ulp-level: two Newton-Raphson steps on the seed
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(fma(-x, y, 1.0), y, y);
+  y = fma(fma(-x, y, 1.0), y, y);
+  return y;
+#else
+  return 1.0 / x;
+#endif
+}
+ART_HD double div_full(double a, double b) {  // a / b with one residual correction
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double y = rcp_full(b);
+  const double q = a * y;
+  return fma(fma(-b, q, a), y, q);
+#else
+  return a / b;
+#endif
+}
+ART_HD double rsqrt_full(double x) {  // 1/sqrt(x), x > 0 finite
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  y = y * fma(-hx * y, y, 1.5);
+  y = y * fma(-hx * y, y, 1.5);
+  return y;
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
+// sqrt(x) and 1/sqrt(x) together; sqrt gets a final residual correction (error < 1 ulp for x > 0)
+ART_HD void sqrt_rsqrt(double x, double& s, double& rs) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  rs = rsqrt_full(x);
+  const double g = x * rs;
+  s = fma(fma(-g, g, x), 0.5 * rs, g);
+#else
+  s = sqrt(x);
+  rs = 1.0 / s;
+#endif
+}
+ART_HD double sqrt_seed(double x) {  // single-precision accuracy: starting points only
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (double)__builtin_sqrtf((float)x);
+#else
+  return sqrt(x);
+#endif
+}
+
+// atan(q) for 0 <= q <= 1 (half the Kahan angle): table-free argument reduction to |t| <= tan(pi/16) by
+// atan(q) = atan(c) + atan((q - c) / (1 + q c)), c in {0, tan(pi/8), tan(pi/4)... } then an odd polynomial.
+ART_HD double atan01(double q) {
+  // breakpoints c_k = tan(k pi/8), k = 0..2; intervals split at tan(pi/16), tan(3pi/16)
+  double c = 0.0, ac = 0.0;
+  if (q > 0.19891236737965800691) { c = 0.41421356237309504880; ac = 0.39269908169872415481; }
+  if (q > 0.66817863791929891999) { c = 1.0; ac = 0.78539816339744830962; }
+  const double t = div_full(q - c, fma(q, c, 1.0));
+  const double z = t * t;  // |t| <= tan(pi/16) = 0.1989: z <= 0.0396, series to z^10 is < 1e-16 relative
+  double p = -1.0 / 21.0;
+  p = fma(p, z, 1.0 / 19.0);
+  p = fma(p, z, -1.0 / 17.0);
+  p = fma(p, z, 1.0 / 15.0);
+  p = fma(p, z, -1.0 / 13.0);
+  p = fma(p, z, 1.0 / 11.0);
+  p = fma(p, z, -1.0 / 9.0);
+  p = fma(p, z, 1.0 / 7.0);
+  p = fma(p, z, -1.0 / 5.0);
+  p = fma(p, z, 1.0 / 3.0);
+  return ac + fma(-t * z, p, t);
+}
+
 // Kahan angle between two UNIT vectors, ART/ModuleGeometry.py:40-44: 2*atan2(|U-V|, |U+V|).
 // (the reference scales by the two norms first; they are 1 +- 1e-16 here.)
 ART_HD double kahan_angle_unit(double ux, double uy, double uz, double vx, double vy, double vz) {
   double ax = ux - vx, ay = uy - vy, az = uz - vz;
   double bx = ux + vx, by = uy + vy, bz = uz + vz;
-  double a2 = dot3(ax, ay, az, ax, ay, az);
-  double b2 = dot3(bx, by, bz, bx, by, bz);
-  return 2.0 * atan2(sqrt(a2), sqrt(b2));
+  const double a2 = dot3(ax, ay, az, ax, ay, az);
+  const double b2 = dot3(bx, by, bz, bx, by, bz);
+  // tan(angle/2) = sqrt(a2/b2); evaluate atan on the ratio <= 1 and reflect for obtuse angles
+  const double lo = fmin(a2, b2), hi = fmax(a2, b2);
+  if (!(hi > 0.0)) return 0.0;
+  const double q = (lo > 0.0) ? lo * rsqrt_full(lo * hi) : 0.0;   // sqrt(lo/hi) = lo / sqrt(lo*hi)
+  const double h = atan01(q);
+  return (a2 <= b2) ? 2.0 * h : 3.14159265358979323846 - 2.0 * h;
 }
 
 // ART/ModuleGeometry.py:249-268, ART/ModuleSupport.py:68-70,:151-155,:228-230,:322-326,:431-435
@@ -86,14 +182,16 @@ ART_HD int quadratic_roots(double a, double b, double c, double& t1, double& t2)
   }
   double disc = fma(b, b, -4.0 * a * c);
   if (!(disc >= 0.0)) return 0;
-  double q = -0.5 * (b + copysign(sqrt(disc), b));
+  double sq = 0.0, rs;
+  if (disc > 0.0) sqrt_rsqrt(disc, sq, rs);
+  double q = -0.5 * (b + copysign(sq, b));
   if (q == 0.0) {  // b == 0 and c == 0: double root at 0
     t1 = 0.0;
     t2 = 0.0;
     return 2;
   }
-  t1 = q / a;
-  t2 = c / q;
+  t1 = q / a;          // a may be tiny (1e-34 for axis-parallel rays on a parabola): keep the IEEE division
+  t2 = div_full(c, q);
   return 2;
 }
 
@@ -176,7 +274,8 @@ ART_HD void zernike_defect(const double* tab, double px, double py, double& h, d
   const double R = tab[0];
   const int order = (int)tab[1];
   const double* coef = tab + 2;
-  const double x = px / R, y = py / R;
+  const double iR = rcp_full(R);
+  const double x = px * iR, y = py * iR;
   double v, gx, gy;
   if (order <= 2) zernike_eval<2>(coef, x, y, v, gx, gy);
   else if (order <= 4) zernike_eval<4>(coef, x, y, v, gx, gy);
@@ -185,8 +284,8 @@ ART_HD void zernike_defect(const double* tab, double px, double py, double& h, d
   else if (order <= 10) zernike_eval<10>(coef, x, y, v, gx, gy);
   else zernike_eval<12>(coef, x, y, v, gx, gy);
   h = v;          // get_offset  :168-174
-  gX = gx / R;    // get_normal  :159-166 returns (-gX, -gY, 1)
-  gY = gy / R;
+  gX = gx * iR;   // get_normal  :159-166 returns (-gX, -gY, 1)
+  gY = gy * iR;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -208,12 +307,13 @@ ART_HD void base_normal(const ArtElementDesc& e, double x, double y, double z, d
     const double kxz = S - R2 - r2, ky = S + R2 - r2;
     gx = -x * kxz; gy = -y * ky; gz = -z * kxz;
   } else if (KIND == ART_ELLIPSOID) {  // :685-693
-    const double ia2 = 1.0 / (e.mp[0] * e.mp[0]), ib2 = 1.0 / (e.mp[1] * e.mp[1]);
-    gx = -x * ia2; gy = -y * ib2; gz = -z * ib2;
+    // same direction as (-x/a^2, -y/b^2, -z/b^2), scaled by a^2 b^2 to avoid two divisions
+    const double a2 = e.mp[0] * e.mp[0], b2 = e.mp[1] * e.mp[1];
+    gx = -x * b2; gy = -y * a2; gz = -z * a2;
   } else {  // cylinder :846-849
     gx = 0.0; gy = -y; gz = -z;
   }
-  const double inv = 1.0 / sqrt(dot3(gx, gy, gz, gx, gy, gz));
+  const double inv = rsqrt_full(dot3(gx, gy, gz, gx, gy, gz));
   nx = gx * inv; ny = gy * inv; nz = gz * inv;
 }
 
@@ -229,12 +329,14 @@ template <int SIDE>
 ART_HD void torus_F(double R, double r2, double x, double y, double z, double ux, double uy, double uz,
                     double& F, double& dF) {
   const double rho2 = fma(x, x, z * z);
-  const double rho = sqrt(rho2);
+  double rho = 0.0, irho = 0.0;
+  if (rho2 > 0.0) sqrt_rsqrt(rho2, rho, irho);
+  const double drho = fma(x, ux, z * uz) * irho;  // d rho / dt (0 on the axis)
   if (SIDE < 0) {
     const double a = rho - R;
     if (a > 0.0) {
       F = fma(a, a, fma(y, y, -r2));
-      dF = 2.0 * fma(a / rho, fma(x, ux, z * uz), y * uy);
+      dF = 2.0 * fma(a, drho, y * uy);
     } else {  // above/below the flat disk: distance is |y|
       F = fma(y, y, -r2);
       dF = 2.0 * y * uy;
@@ -242,7 +344,6 @@ ART_HD void torus_F(double R, double r2, double x, double y, double z, double ux
   } else {
     const double a = rho + R;
     F = fma(a, a, fma(y, y, -r2));
-    const double drho = (rho > 0.0) ? fma(x, ux, z * uz) / rho : 0.0;
     dF = 2.0 * fma(a, drho, y * uy);
   }
 }
@@ -264,10 +365,12 @@ ART_HD bool torus_newton(double R, double r2, double Ax, double Ay, double Az, d
         // root on this side -> no intersection
         active = false;
       } else {
-        const double dt = F / dF;
+        // the step may use the 1e-7-accurate hardware reciprocal: Newton corrects itself, and the LAST step
+        // (|dt| <= 1e-7 |t|) then carries an error <= 1e-7 |dt| ~ 1e-14 |t|
+        const double dt = F * rcp_seed(dF);
         t -= dt;
-        if (fabs(dt) <= 1e-9 * (1.0 + fabs(t)) || ++it >= 60) {
-          // quadratic convergence: the step just taken leaves an error ~ (dt^2) * F''/(2F') << 1 ulp
+        if (fabs(dt) <= 1e-7 * (1.0 + fabs(t)) || ++it >= 60) {
+          // quadratic convergence: the step just taken leaves an error ~ dt^2 * F''/(2F') ~ 1e-14 (1+|t|)^2/(r cos)
           found = true;
           active = false;
         }
@@ -282,13 +385,15 @@ ART_HD bool torus_newton(double R, double r2, double Ax, double Ay, double Az, d
 template <int SIDE>
 ART_HD int torus_body_roots(double R, double r2, double rb, double Ax, double Ay, double Az, double ux, double uy,
                             double uz, double& ta, double& tb) {
-  const double b = 2.0 * dot3(Ax, Ay, Az, ux, uy, uz);
-  const double uu = dot3(ux, uy, uz, ux, uy, uz);
+  // |u| = 1: t^2 + 2 hb t + c = 0.  Only starting points are needed, so a single-precision sqrt is enough; the
+  // miss test keeps a safety margin for it.
+  const double hb = dot3(Ax, Ay, Az, ux, uy, uz);
   const double c = dot3(Ax, Ay, Az, Ax, Ay, Az) - rb * rb;
-  const double disc = fma(b, b, -4.0 * uu * c);
-  bool any = disc >= 0.0;
-  const double sq = any ? sqrt(disc) : 0.0;
-  const double ts1 = (-b - sq) / (2.0 * uu), ts2 = (-b + sq) / (2.0 * uu);
+  const double disc = fma(hb, hb, -c);
+  bool any = disc >= -1e-6 * rb * rb;
+  const double sq = (disc > 0.0) ? sqrt_seed(disc) : 0.0;
+  const double pad = 1e-6 * (rb + fabs(hb));
+  const double ts1 = -hb - sq - pad, ts2 = -hb + sq + pad;
   any = any && (ts2 > 1e-12);
   double F0, dF0;
   torus_F<SIDE>(R, r2, Ax, Ay, Az, ux, uy, uz, F0, dF0);
@@ -296,10 +401,10 @@ ART_HD int torus_body_roots(double R, double r2, double rb, double Ax, double Ay
   // origin outside the body and moving away from it: both roots (if any) are behind the origin
   any = any && (origin_inside || dF0 < 0.0);
   // exit root: start just outside the sphere exit, walk left
-  double t_out = ts2 + 1e-9 * (1.0 + fabs(ts2));
+  double t_out = ts2;
   const bool has_out = torus_newton<SIDE>(R, r2, Ax, Ay, Az, ux, uy, uz, +1.0, any, t_out);
   // entry root only when the origin is outside the body: start at max(ts1, 0), walk right
-  double t_in = (ts1 > 0.0 ? ts1 - 1e-9 * (1.0 + fabs(ts1)) : 0.0);
+  double t_in = (ts1 > 0.0 ? ts1 : 0.0);
   const bool has_in = torus_newton<SIDE>(R, r2, Ax, Ay, Az, ux, uy, uz, -1.0, any && has_out && !origin_inside, t_in);
   int n = 0;
   if (has_in) { ta = t_in; n = 1; }
@@ -344,7 +449,7 @@ ART_HD bool intersect(const ArtElementDesc& e, double Ax, double Ay, double Az, 
       qb = 2.0 * fma(ux, Ax, uy * Ay) - 2.0 * p * uz;
       qc = fma(Ax, Ax, Ay * Ay) - 2.0 * p * Az;
     } else if (KIND == ART_ELLIPSOID) {  // :667-669
-      const double ia2 = 1.0 / (e.mp[0] * e.mp[0]), ib2 = 1.0 / (e.mp[1] * e.mp[1]);
+      const double ia2 = rcp_full(e.mp[0] * e.mp[0]), ib2 = rcp_full(e.mp[1] * e.mp[1]);
       qa = fma(uy, uy, uz * uz) * ib2 + ux * ux * ia2;
       qb = 2.0 * (fma(uy, Ay, uz * Az) * ib2 + ux * Ax * ia2);
       qc = fma(Ay, Ay, Az * Az) * ib2 + Ax * Ax * ia2 - 1.0;
@@ -414,20 +519,21 @@ ART_HD bool trace_ray(const ArtElementDesc& e, const double* zern, Ray& r) {
         h += hd;
       }
       const double cosa = -dot3(ux, uy, uz, nx, ny, nz);
-      const double s = h / cosa;
+      const double s = div_full(h, cosa);
       t -= s;
       Px = fma(-s, ux, Px); Py = fma(-s, uy, Py); Pz = fma(-s, uz, Pz);
       base_normal<KIND>(e, Px, Py, Pz, nx, ny, nz);
       if (e.flags & ART_FLAG_PERTURBED_NORMAL) {
         // DeformedMirror.get_normal, ModuleMirror.py:952-961 with normal_add (ModuleGeometry.py:394-407):
         // surface slopes add up
-        double gXs = -nx / nz, gYs = -ny / nz;
+        const double inz = rcp_full(nz);
+        double gXs = -nx * inz, gYs = -ny * inz;
         for (int d = 0; d < e.n_defects; ++d) {
           double hd, gX, gY;
           zernike_defect(zern + d * ART_ZERN_STRIDE, Px - e.centre[0], Py - e.centre[1], hd, gX, gY);
           gXs += gX; gYs += gY;
         }
-        const double inv = 1.0 / sqrt(fma(gXs, gXs, fma(gYs, gYs, 1.0)));
+        const double inv = rsqrt_full(fma(gXs, gXs, fma(gYs, gYs, 1.0)));
         nx = -gXs * inv; ny = -gYs * inv; nz = inv;
       }
     }
@@ -438,8 +544,10 @@ ART_HD bool trace_ray(const ArtElementDesc& e, const double* zern, Ray& r) {
   }
   // optic -> lab frame (:306-309)
   double ox, oy, oz, dx, dy, dz;
-  mat3_apply(e.bwd, Px - e.centre[0], Py - e.centre[1], Pz - e.centre[2], ox, oy, oz);
-  mat3_apply(e.bwd, vx, vy, vz, dx, dy, dz);
+  // (e.bwd holds the same map built the reference's way; the kernels use the transpose of fwd, which is equal
+  // to it to rounding, to halve the constants they keep in scalar registers)
+  mat3t_apply(e.fwd, Px - e.centre[0], Py - e.centre[1], Pz - e.centre[2], ox, oy, oz);
+  mat3t_apply(e.fwd, vx, vy, vz, dx, dy, dz);
   // Ray.vector setter renormalises (ModuleOpticalRay.py:85-90): one Newton step of 1/sqrt on |d|^2 ~ 1
   const double s2 = dot3(dx, dy, dz, dx, dy, dz);
   const double k = fma(-0.5, s2, 1.5);

@@ -19,17 +19,19 @@ def shard_range(n_total, rank, world):
 
 
 def allreduce_stats(stats16, device):
-    """Combine per-shard art_detector_stats vectors into the global one (same layout)."""
+    """Combine per-shard art_detector_stats vectors into the global one (same layout).  Accepts a host array or
+    a device tensor; returns a tensor on `device` (nothing blocks the host)."""
+    t = stats16 if torch.is_tensor(stats16) else torch.as_tensor(np.asarray(stats16, dtype=np.float64))
+    t = t.to(device)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return np.asarray(stats16, dtype=np.float64)
-    t = torch.as_tensor(np.asarray(stats16, dtype=np.float64), device=device)
+        return t
     s, mn, mx = t[_SUM].clone(), t[_MIN].clone(), t[_MAX].clone()
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
     dist.all_reduce(mn, op=dist.ReduceOp.MIN)
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     out = torch.zeros(16, dtype=torch.float64, device=device)
     out[_SUM], out[_MIN], out[_MAX] = s, mn, mx
-    return out.cpu().numpy()
+    return out
 
 
 def gather_readout(X, Y, opl, alive, dst=0, pack=None):

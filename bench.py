@@ -127,17 +127,12 @@ def main():
             pack["recv"] = [torch.empty((3, n), dtype=torch.float64, device=be.device) for _ in range(world)]
             pack["arecv"] = [torch.empty(n, dtype=torch.uint8, device=be.device) for _ in range(world)]
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-
-    def step(i=None):
-        if i is not None:
-            ev[i][0].record()
+    def step():
+        # nothing in a step blocks the host: launches queue up like the steps of a training loop
         o = mp.RayTracingCalculation(src, els, mode=mode)
-        if i is not None:
-            ev[i][1].record()
-        r = det.readout(o[-1])
+        r = det.readout(o[-1], sync=False)
         if world > 1:
-            sharding.allreduce_stats(r["stats"], be.device)
+            r["stats_dev"] = sharding.allreduce_stats(r["stats_dev"], be.device)
             sharding.gather_readout(r["X"], r["Y"], r["opl"], o[-1].alive, 0, pack)
         return o, r
 
@@ -146,9 +141,10 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    be.trace_events = []          # HIP events bracketing every trace launch, on the launch stream
     t0 = time.perf_counter()
     for i in range(args.steps):
-        o, r = step(i)
+        o, r = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -158,9 +154,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    trace_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # HIP events on the launch stream
+    evs, be.trace_events = be.trace_events, None
+    stats_host = r["stats_dev"].cpu().numpy()
+    assert stats_host[0] > 0 and np.isfinite(stats_host[1])
     launches = 1 if mode == "chain" else args.mirrors
-    kernel_ms = trace_ms / launches
+    assert len(evs) == launches * args.steps
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))   # average duration of one trace launch
+    trace_ms = kernel_ms * launches
     inter_per_launch = inter_per_step_rank / launches
     achieved = ALGO_BYTES_PER_INTERSECTION * inter_per_launch / (kernel_ms * 1e-3) / 1e9
 

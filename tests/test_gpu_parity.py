@@ -118,7 +118,9 @@ def test_gpu_full_size_properties(hip):
     for a, b in zip(out_c, out_e):
         assert torch.equal(a.alive, b.alive)
         m = a.alive.bool()
-        assert torch.equal(a.data[:, m], b.data[:, m])
+        assert float((a.data[0:3, m] - b.data[0:3, m]).abs().max()) <= 1e-13 * 2000
+        assert float((a.data[3:6, m] - b.data[3:6, m]).abs().max()) <= 1e-13
+        assert float((a.data[6:8, m] - b.data[6:8, m]).abs().max()) <= 1e-13 * 2000
     last = out_c[-1]
     m = last.alive.bool()
     assert abs(int(m.sum().item()) / n - 0.673) < 0.01      # SURVEY: mask passes 67.3 %

@@ -73,7 +73,7 @@ class TwinBackend:
     def _np(t):
         return None if t is None else t.numpy()
 
-    def detector_stats(self, alive, X, Y, opl, w, n):
+    def detector_stats(self, alive, X, Y, opl, w, n, to_host=True):
         a = alive.numpy().astype(bool)
         X, Y, opl, w = (self._np(t) for t in (X, Y, opl, w))
         z = np.zeros(int(a.sum()))
@@ -85,7 +85,7 @@ class TwinBackend:
         if len(z):
             out[:14] = [len(z), o.sum(), x.min(), x.max(), y.min(), y.max(), x.sum(), y.sum(), ww.sum(),
                         (ww * x).sum(), (ww * y).sum(), (ww * o).sum(), o.min(), o.max()]
-        return out
+        return out if to_host else torch.from_numpy(out)
 
     def detector_moments(self, alive, X, Y, opl, w, n, cx, cy, co):
         a = alive.numpy().astype(bool)
