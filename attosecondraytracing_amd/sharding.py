@@ -34,23 +34,37 @@ def allreduce_stats(stats16, device):
     return out
 
 
-def gather_readout(X, Y, opl, alive, dst=0, pack=None):
+def gather_readout(X, Y, opl, alive, dst=0, pack=None, sizes=None):
     """Gather the detector read-out of every shard to rank `dst` (rank order = global ray order).
     Returns (XYO [3, n_total] float64, alive [n_total] uint8) on dst, (None, None) elsewhere.
-    `pack` may hold preallocated {'send': [3,n], 'recv': [list of [3,n]], 'arecv': [list of [n]]} buffers."""
+    Shards may differ in length (index ranges of a ray count not divisible by the world size): every rank sends
+    a block padded to the longest shard and the root trims.  `sizes` = list of shard lengths if already known
+    (otherwise one tiny all-gather); `pack` may hold preallocated {'send': [3,nmax], 'asend': [nmax],
+    'recv': [world x [3,nmax]], 'arecv': [world x [nmax]]} buffers."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     if world == 1:
         return torch.stack([X, Y, opl]), alive
     rank = dist.get_rank()
     n = X.numel()
-    send = pack["send"] if pack else torch.empty((3, n), dtype=torch.float64, device=X.device)
-    send[0], send[1], send[2] = X, Y, opl
+    if sizes is None:
+        t = torch.tensor([n], dtype=torch.int64, device=X.device)
+        allsz = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allsz, t)
+        sizes = [int(v.item()) for v in allsz]
+    nmax = max(sizes)
+    send = pack["send"] if pack else torch.zeros((3, nmax), dtype=torch.float64, device=X.device)
+    asend = pack["asend"] if pack else torch.zeros(nmax, dtype=torch.uint8, device=X.device)
+    send[0, :n], send[1, :n], send[2, :n] = X, Y, opl
+    asend[:n] = alive
     if rank == dst:
         recv = pack["recv"] if pack else [torch.empty_like(send) for _ in range(world)]
-        arecv = pack["arecv"] if pack else [torch.empty_like(alive) for _ in range(world)]
+        arecv = pack["arecv"] if pack else [torch.empty_like(asend) for _ in range(world)]
         dist.gather(send, recv, dst=dst)
-        dist.gather(alive, arecv, dst=dst)
-        return torch.cat(recv, dim=1), torch.cat(arecv)
+        dist.gather(asend, arecv, dst=dst)
+        if all(sz == nmax for sz in sizes):
+            return torch.cat(recv, dim=1), torch.cat(arecv)
+        return (torch.cat([r[:, :sz] for r, sz in zip(recv, sizes)], dim=1),
+                torch.cat([a[:sz] for a, sz in zip(arecv, sizes)]))
     dist.gather(send, None, dst=dst)
-    dist.gather(alive, None, dst=dst)
+    dist.gather(asend, None, dst=dst)
     return None, None

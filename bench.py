@@ -77,6 +77,23 @@ def cpu_baseline(chain, Rr, n_sample):
     return inter / dt, inter, dt
 
 
+def profiled_traffic(kernel, n, mirrors, mode):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same workload
+    (profiles/rNN_relay<M>_<mode>.json, written by tools/summarize_profile.py from separate --pmc FETCH_SIZE /
+    WRITE_SIZE passes with the gfx950 x2 read correction).  None when no matching profile is committed."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_relay{mirrors}_{mode}.json"))):
+        try:
+            j = json.load(open(f))
+        except Exception:
+            continue
+        k = kernel.replace("ART_TORUS,", "3, ")
+        if j.get("rays_per_gpu") == n and k in j.get("per_launch", {}):
+            best = (j["per_launch"][k]["total_bytes"], os.path.relpath(f, ROOT))
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,7 +139,8 @@ def main():
     pack = None
     if world > 1:
         import torch.distributed as dist
-        pack = {"send": torch.empty((3, n), dtype=torch.float64, device=be.device)}
+        pack = {"send": torch.empty((3, n), dtype=torch.float64, device=be.device),
+                "asend": torch.empty(n, dtype=torch.uint8, device=be.device)}
         if rank == 0:
             pack["recv"] = [torch.empty((3, n), dtype=torch.float64, device=be.device) for _ in range(world)]
             pack["arecv"] = [torch.empty(n, dtype=torch.uint8, device=be.device) for _ in range(world)]
@@ -133,7 +151,7 @@ def main():
         r = det.readout(o[-1], sync=False)
         if world > 1:
             r["stats_dev"] = sharding.allreduce_stats(r["stats_dev"], be.device)
-            sharding.gather_readout(r["X"], r["Y"], r["opl"], o[-1].alive, 0, pack)
+            sharding.gather_readout(r["X"], r["Y"], r["opl"], o[-1].alive, 0, pack, sizes=[n] * world)
         return o, r
 
     for _ in range(args.warmup):
@@ -165,6 +183,8 @@ def main():
     achieved = ALGO_BYTES_PER_INTERSECTION * inter_per_launch / (kernel_ms * 1e-3) / 1e9
 
     if rank == 0:
+        kname = "k_trace_chain<false>" if mode == "chain" else "k_trace_element<ART_TORUS,false>"
+        tr = profiled_traffic(kname, n, args.mirrors, mode)
         value = inter_per_step_rank * world * args.steps / dt
         res = {
             "metric": "ray-surface intersections/s", "value": value, "unit": "intersections/s",
@@ -176,8 +196,9 @@ def main():
                        "rays_per_gpu": n, "mirrors": args.mirrors, "trace_mode": mode,
                        "step": "RayTracingCalculation + Detector.readout" + (" + RCCL gather to rank 0" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_trace_chain<false>" if mode == "chain" else "k_trace_element<ART_TORUS,false>",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None if tr is None else tr[0],
+                         "traffic_source": None if tr is None else tr[1] + " (rocprofv3 PMC, bytes per launch)",
+                         "kernel": kname,
                          "kernel_ms": kernel_ms, "intersections_per_launch": inter_per_launch,
                          "algorithmic_bytes_per_intersection": ALGO_BYTES_PER_INTERSECTION},
             "trace_only_intersections_per_s": inter_per_step_rank / (trace_ms * 1e-3),

@@ -1,0 +1,110 @@
+"""CPU, world_size 2 over gloo: the N > 1 path of bench.py / sharding.py -- index-range shards generated per rank,
+traced independently (CPU twin of the kernels here), statistics all-reduced, read-out gathered to rank 0 --
+reproduces the single-process result exactly (rays are independent; rank order = global ray order)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as tmp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _scene(n_total):
+    import ART.ModuleMirror as mmirror
+    import ART.ModuleMask as mmask
+    import ART.ModuleSupport as msupp
+    import ART.ModuleProcessing as mp
+    SP = {"Divergence": 0.025, "SourceSize": 0, "Wavelength": 50e-6, "DeltaFT": 0.5, "NumberRays": 64}
+    Mask = mmask.Mask(msupp.SupportRoundHole(30, 10.25, 0, 0))
+    R, r = mmirror.ReturnOptimalToroidalRadii(600, 80)
+    Tor = mmirror.MirrorToroidal(R, r, msupp.SupportRectangle(200, 30))
+    return mp.OEPlacement(SP, [Mask, Tor, Tor], [500, 100, 600], [0, 80, -80], [0, 0, 40.0], "gloo")
+
+
+def _run_shard(rank, world, n_total):
+    """Trace shard `rank` of a n_total-ray point source; returns (readout dict, last bundle, detector)."""
+    from attosecondraytracing_amd import sharding, ModuleGeometry as mgeo
+    from attosecondraytracing_amd.bundle import RayBundle
+    from attosecondraytracing_amd import _lib
+    import ART.ModuleProcessing as mp
+    import ART.ModuleDetector as mdet
+    be = _lib.get_backend()
+    chain = _scene(n_total)
+    lo, hi = sharding.shard_range(n_total, rank, world)
+    src = RayBundle.allocate(hi - lo, backend=be)
+    rot = mgeo.rotation_matrix(np.array([0.0, 0.0, 1.0]), np.array([1.0, 0.0, 0.0]))
+    be.make_source(0, 0.025, rot, np.zeros(3), lo, hi - lo, n_total, src.view())
+    src.intensity = torch.ones(hi - lo, dtype=torch.float64)
+    out = mp.RayTracingCalculation(src, chain.optical_elements)
+    det = mdet.Detector(np.zeros(3), np.array([1900.0, 30.0, 0.0]), np.array([-0.9, -0.1, 0.2]))
+    return det.readout(out[-1], sync=False), out[-1], det
+
+
+def _worker(rank, world, port, n_total, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from twin_backend import TwinBackend
+    from attosecondraytracing_amd import _lib, sharding
+    _lib._BACKEND = TwinBackend()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        r, last, det = _run_shard(rank, world, n_total)
+        stats = sharding.allreduce_stats(r["stats_dev"], torch.device("cpu"))
+        XYO, alive = sharding.gather_readout(r["X"], r["Y"], r["opl"], last.alive, 0)
+        if rank == 0:
+            q.put((stats.numpy(), XYO.numpy(), alive.numpy()))
+        else:
+            assert XYO is None and alive is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [4001])
+def test_two_rank_shards_match_single_process(n_total):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from twin_backend import TwinBackend
+    from attosecondraytracing_amd import _lib
+    old = _lib._BACKEND
+    _lib._BACKEND = TwinBackend()
+    try:
+        r, last, det = _run_shard(0, 1, n_total)
+        ref_stats = r["stats_dev"].numpy()
+        ref = np.stack([r["X"].numpy(), r["Y"].numpy(), r["opl"].numpy()])
+        ref_alive = last.alive.numpy()
+    finally:
+        _lib._BACKEND = old
+    ctx = tmp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(rk, 2, port, n_total, q)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    stats, XYO, alive = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(alive, ref_alive)
+    m = ref_alive.astype(bool)
+    assert 0 < m.sum() < n_total
+    assert np.array_equal(XYO[:, m], ref[:, m])            # bit-exact: same per-ray code, same inputs
+    assert stats[0] == ref_stats[0]
+    for k in (2, 3, 4, 5, 12, 13):
+        assert stats[k] == ref_stats[k]                    # min / max are exact
+    for k in (1, 6, 7, 8, 11):
+        assert abs(stats[k] - ref_stats[k]) <= 1e-12 * abs(ref_stats[k])   # sums: order of addition differs
+
+
+def test_shard_ranges_partition():
+    from attosecondraytracing_amd.sharding import shard_range
+    for n in (0, 1, 7, 8, 1000, 10 ** 8 + 3):
+        for w in (1, 2, 3, 8):
+            edges = [shard_range(n, r, w) for r in range(w)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(w - 1))
+            assert max(b - a for a, b in edges) - min(b - a for a, b in edges) <= 1

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiling recipe used for profiles/ (run on the GPU box through gpurun):
-#   tools_prof.sh <tag> [bench args...]
+#   tools/prof.sh <tag> [bench args...]
 # Pass 1: kernel trace + stats.  Pass 2/3: HBM counters, each in its own --pmc run (FETCH_SIZE and WRITE_SIZE do
 # not fit one pass on gfx950; see MI355X_MICROARCH.md "rocprofv3 PMC slots").
 set -e

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 CSVs written by tools/prof.sh into a small summary under profiles/.
+
+usage: tools/summarize_profile.py gpurun_out/prof_<tag> profiles/<name>.md [rays_per_gpu]
+
+HBM traffic follows MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE come from separate
+--pmc passes, are in KiB, and on gfx950 FETCH_SIZE counts 64 B per 128-B request for coalesced streaming reads,
+i.e. exactly half the bytes.  Both are calibrated here on kernels of the same run whose byte counts are known
+exactly (same 8-B-per-lane access pattern): k_bundle_sums_partial reads 49 B/ray and k_make_source writes 65 B/ray.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return name.split("(")[0]
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    n = int(sys.argv[3]) if len(sys.argv) > 3 else 10_000_000
+    out = ["# rocprofv3 summary: " + os.path.basename(src), ""]
+    bj = os.path.join(src, "bench_trace.json")
+    if os.path.exists(bj):
+        try:
+            b = json.loads(open(bj).read().strip().splitlines()[-1])
+            out += ["bench line of the kernel-trace pass (profiled run, not the headline number):", "```",
+                    json.dumps({k: b[k] for k in ("value", "ms_per_step", "config", "roofline")}), "```", ""]
+        except Exception:
+            pass
+    # ---- kernel trace: only the full-size launches (largest grid per kernel)
+    kt = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))[0]
+    rows = list(csv.DictReader(open(kt)))
+    byk = collections.defaultdict(list)
+    for r in rows:
+        byk[short(r["Kernel_Name"])].append((int(r["Grid_Size_X"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]),
+                                            r.get("VGPR_Count", ""), r.get("SGPR_Count", ""), r.get("LDS_Block_Size", "")))
+    out += ["## kernel trace (`rocprofv3 --kernel-trace --stats`), full-size launches only", "",
+            "| kernel | launches | avg us | min us | max us | grid threads | VGPR | SGPR | LDS B |", "|---|---:|---:|---:|---:|---:|---:|---:|---:|"]
+    tot = 0
+    stat = {}
+    for k, v in sorted(byk.items(), key=lambda kv: -sum(x[1] for x in kv[1])):
+        g = max(x[0] for x in v)
+        big = [x for x in v if x[0] == g]
+        d = [x[1] for x in big]
+        stat[k] = (len(d), sum(d) / len(d))
+        if sum(d) < 20000:
+            continue
+        out.append(f"| {k} | {len(d)} | {sum(d)/len(d)/1e3:.1f} | {min(d)/1e3:.1f} | {max(d)/1e3:.1f} | {g} | {big[0][2]} | {big[0][3]} | {big[0][4]} |")
+    out.append("")
+    # ---- PMC passes
+    def pmc(tag, counter):
+        f = glob.glob(os.path.join(src, "pmc_" + tag, "*", "*_counter_collection.csv"))
+        if not f:
+            return {}
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(f[0])):
+            if r["Counter_Name"] == counter:
+                acc[short(r["Kernel_Name"])].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
+        res = {}
+        for k, v in acc.items():
+            g = max(x[0] for x in v)
+            big = [x[1] for x in v if x[0] == g]
+            res[k] = sum(big) / len(big) * 1024.0   # KiB -> bytes
+        return res
+    fe, wr = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
+    out += ["## HBM traffic per launch (`--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separate passes)", ""]
+    cal_r = fe.get("k_bundle_sums_partial", 0) / (49.0 * n) if fe.get("k_bundle_sums_partial") else None
+    cal_w = wr.get("k_make_source", 0) / (65.0 * n) if wr.get("k_make_source") else None
+    out.append(f"calibration on known byte counts ({n} rays): FETCH_SIZE/true read bytes = "
+               f"{cal_r if cal_r is None else round(cal_r, 4)} (k_bundle_sums_partial, 49 B/ray; guide says 0.5 on gfx950), "
+               f"WRITE_SIZE/true written bytes = {cal_w if cal_w is None else round(cal_w, 4)} (k_make_source, 65 B/ray).")
+    out += ["", "| kernel | FETCH_SIZE raw MB | read MB (x2 gfx950 correction) | WRITE_SIZE MB | total MB | avg us (trace pass) | HBM GB/s |",
+            "|---|---:|---:|---:|---:|---:|---:|"]
+    for k in fe:
+        if k not in stat or fe[k] + wr.get(k, 0) < 5e6:
+            continue
+        rd = 2.0 * fe[k]
+        w = wr.get(k, 0.0)
+        us = stat[k][1] / 1e3
+        out.append(f"| {k} | {fe[k]/1e6:.1f} | {rd/1e6:.1f} | {w/1e6:.1f} | {(rd+w)/1e6:.1f} | {us:.1f} | {(rd+w)/us/1e3:.0f} |")
+    out.append("")
+    traffic = {k: {"read_bytes": 2.0 * fe[k], "write_bytes": wr.get(k, 0.0), "total_bytes": 2.0 * fe[k] + wr.get(k, 0.0),
+                   "avg_us_trace_pass": stat[k][1] / 1e3} for k in fe if k in stat and fe[k] + wr.get(k, 0) >= 5e6}
+    json.dump({"source": os.path.basename(src), "rays_per_gpu": n, "fetch_calibration": cal_r, "write_calibration": cal_w,
+               "per_launch": traffic}, open(os.path.splitext(dst)[0] + ".json", "w"), indent=1)
+    open(dst, "w").write("\n".join(out) + "\n")
+    print("\n".join(out))
+
+
+if __name__ == "__main__":
+    main()
