@@ -87,10 +87,17 @@ class Detector:
 
     # ------------------------------------------------------------------ device read-out
     def _desc(self):
+        """ArtDetectorDesc; the rotation normal -> ez (ModuleDetector.py:231) is cached until the normal changes."""
+        key = self._normal.tobytes()
+        cached = getattr(self, "_rot_cache", None)
+        if cached is None or cached[0] != key:
+            rot = mgeo.rotation_matrix(self.normal, np.array([0.0, 0.0, 1.0])).reshape(9)
+            cached = (key, [float(v) for v in rot])
+            self._rot_cache = cached
         d = _abi.ArtDetectorDesc()
         d.centre[:] = [float(v) for v in self.centre]
         d.normal[:] = [float(v) for v in self.normal]
-        d.rot[:] = [float(v) for v in mgeo.rotation_matrix(self.normal, np.array([0.0, 0.0, 1.0])).reshape(9)]
+        d.rot[:] = cached[1]
         return d
 
     def readout(self, RayList, points3d=False, sync=True):

@@ -103,17 +103,16 @@ def RayTracingCalculation(source_rays, optical_elements, IgnoreDefects=True, mod
         descs.append(d)
         keep.append(k)
     mode = mode or DEFAULT_TRACE_MODE
-    outs = []
+    if history:
+        outs = RayBundle.allocate_many(n, m, src, be)
+    else:
+        outs = [None] * (m - 1) + [RayBundle.allocate(n, like=src, backend=be)]
     prev = src
-    for k in range(m):
-        if history or k == m - 1:
-            b = RayBundle.allocate(n, like=src, backend=be)
+    for b in outs:
+        if b is not None:
             b.parent = prev
             b._keepalive = keep
             prev = b
-            outs.append(b)
-        else:
-            outs.append(None)
     if mode == "chain":
         views = [b.view() if b is not None else _abi.ArtBundleView() for b in outs]
         be.trace_chain(descs, src.view(), views, n)

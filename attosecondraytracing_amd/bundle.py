@@ -42,6 +42,15 @@ class RayBundle:
         return cls(data, alive, backend=be)
 
     @classmethod
+    def allocate_many(cls, n, count, like, backend=None):
+        """`count` bundles carved out of two allocations ([count, 8, n] fp64 + [count, n] uint8): the per-element
+        history of one chain."""
+        be = backend or like.backend
+        data = torch.empty((count, 8, int(n)), dtype=torch.float64, device=be.device)
+        alive = torch.empty((count, int(n)), dtype=torch.uint8, device=be.device)
+        return [cls(data[k], alive[k], like.number, like.intensity, like.wavelength, like, be) for k in range(count)]
+
+    @classmethod
     def from_arrays(cls, point, vector, number=None, intensity=None, wavelength=None, path0=None, backend=None):
         be = backend or _lib.get_backend()
         point = np.ascontiguousarray(point, dtype=np.float64).reshape(-1, 3)

@@ -395,11 +395,21 @@ ART_HD int torus_body_roots(double R, double r2, double rb, double Ax, double Ay
   const double pad = 1e-6 * (rb + fabs(hb));
   const double ts1 = -hb - sq - pad, ts2 = -hb + sq + pad;
   any = any && (ts2 > 1e-12);
-  double F0, dF0;
-  torus_F<SIDE>(R, r2, Ax, Ay, Az, ux, uy, uz, F0, dF0);
-  const bool origin_inside = F0 < 0.0;
-  // origin outside the body and moving away from it: both roots (if any) are behind the origin
-  any = any && (origin_inside || dF0 < 0.0);
+  // Is the ray origin inside the body?  Usual case for a mirror (the previous optic sits inside the tube): decided
+  // without a square root by the inscribed box |y| < 0.7 r, rho < R + 0.7 r (0.7^2 + 0.7^2 < 1); only origins
+  // outside that box evaluate F(0) exactly.
+  bool origin_inside = false;
+  if (SIDE < 0) {
+    const double r07 = 0.7 * (rb - R), lim = R + r07;
+    origin_inside = (fma(Ax, Ax, Az * Az) < lim * lim) && (Ay * Ay < r07 * r07);
+  }
+  if (!origin_inside) {
+    double F0, dF0;
+    torus_F<SIDE>(R, r2, Ax, Ay, Az, ux, uy, uz, F0, dF0);
+    origin_inside = F0 < 0.0;
+    // origin outside the body and moving away from it: both roots (if any) are behind the origin
+    any = any && (origin_inside || dF0 < 0.0);
+  }
   // exit root: start just outside the sphere exit, walk left
   double t_out = ts2;
   const bool has_out = torus_newton<SIDE>(R, r2, Ax, Ay, Az, ux, uy, uz, +1.0, any, t_out);

@@ -35,6 +35,62 @@ inline int grid_for(int64_t n) {
   return (int)b;
 }
 
+// ---- buffer-resource access -----------------------------------------------------------------------------
+// Every stream is addressed through a 128-bit buffer descriptor (base, byte count) with the per-lane byte offset
+// in a 32-bit VGPR.  The hardware range check gives branch-free predication: a lane whose offset is out of range
+// loads 0 / stores nothing.  That is what lets dead rays skip their 8 output stores WITHOUT a branch around the
+// stores -- a branch would make the compiler drain every outstanding store (s_waitcnt vmcnt(0)) at the join and
+// undo the software pipelining below.  One launch covers at most kMaxRaysPerLaunch rays (32-bit byte offsets).
+typedef int v2i32 __attribute__((ext_vector_type(2)));
+constexpr int64_t kMaxRaysPerLaunch = (int64_t)1 << 28;  // 2^28 rays * 8 B = 2 GiB per stream
+constexpr unsigned kDropOffset = 0xFFFFFFFFu;
+
+struct BundleRsrc {
+  __amdgpu_buffer_rsrc_t ox, oy, oz, dx, dy, dz, path, inc, alive;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ BundleRsrc make_rsrc(const ArtBundleView& v, int64_t n) {
+  const unsigned b8 = (unsigned)(n * 8), b1 = (unsigned)n;
+  BundleRsrc r;
+  r.ox = rsrc_of(v.ox, b8); r.oy = rsrc_of(v.oy, b8); r.oz = rsrc_of(v.oz, b8);
+  r.dx = rsrc_of(v.dx, b8); r.dy = rsrc_of(v.dy, b8); r.dz = rsrc_of(v.dz, b8);
+  r.path = rsrc_of(v.path, b8); r.inc = rsrc_of(v.incidence, b8);
+  r.alive = rsrc_of(v.alive, b1);
+  return r;
+}
+__device__ __forceinline__ double ld_f64(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  const v2i32 d = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0);
+  double v;
+  __builtin_memcpy(&v, &d, 8);
+  return v;
+}
+__device__ __forceinline__ void st_f64(__amdgpu_buffer_rsrc_t rs, unsigned off, double v) {
+  v2i32 d;
+  __builtin_memcpy(&d, &v, 8);
+  __builtin_amdgcn_raw_buffer_store_b64(d, rs, (int)off, 0, 0);
+}
+// slot index -> byte offsets; out-of-range slots (i >= n) fall outside every descriptor automatically
+__device__ __forceinline__ void load_slot(const BundleRsrc& b, int64_t i, art::Ray& r, uint8_t& alive) {
+  const unsigned o1 = (unsigned)i, o8 = o1 * 8u;
+  alive = __builtin_amdgcn_raw_buffer_load_b8(b.alive, (int)o1, 0, 0);
+  r.ox = ld_f64(b.ox, o8); r.oy = ld_f64(b.oy, o8); r.oz = ld_f64(b.oz, o8);
+  r.dx = ld_f64(b.dx, o8); r.dy = ld_f64(b.dy, o8); r.dz = ld_f64(b.dz, o8);
+  r.path = ld_f64(b.path, o8);
+}
+__device__ __forceinline__ void store_slot(const BundleRsrc& b, int64_t i, const art::Ray& r, bool ok) {
+  const unsigned o1 = (unsigned)i;
+  const unsigned o8 = ok ? o1 * 8u : kDropOffset;  // dead rays: the range check drops the 8 stores
+  st_f64(b.ox, o8, r.ox); st_f64(b.oy, o8, r.oy); st_f64(b.oz, o8, r.oz);
+  st_f64(b.dx, o8, r.dx); st_f64(b.dy, o8, r.dy); st_f64(b.dz, o8, r.dz);
+  st_f64(b.path, o8, r.path);
+  st_f64(b.inc, o8, r.inc);
+  __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(ok ? 1 : 0), b.alive, (int)o1, 0, 0);
+}
+
+// plain-pointer access for the small kernels (detector, sources)
 __device__ __forceinline__ void load_ray(const ArtBundleView& v, int64_t i, art::Ray& r) {
   r.ox = v.ox[i]; r.oy = v.oy[i]; r.oz = v.oz[i];
   r.dx = v.dx[i]; r.dy = v.dy[i]; r.dz = v.dz[i];
@@ -59,16 +115,29 @@ __global__ __launch_bounds__(kBlock) void k_trace_element(const ArtElementDesc e
     __syncthreads();
     zern = s_zern;
   }
+  // Software-pipelined grid-stride loop: the 7 input streams + alive of the NEXT slot are requested (one round
+  // trip, speculatively for dead slots too) before the current ray is traced, so HBM latency hides under the
+  // ~450 fp64 instructions of an intersection; loads and stores are branch-free (see above), so the only waits
+  // the compiler inserts are counted ones on the prefetched registers.
+  const BundleRsrc bi = make_rsrc(in, n), bo = make_rsrc(out, n);
   const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    bool ok = in.alive[i] != 0;
-    art::Ray r;
-    if (ok) {
-      load_ray(in, i, r);
-      ok = art::trace_ray<KIND, DEFECT>(e, zern, r);
-    }
-    if (ok) store_ray(out, i, r);
-    out.alive[i] = ok ? 1 : 0;
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  art::Ray r;
+  r.inc = 0.0;
+  uint8_t a;
+  load_slot(bi, i, r, a);
+  while (i < n) {
+    const int64_t inext = i + stride;
+    art::Ray rn;
+    rn.inc = 0.0;
+    uint8_t an;
+    load_slot(bi, inext, rn, an);
+    bool ok = a != 0;
+    if (ok) ok = art::trace_ray<KIND, DEFECT>(e, zern, r);
+    store_slot(bo, i, r, ok);
+    r = rn;
+    a = an;
+    i = inext;
   }
 }
 
@@ -91,18 +160,28 @@ __global__ __launch_bounds__(kBlock) void k_trace_chain(const ChainArgs a, const
     }
     __syncthreads();
   }
+  const BundleRsrc bi = make_rsrc(in, n);
   const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    bool ok = in.alive[i] != 0;
-    art::Ray r;
-    if (ok) load_ray(in, i, r);
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  art::Ray r;
+  r.inc = 0.0;
+  uint8_t al;
+  load_slot(bi, i, r, al);
+  while (i < n) {  // software-pipelined like k_trace_element: next slot's inputs in flight while this ray is traced
+    const int64_t inext = i + stride;
+    art::Ray rn;
+    rn.inc = 0.0;
+    uint8_t an;
+    load_slot(bi, inext, rn, an);
+    bool ok = al != 0;
     for (int k = 0; k < a.n_elems; ++k) {
       if (ok) ok = art::trace_ray_dyn<DEFECT>(a.e[k], s_zern + a.zoff[k], r);
-      if (a.out[k].alive != nullptr) {
-        if (ok) store_ray(a.out[k], i, r);
-        a.out[k].alive[i] = ok ? 1 : 0;
-      }
+      // no history view for this element -> zero-length descriptors: every store is dropped by the range check
+      store_slot(make_rsrc(a.out[k], a.out[k].alive != nullptr ? n : 0), i, r, ok);
     }
+    r = rn;
+    al = an;
+    i = inext;
   }
 }
 

@@ -34,13 +34,16 @@ def allreduce_stats(stats16, device):
     return out
 
 
-def gather_readout(X, Y, opl, alive, dst=0, pack=None, sizes=None):
+def gather_readout(X, Y, opl, alive, dst=0, pack=None, sizes=None, async_op=False):
     """Gather the detector read-out of every shard to rank `dst` (rank order = global ray order).
     Returns (XYO [3, n_total] float64, alive [n_total] uint8) on dst, (None, None) elsewhere.
     Shards may differ in length (index ranges of a ray count not divisible by the world size): every rank sends
     a block padded to the longest shard and the root trims.  `sizes` = list of shard lengths if already known
     (otherwise one tiny all-gather); `pack` may hold preallocated {'send': [3,nmax], 'asend': [nmax],
-    'recv': [world x [3,nmax]], 'arecv': [world x [nmax]]} buffers."""
+    'recv': [world x [3,nmax]], 'arecv': [world x [nmax]]} buffers.
+    With async_op=True (needs `pack` and `sizes`) the two collectives are only enqueued and a list of work handles
+    is returned: the caller overlaps them with further kernels and calls `.wait()` on each handle before it
+    touches the pack's buffers again (the result then sits in pack['recv'] / pack['arecv'] on dst)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     if world == 1:
         return torch.stack([X, Y, opl]), alive
@@ -56,6 +59,10 @@ def gather_readout(X, Y, opl, alive, dst=0, pack=None, sizes=None):
     asend = pack["asend"] if pack else torch.zeros(nmax, dtype=torch.uint8, device=X.device)
     send[0, :n], send[1, :n], send[2, :n] = X, Y, opl
     asend[:n] = alive
+    if async_op:
+        recv = pack["recv"] if rank == dst else None
+        arecv = pack["arecv"] if rank == dst else None
+        return [dist.gather(send, recv, dst=dst, async_op=True), dist.gather(asend, arecv, dst=dst, async_op=True)]
     if rank == dst:
         recv = pack["recv"] if pack else [torch.empty_like(send) for _ in range(world)]
         arecv = pack["arecv"] if pack else [torch.empty_like(asend) for _ in range(world)]

@@ -136,14 +136,19 @@ def main():
     inter_per_step_rank = int(sum(entering))
     del out
 
-    pack = None
+    packs, works = [], [None, None]
     if world > 1:
         import torch.distributed as dist
-        pack = {"send": torch.empty((3, n), dtype=torch.float64, device=be.device),
-                "asend": torch.empty(n, dtype=torch.uint8, device=be.device)}
-        if rank == 0:
-            pack["recv"] = [torch.empty((3, n), dtype=torch.float64, device=be.device) for _ in range(world)]
-            pack["arecv"] = [torch.empty(n, dtype=torch.uint8, device=be.device) for _ in range(world)]
+        # double-buffered gather buffers: the gather of step i (RCCL, its own stream) overlaps the tracing of
+        # step i+1; a buffer is reused only after the gather that read it has been waited for
+        for _ in range(2):
+            pk = {"send": torch.empty((3, n), dtype=torch.float64, device=be.device),
+                  "asend": torch.empty(n, dtype=torch.uint8, device=be.device)}
+            if rank == 0:
+                pk["recv"] = [torch.empty((3, n), dtype=torch.float64, device=be.device) for _ in range(world)]
+                pk["arecv"] = [torch.empty(n, dtype=torch.uint8, device=be.device) for _ in range(world)]
+            packs.append(pk)
+    step_no = [0]
 
     def step():
         # nothing in a step blocks the host: launches queue up like the steps of a training loop
@@ -151,11 +156,25 @@ def main():
         r = det.readout(o[-1], sync=False)
         if world > 1:
             r["stats_dev"] = sharding.allreduce_stats(r["stats_dev"], be.device)
-            sharding.gather_readout(r["X"], r["Y"], r["opl"], o[-1].alive, 0, pack, sizes=[n] * world)
+            b = step_no[0] % 2
+            step_no[0] += 1
+            if works[b] is not None:
+                for w in works[b]:
+                    w.wait()
+            works[b] = sharding.gather_readout(r["X"], r["Y"], r["opl"], o[-1].alive, 0, packs[b],
+                                               sizes=[n] * world, async_op=True)
         return o, r
+
+    def drain():
+        for b in range(2):
+            if works[b] is not None:
+                for w in works[b]:
+                    w.wait()
+                works[b] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -163,6 +182,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         o, r = step()
+    t_enq = time.perf_counter() - t0   # host time to enqueue all steps (diagnostic: host-bound if ~ dt)
+    drain()                       # every gather has landed on rank 0 before the clock stops
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -202,6 +223,7 @@ def main():
                          "kernel_ms": kernel_ms, "intersections_per_launch": inter_per_launch,
                          "algorithmic_bytes_per_intersection": ALGO_BYTES_PER_INTERSECTION},
             "trace_only_intersections_per_s": inter_per_step_rank / (trace_ms * 1e-3),
+            "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
         }
         if world == 1 and args.cpu_sample > 0:
             v, inter, secs = cpu_baseline(chain, Rr, args.cpu_sample)

@@ -56,6 +56,18 @@ def _worker(rank, world, port, n_total, q):
         r, last, det = _run_shard(rank, world, n_total)
         stats = sharding.allreduce_stats(r["stats_dev"], torch.device("cpu"))
         XYO, alive = sharding.gather_readout(r["X"], r["Y"], r["opl"], last.alive, 0)
+        # the overlapped form bench.py uses: preallocated pack, known sizes, handles waited for later
+        sizes = [b - a for a, b in (sharding.shard_range(n_total, k, world) for k in range(world))]
+        nmax = max(sizes)
+        pack = {"send": torch.zeros((3, nmax), dtype=torch.float64), "asend": torch.zeros(nmax, dtype=torch.uint8)}
+        if rank == 0:
+            pack["recv"] = [torch.empty((3, nmax), dtype=torch.float64) for _ in range(world)]
+            pack["arecv"] = [torch.empty(nmax, dtype=torch.uint8) for _ in range(world)]
+        for w in sharding.gather_readout(r["X"], r["Y"], r["opl"], last.alive, 0, pack, sizes, async_op=True):
+            w.wait()
+        if rank == 0:
+            again = torch.cat([t[:, :sz] for t, sz in zip(pack["recv"], sizes)], dim=1)
+            assert torch.equal(again, XYO)
         if rank == 0:
             q.put((stats.numpy(), XYO.numpy(), alive.numpy()))
         else:
