@@ -50,6 +50,26 @@ import ART.ModuleGeometry as mgeo  # noqa: E402
 import ART.ModuleAnalysisAndPlots as mplots  # noqa: E402
 
 
+# record the arguments of every reference placement on the chain it returns, so that the fixtures also pin
+# OEPlacement (ART/ModuleProcessing.py:32-246): tests re-run the product's OEPlacement with the same arguments
+_orig_single = mp._singleOEPlacement
+
+
+def _recording_single(SourceProperties, OpticsList, DistanceList, IncidenceAngleList, IncidencePlaneAngleList,
+                      Description):
+    args = {"SourceProperties": {k: (None if v is None else float(v)) for k, v in SourceProperties.items()},
+            "DistanceList": [float(v) for v in DistanceList],
+            "IncidenceAngleList": [float(v) for v in IncidenceAngleList],
+            "IncidencePlaneAngleList": [float(v) for v in IncidencePlaneAngleList]}
+    chain = _orig_single(SourceProperties, OpticsList, DistanceList, IncidenceAngleList, IncidencePlaneAngleList,
+                         Description)
+    chain._placement = args
+    return chain
+
+
+mp._singleOEPlacement = _recording_single
+
+
 # ----------------------------------------------------------------------------- describing objects
 def describe_support(S):
     n = type(S).__name__
@@ -157,6 +177,8 @@ def dump_chain(name, chain, detector_distance=None, ignore_defects=None, extra=N
         scene["ETransmission"] = float(mplots.getETransmission(chain.source_rays, last))
     if extra:
         scene.update(extra)
+    if getattr(chain, "_placement", None) is not None and not getattr(chain, "_modified_after_placement", False):
+        scene["placement"] = chain._placement
     arrays["scene_json"] = np.array(json.dumps(scene))
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **arrays)
@@ -173,8 +195,10 @@ def scene_c1(n_rays, name):
     Parabola = mmirror.MirrorParabolic(100, 90, Support)
     chain = mp.OEPlacement(SourceProperties, [Parabola], [200], [0.00],
                            Description="A 90deg off-axis parabola with a hole, illuminated by a plane wave.")
+    chain._modified_after_placement = True   # rolled: poses no longer those of OEPlacement; keep the source only
+    placement = chain._placement
     chain.optical_elements[0].rotate_roll_by(np.rad2deg(50e-6))
-    return dump_chain(name, chain, detector_distance=100)
+    return dump_chain(name, chain, detector_distance=100, extra={"placement_before_roll": placement})
 
 
 def scene_c2(n_rays=1000):
@@ -218,6 +242,7 @@ def scene_c5(n_rays=1000):
     chain = mp.OEPlacement(SourceProperties, [Deformed], [15], [0], Description="deformed parabola (Zernike)")
     dump_chain("c5_zernike_ignoredefects", chain, detector_distance=25.4, ignore_defects=True)
     chain2 = chain.copy_chain()
+    chain2._placement = chain._placement
     dump_chain("c5_zernike_withdefects", chain2, detector_distance=25.4, ignore_defects=False)
     # two stacked defects (normal_add applied twice, ART/ModuleMirror.py:952-961)
     Defect2 = mdef.Zernike(Support, {(1, 1): 2e-5, (4, 0): -1e-5, (7, 3): 3e-6})
@@ -245,8 +270,10 @@ def scene_single(name, optic, distance, incidence_deg, n=600, half_angle=0.05, j
     chain = mp.OEPlacement(SourceProperties, [optic], [distance], [incidence_deg], [plane_angle], name)
     if jitter > 0:
         chain.source_rays = _jittered_point_source(n, half_angle, seed, jitter)
+        chain._placement["jittered_source"] = True
     if yaw_deg:
         chain.optical_elements[0].rotate_yaw_by(yaw_deg)
+        chain._modified_after_placement = True
     if extra_shift is not None:
         chain.optical_elements[0].position = chain.optical_elements[0].position + np.asarray(extra_shift, float)
     return dump_chain(name, chain, detector_distance=detector_distance)
