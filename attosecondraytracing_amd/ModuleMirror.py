@@ -239,7 +239,7 @@ class DeformedMirror(_Mirror):
         if len(self.DeformationList) > _abi.ART_MAX_DEFECTS:
             raise NotImplementedError(f"at most {_abi.ART_MAX_DEFECTS} defects per mirror are supported")
         for d in self.DeformationList:
-            if not hasattr(d, "_abi_table"):
+            if not (hasattr(d, "_abi_table") or hasattr(d, "_abi_grid")):
                 raise NotImplementedError(f"defect type {type(d).__name__} has no device implementation yet")
 
     @property
@@ -249,8 +249,14 @@ class DeformedMirror(_Mirror):
     def _abi_params(self):
         return self.Mirror._abi_params()
 
+    def _zernike_defects(self):
+        return [d for d in self.DeformationList if hasattr(d, "_abi_table")]
+
+    def _grid_defects(self):
+        return [d for d in self.DeformationList if hasattr(d, "_abi_grid")]
+
     def _abi_defect_table(self):
-        return np.concatenate([d._abi_table() for d in self.DeformationList])
+        return np.concatenate([d._abi_table() for d in self._zernike_defects()])
 
     def get_centre(self):
         return self.Mirror.get_centre()

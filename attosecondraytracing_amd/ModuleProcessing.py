@@ -65,13 +65,35 @@ def _build_descriptor(oe, IgnoreDefects, backend):
     d.mp[:] = mp_ + [0.0] * (4 - len(mp_))
     keep = None
     d.n_defects = 0
+    d.n_grid = 0
     d.flags = 0
     d.zern = None
+    d.grid = None
     if hasattr(optic, "DeformationList") and len(optic.DeformationList) > 0:
+        import ctypes as C
         be = backend or _lib.get_backend()
-        keep = be.from_numpy(optic._abi_defect_table())
-        d.zern = keep.data_ptr()
-        d.n_defects = len(optic.DeformationList)
+        keep = []
+        zern, grids = optic._zernike_defects(), optic._grid_defects()
+        if grids and not IgnoreDefects:
+            # same outcome as the reference: DeformedMirror.get_normal -> Fourrier.get_normal raises
+            grids[0].get_normal(None)
+        if zern:
+            t = be.from_numpy(optic._abi_defect_table())
+            keep.append(t)
+            d.zern = t.data_ptr()
+            d.n_defects = len(zern)
+        if grids:
+            arr = (_abi.ArtGridDefect * len(grids))()
+            for g, D in zip(arr, grids):
+                fields, dev = D._abi_grid(be)
+                keep.append(dev)
+                for k_, v_ in fields.items():
+                    setattr(g, k_, v_)
+            raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+            t = be.from_numpy(raw)
+            keep.append(t)
+            d.grid = t.data_ptr()
+            d.n_grid = len(grids)
         if not IgnoreDefects:
             d.flags = _abi.ART_FLAG_PERTURBED_NORMAL
     return d, keep

@@ -1,7 +1,7 @@
 """ctypes mirror of include/art_hip.h (structs, enums, prototypes).  Keep in sync with ART_ABI_VERSION."""
 import ctypes as C
 
-ART_ABI_VERSION = 1
+ART_ABI_VERSION = 2
 
 ART_OK = 0
 ART_ERR_BAD_ARG = -1
@@ -25,6 +25,11 @@ c_double_p = C.POINTER(C.c_double)
 c_uint8_p = C.POINTER(C.c_uint8)
 
 
+class ArtGridDefect(C.Structure):
+    _fields_ = [("h", C.c_void_p), ("nx", C.c_int32), ("ny", C.c_int32),
+                ("x0", C.c_double), ("y0", C.c_double), ("dx", C.c_double), ("dy", C.c_double)]
+
+
 class ArtElementDesc(C.Structure):
     _fields_ = [
         ("kind", C.c_int32),
@@ -38,6 +43,9 @@ class ArtElementDesc(C.Structure):
         ("sp", C.c_double * 6),
         ("mp", C.c_double * 4),
         ("zern", C.c_void_p),
+        ("grid", C.c_void_p),
+        ("n_grid", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

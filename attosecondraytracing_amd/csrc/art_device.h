@@ -288,6 +288,19 @@ ART_HD void zernike_defect(const double* tab, double px, double py, double& h, d
   gY = gy * iR;
 }
 
+// Gridded height map: bilinear lookup (ART/ModuleDefects.py:131-137; SciPy RegularGridInterpolator, linear)
+ART_HD double grid_offset(const ArtGridDefect& g, double px, double py) {
+  const double fx = (px - g.x0) / g.dx, fy = (py - g.y0) / g.dy;
+  int ix = (int)floor(fx), iy = (int)floor(fy);
+  ix = ix < 0 ? 0 : (ix > g.nx - 2 ? g.nx - 2 : ix);
+  iy = iy < 0 ? 0 : (iy > g.ny - 2 ? g.ny - 2 : iy);
+  const double tx = fx - (double)ix, ty = fy - (double)iy;
+  const double* r0 = g.h + (int64_t)ix * g.ny + iy;
+  const double* r1 = r0 + g.ny;
+  const double v00 = r0[0], v01 = r0[1], v10 = r1[0], v11 = r1[1];
+  return (v00 * (1.0 - tx) + v10 * tx) * (1.0 - ty) + (v01 * (1.0 - tx) + v11 * tx) * ty;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // undeformed normals, get_normal of each mirror class
 template <int KIND>
@@ -519,7 +532,7 @@ ART_HD bool trace_ray(const ArtElementDesc& e, const double* zern, Ray& r) {
   } else {
     double nx, ny, nz;
     base_normal<KIND>(e, Px, Py, Pz, nx, ny, nz);
-    if (DEFECT && e.n_defects > 0) {
+    if (DEFECT && (e.n_defects > 0 || e.n_grid > 0)) {
       // DeformedMirror._get_intersection, ModuleMirror.py:969-980: slide the hit point along the ray by
       // h / cos(alpha), h = summed defect offsets at (P - centre), alpha = angle(-u, base normal)
       double h = 0.0;
@@ -528,6 +541,7 @@ ART_HD bool trace_ray(const ArtElementDesc& e, const double* zern, Ray& r) {
         zernike_defect(zern + d * ART_ZERN_STRIDE, Px - e.centre[0], Py - e.centre[1], hd, gX, gY);
         h += hd;
       }
+      for (int d = 0; d < e.n_grid; ++d) h += grid_offset(e.grid[d], Px - e.centre[0], Py - e.centre[1]);
       const double cosa = -dot3(ux, uy, uz, nx, ny, nz);
       const double s = div_full(h, cosa);
       t -= s;

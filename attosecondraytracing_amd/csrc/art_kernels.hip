@@ -416,6 +416,9 @@ int check_elem(const ArtElementDesc* e) {
   if (e->n_defects < 0 || e->n_defects > ART_MAX_DEFECTS) return fail(ART_ERR_UNSUPPORTED, "too many defects on one mirror");
   if (e->n_defects > 0 && e->kind == ART_MASK) return fail(ART_ERR_BAD_ARG, "a mask cannot carry defects");
   if (e->n_defects > 0 && !e->zern) return fail(ART_ERR_BAD_ARG, "n_defects > 0 but zern table is NULL");
+  if (e->n_grid < 0 || e->n_grid > ART_MAX_DEFECTS) return fail(ART_ERR_UNSUPPORTED, "too many gridded defects on one mirror");
+  if (e->n_grid > 0 && e->kind == ART_MASK) return fail(ART_ERR_BAD_ARG, "a mask cannot carry defects");
+  if (e->n_grid > 0 && !e->grid) return fail(ART_ERR_BAD_ARG, "n_grid > 0 but grid table is NULL");
   return ART_OK;
 }
 
@@ -423,7 +426,7 @@ template <int KIND>
 void launch_element(const ArtElementDesc& e, const ArtBundleView& in, const ArtBundleView& out, int64_t n,
                     hipStream_t s) {
   const int grid = grid_for(n);
-  if (e.n_defects > 0)
+  if (e.n_defects > 0 || e.n_grid > 0)
     hipLaunchKernelGGL((k_trace_element<KIND, true>), dim3(grid), dim3(kBlock), 0, s, e, in, out, n);
   else
     hipLaunchKernelGGL((k_trace_element<KIND, false>), dim3(grid), dim3(kBlock), 0, s, e, in, out, n);
@@ -492,6 +495,7 @@ int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundl
   for (int k0 = 0; k0 < n_elems; k0 += kChainMax) {
     ChainArgs a;
     memset(&a, 0, sizeof(a));
+    bool any_defect = false;
     const int m = (n_elems - k0 < kChainMax) ? n_elems - k0 : kChainMax;
     a.n_elems = m;
     for (int k = 0; k < m; ++k) {
@@ -499,10 +503,11 @@ int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundl
       a.out[k] = outs[k0 + k];
       a.zoff[k] = a.zern_doubles;
       a.zern_doubles += a.e[k].n_defects * ART_ZERN_STRIDE;
+      if (a.e[k].n_defects > 0 || a.e[k].n_grid > 0) any_defect = true;
     }
     // the chunk's last bundle is the next chunk's input: it must exist
     if (!view_ok(&a.out[m - 1])) return fail(ART_ERR_BAD_ARG, "chains longer than 8 need a view every 8th element");
-    if (a.zern_doubles > 0)
+    if (any_defect)
       hipLaunchKernelGGL(k_trace_chain<true>, dim3(grid_for(n)), dim3(kBlock), (size_t)a.zern_doubles * sizeof(double),
                          s, a, *cur, n);
     else

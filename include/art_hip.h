@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ART_ABI_VERSION 1
+#define ART_ABI_VERSION 2
 
 /* error codes */
 #define ART_OK 0
@@ -67,6 +67,17 @@ enum ArtSupportKind {
 #define ART_ZERN_STRIDE (2 + ART_ZERN_NCOEF)                                       /* 93 */
 #define ART_MAX_DEFECTS 4
 
+/* Gridded height-map defect (ART/ModuleDefects.py `Fourrier` :69-146; offset lookup :131-137 through SciPy's
+ * RegularGridInterpolator(method="linear")): h[ix * ny + iy] on the regular grid x = x0 + ix*dx, y = y0 + iy*dy,
+ * bilinear interpolation, evaluated at (P - centre).  An array of these structs lives in DEVICE memory.
+ * Points outside the grid are clamped to the edge cell (SciPy raises there; hits are inside the support, which
+ * the grid covers).  Only the offset is used: the reference's Fourrier.get_normal raises under NumPy >= 1.24. */
+typedef struct ArtGridDefect {
+  const double* h;       /* DEVICE, nx * ny doubles */
+  int32_t nx, ny;
+  double x0, y0, dx, dy;
+} ArtGridDefect;
+
 /* One optical element = optic + pose.  Replaces the per-ray frame changes of
  * ART/ModuleProcessing.py:289-295, :306-309 by two constant 3x3 maps built on the host with the
  * reference's own RotationPoint special cases (ART/ModuleGeometry.py:333-343):
@@ -84,6 +95,9 @@ typedef struct ArtElementDesc {
   double sp[6];          /* support parameters                              */
   double mp[4];          /* mirror parameters                               */
   const double* zern;    /* DEVICE pointer, n_defects * ART_ZERN_STRIDE doubles, or NULL */
+  const ArtGridDefect* grid; /* DEVICE pointer to n_grid structs, or NULL           */
+  int32_t n_grid;        /* 0..ART_MAX_DEFECTS gridded height-map defects           */
+  int32_t reserved;
 } ArtElementDesc;
 
 /* SoA view of one ray bundle (all DEVICE pointers, length n).  `path` is the running optical path

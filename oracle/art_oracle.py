@@ -54,6 +54,21 @@ class ZernikeDefect:
 
 
 @dataclass
+class GridDefect:
+    """Height map of a `Fourrier` defect (ART/ModuleDefects.py:69-146): `deformation` as the reference stores it
+    (shape [ny, nx]); offset = RegularGridInterpolator((X, Y), deformation.T, "linear") (:104-110, :131-137)."""
+    deformation: np.ndarray
+    rect: Sequence[float]
+
+    def offset(self, P):
+        from scipy.interpolate import RegularGridInterpolator
+        d = self.deformation
+        X = np.linspace(-self.rect[0] / 2, self.rect[0] / 2, num=d.shape[1])
+        Y = np.linspace(-self.rect[1] / 2, self.rect[1] / 2, num=d.shape[0])
+        return RegularGridInterpolator((X, Y), np.transpose(d), method="linear")(P[:, :2])
+
+
+@dataclass
 class Optic:
     """kind in {plane, sphere, parabola, torus, ellipsoid, cylinder, mask}; params per kind."""
     kind: str
@@ -61,6 +76,7 @@ class Optic:
     params: Dict[str, float] = field(default_factory=dict)
     defects: List[ZernikeDefect] = field(default_factory=list)
     type: str = ""
+    grids: List[GridDefect] = field(default_factory=list)
 
     def is_mirror(self) -> bool:
         return self.kind != "mask"
@@ -450,12 +466,14 @@ def base_intersection(O: Optic, A, u):
 def intersection(O: Optic, A, u):
     """`_get_intersection` incl. DeformedMirror (ART/ModuleMirror.py:969-980)."""
     hit, P = base_intersection(O, A, u)
-    if O.defects and hit.any():
+    if (O.defects or O.grids) and hit.any():
         C = O.centre()
         Ph = P[hit]
         h = np.zeros(Ph.shape[0])
         for D in O.defects:
             h = h + zernike_offset(D, Ph - C)
+        for G in O.grids:
+            h = h + G.offset(Ph - C)
         alpha = angle_between(-u[hit], base_normal(O, Ph))
         P = P.copy()
         P[hit] = Ph - u[hit] * (h / np.cos(alpha))[:, None]
@@ -691,14 +709,16 @@ def apply_gaussian_intensity(B: Bundle, fraction=1 / np.e ** 2) -> Bundle:
 
 
 # =============================================================================== fixture glue
-def optic_from_desc(d) -> Optic:
+def optic_from_desc(d, arrays=None) -> Optic:
     S = Support(d["support"]["kind"], list(d["support"]["p"]))
     params = {k: d[k] for k in ("R", "r", "feff", "offaxis_rad", "p", "a", "b") if k in d}
     defects = [ZernikeDefect({(int(c[0]), int(c[1])): float(c[2]) for c in z["coeffs"]}, float(z["R"]))
-               for z in d.get("defects", [])]
-    return Optic(d["kind"], S, params, defects, d.get("type", ""))
+               for z in d.get("defects", []) if z["kind"] == "zernike"]
+    rect = [2 * S.p[0], 2 * S.p[0]] if S.kind in ("round", "roundhole") else [S.p[0], S.p[1]]   # _CircumRect
+    grids = [GridDefect(arrays[z["map"]], rect) for z in d.get("defects", []) if z["kind"] == "fourrier"]
+    return Optic(d["kind"], S, params, defects, d.get("type", ""), grids)
 
 
-def elements_from_scene(scene) -> List[Element]:
-    return [Element(optic_from_desc(e), np.array(e["position"], float), np.array(e["normal"], float),
+def elements_from_scene(scene, arrays=None) -> List[Element]:
+    return [Element(optic_from_desc(e, arrays), np.array(e["position"], float), np.array(e["normal"], float),
                     np.array(e["majoraxis"], float)) for e in scene["elements"]]

@@ -112,6 +112,10 @@ def describe_optic(O, arrays, tag):
             if dn == "Zernike":
                 defects.append({"kind": "zernike", "R": float(D.R),
                                 "coeffs": [[int(k[0]), int(k[1]), float(c)] for k, c in D.coefficients.items()]})
+            elif dn == "Fourrier":
+                key = f"{tag}fourrier{j}_map"
+                arrays[key] = np.asarray(D.deformation)
+                defects.append({"kind": "fourrier", "map": key, "ctor": getattr(D, "_ctor", None)})
             else:
                 raise ValueError("defect kind not captured: " + dn)
         d["defects"] = defects
@@ -325,6 +329,30 @@ def scenes_single_elements():
                  n=1000, half_angle=0.25, jitter=2.0, detector_distance=100, plane_angle=-60.0)
 
 
+def scene_fourrier(n_rays=1500):
+    """examples/CONFIG_deformed.py:19-46 with a coarser Fourrier map (smallest = 1 mm -> 80 x 80) and a seeded RNG:
+    the only unseeded call of the ctor is one np.random.uniform (ART/ModuleDefects.py:92)."""
+    SourceProperties = {"Divergence": 0, "SourceSize": 100, "Wavelength": 800e-6, "DeltaFT": 0, "NumberRays": n_rays}
+    Support = msupp.SupportRectangle(40, 40)
+    Mirror = mmirror.MirrorParabolic(25.4, 0, Support)
+    for tag, ctor in (("a", dict(RMS=1e-1, smallest=1.0, seed=2024)),
+                      ("b", dict(RMS=2e-2, slope=-1.5, smallest=0.5, biggest=25.0, seed=99))):
+        kw = {k: v for k, v in ctor.items() if k != "seed"}
+        np.random.seed(ctor["seed"])
+        Defect = mdef.Fourrier(Support, **kw)
+        Defect._ctor = ctor
+        Deformed = mmirror.DeformedMirror(Mirror, [Defect])
+        chain = mp.OEPlacement(SourceProperties, [Deformed], [15], [0], Description="deformed parabola (Fourrier)")
+        dump_chain("c5_fourrier_" + tag, chain, detector_distance=25.4, ignore_defects=True)
+    # Fourrier + Zernike stacked on one mirror
+    np.random.seed(5)
+    D1 = mdef.Fourrier(Support, RMS=5e-2, smallest=2.0)
+    D1._ctor = dict(RMS=5e-2, smallest=2.0, seed=5)
+    D2 = mdef.Zernike(Support, {(2, 1): 1e-4, (4, 2): 2e-5})
+    chain = mp.OEPlacement(SourceProperties, [mmirror.DeformedMirror(Mirror, [D1, D2])], [15], [0], Description="mixed defects")
+    dump_chain("c5_fourrier_zernike", chain, detector_distance=25.4, ignore_defects=True)
+
+
 def scene_mixed8(n_rays=1000):
     """8-element mixed chain (BASELINE config 4 analogue): OAP collimate -> plane -> toroid pair -> planes -> OAP focus."""
     SourceProperties = {"Divergence": 0.03, "SourceSize": 0, "Wavelength": 50e-6, "DeltaFT": 0.5,
@@ -490,6 +518,7 @@ if __name__ == "__main__":
     scene_c2()
     scene_c3()
     scene_c5()
+    scene_fourrier()
     scenes_single_elements()
     scene_mixed8()
     scene_frames()

@@ -22,7 +22,7 @@ def build_support(d):
     return cls(*d["p"])
 
 
-def build_optic(e):
+def build_optic(e, arrays=None):
     S = build_support(e["support"])
     k = e["kind"]
     if k == "plane":
@@ -43,15 +43,25 @@ def build_optic(e):
     else:
         raise ValueError(k)
     if e.get("defects"):
-        defs = [mdef.Zernike(S, {(int(c[0]), int(c[1])): float(c[2]) for c in z["coeffs"]}) for z in e["defects"]]
+        defs = []
+        for z in e["defects"]:
+            if z["kind"] == "zernike":
+                defs.append(mdef.Zernike(S, {(int(c[0]), int(c[1])): float(c[2]) for c in z["coeffs"]}))
+            else:   # Fourrier: same ctor arguments and RNG seed as the reference run -> bit-identical map
+                ctor = dict(z["ctor"])
+                np.random.seed(int(ctor.pop("seed")))
+                D = mdef.Fourrier(S, **ctor)
+                if arrays is not None:
+                    assert np.array_equal(D.deformation, arrays[z["map"]]), "synthesised Fourrier map differs"
+                defs.append(D)
         O = mmirror.DeformedMirror(O, defs)
     return O
 
 
-def build_elements(scene):
+def build_elements(scene, arrays=None):
     els = []
     for e in scene["elements"]:
-        O = build_optic(e)
+        O = build_optic(e, arrays)
         assert O.type == e["type"]
         c = np.asarray(O.get_centre(), dtype=float)
         assert np.abs(c - np.array(e["centre"])).max() <= 1e-12 * max(1.0, np.abs(c).max())

@@ -27,7 +27,7 @@ def hip():
 def test_gpu_chain_matches_reference(hip, name, mode):
     import ART.ModuleProcessing as mp
     scene, a = load_golden(name)
-    els = pc.build_elements(scene)
+    els = pc.build_elements(scene, a)
     src = pc.source_bundle(a, scene)
     out = mp.RayTracingCalculation(src, els, IgnoreDefects=scene.get("IgnoreDefects", True), mode=mode)
     pc.check_outputs(out, a, scene)
@@ -41,7 +41,7 @@ def test_gpu_detector_matches_reference(hip, name):
     scene, a = load_golden(name)
     if "detector" not in scene:
         pytest.skip("no detector in fixture")
-    els = pc.build_elements(scene)
+    els = pc.build_elements(scene, a)
     src = pc.source_bundle(a, scene)
     last = mp.RayTracingCalculation(src, els, IgnoreDefects=scene.get("IgnoreDefects", True))[-1]
     d = scene["detector"]

@@ -28,7 +28,7 @@ def test_oeplacement_matches_reference(twin, name):
     pl = scene.get("placement") or scene.get("placement_before_roll")
     if pl is None:
         pytest.skip("poses were modified after placement in this fixture")
-    optics = [pc.build_optic(e) for e in scene["elements"]]
+    optics = [pc.build_optic(e, a) for e in scene["elements"]]
     SP = dict(pl["SourceProperties"])
     SP["NumberRays"] = int(SP["NumberRays"])
     chain = mp.OEPlacement(SP, optics, list(pl["DistanceList"]), list(pl["IncidenceAngleList"]),
@@ -96,7 +96,7 @@ def test_autofocus_matches_reference(twin):
     import ART.ModuleProcessing as mp
     import ART.ModuleDetector as mdet
     scene, a = load_golden("autofocus_c3")
-    els = pc.build_elements(scene)
+    els = pc.build_elements(scene, a)
     src = pc.source_bundle(a, scene)
     last = mp.RayTracingCalculation(src, els)[-1]
     d = scene["detector"]
@@ -119,7 +119,7 @@ def test_bundle_list_protocol(twin):
     import ART.ModuleProcessing as mp
     import ART.ModuleOpticalRay as mray
     scene, a = load_golden("c3_twisted_chain04")
-    els = pc.build_elements(scene)
+    els = pc.build_elements(scene, a)
     out = mp.RayTracingCalculation(pc.source_bundle(a, scene), els)
     b = out[-1]
     assert len(b) == 673
@@ -155,7 +155,7 @@ def test_chain_cache_and_misalignment(twin):
     """get_output_rays recomputes only when the source or an element changed (ModuleOpticalChain.py:183-202)."""
     import ART.ModuleOpticalChain as moc
     scene, a = load_golden("c2_fxf_chain05")
-    chain = moc.OpticalChain(pc.source_bundle(a, scene), pc.build_elements(scene), "cache")
+    chain = moc.OpticalChain(pc.source_bundle(a, scene), pc.build_elements(scene, a), "cache")
     o1 = chain.get_output_rays()
     assert chain.get_output_rays() is o1
     chain.rotate_OE(1, "pitch", 0.01)

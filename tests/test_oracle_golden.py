@@ -20,7 +20,7 @@ def test_oracle_chain_matches_reference(name, fast):
     if not fast and scene["n_source"] > 600 and len(scene["elements"]) > 3:
         pytest.skip("per-ray quaternion loop only on the small cases")
     src = source_from_arrays(a, scene)
-    els = orc.elements_from_scene(scene)
+    els = orc.elements_from_scene(scene, a)
     for e, d in zip(els, scene["elements"]):
         assert np.allclose(e.optic.centre(), d["centre"], rtol=0, atol=1e-12 * max(1.0, np.abs(d["centre"]).max()))
     out = orc.ray_tracing_calculation(src, els, IgnoreDefects=scene.get("IgnoreDefects", True), fast=fast)
@@ -47,7 +47,7 @@ def test_oracle_detector_matches_reference(name):
     if "detector" not in scene:
         pytest.skip("no detector in fixture")
     src = source_from_arrays(a, scene)
-    els = orc.elements_from_scene(scene)
+    els = orc.elements_from_scene(scene, a)
     out = orc.ray_tracing_calculation(src, els, IgnoreDefects=scene.get("IgnoreDefects", True))
     last = out[-1]
     d = scene["detector"]

@@ -99,8 +99,15 @@ def test_other_configs_run(twin, name):
         assert 0 < et <= 100.0 + 1e-9
 
 
-def test_config_deformed_reports_unbuilt_defect(twin):
-    """CONFIG_deformed.py builds a `Fourrier` map defect, which is not built yet: it must fail loudly at
-    construction, not trace silently without the defect."""
-    with pytest.raises(NotImplementedError, match="Fourrier"):
-        _load("CONFIG_deformed.py")
+def test_config_deformed(twin):
+    """CONFIG_deformed.py: a Fourrier height map with smallest = 0.01 mm on a 40 x 40 mm support = 8000 x 8000
+    samples (0.5 GB as fp64, synthesised with a 4001 x 8000 complex FFT).  Runs unmodified; slow-ish on CPU."""
+    import numpy as np
+    np.random.seed(1)
+    mod = _load("CONFIG_deformed.py")
+    D = mod.DeformedMirror.DeformationList[0]
+    assert D.deformation.shape == (8000, 8000) and abs(D.rms - 0.1) < 1e-12
+    kept = _run(mod)
+    out = kept["OpticalChain"][0].get_output_rays()[-1]
+    assert len(kept["OpticalChain"][0].source_rays) == 999 and len(out) == 202      # same count as the Zernike fixtures
+    assert np.isfinite(kept["SpotSizeSD"][0]) and kept["SpotSizeSD"][0] > 0

@@ -23,7 +23,7 @@ def twin():
 def test_twin_chain_matches_reference(twin, name, mode):
     import ART.ModuleProcessing as mp
     scene, a = load_golden(name)
-    els = pc.build_elements(scene)
+    els = pc.build_elements(scene, a)
     src = pc.source_bundle(a, scene)
     out = mp.RayTracingCalculation(src, els, IgnoreDefects=scene.get("IgnoreDefects", True), mode=mode)
     pc.check_outputs(out, a, scene)
@@ -37,7 +37,7 @@ def test_twin_detector_matches_reference(twin, name):
     scene, a = load_golden(name)
     if "detector" not in scene:
         pytest.skip("no detector in fixture")
-    els = pc.build_elements(scene)
+    els = pc.build_elements(scene, a)
     src = pc.source_bundle(a, scene)
     last = mp.RayTracingCalculation(src, els, IgnoreDefects=scene.get("IgnoreDefects", True))[-1]
     d = scene["detector"]
