@@ -196,96 +196,51 @@ ART_HD int quadratic_roots(double a, double b, double c, double& t1, double& t2)
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Zernike defects (ART/ModuleDefects.py:149-174; recurrences ART/recursive_zernike_generator.py:35-254).
-// Evaluates h = sum c_nm Z_nm, gx = sum c_nm dZ_nm/dx, gy = sum c_nm dZ_nm/dy at (x, y) with x, y already
-// divided by R.  Rows n-1 and n-2 live in registers (loops fully unrolled for the template order N).
-template <int N>
-ART_HD void zernike_eval(const double* coef, double x, double y, double& val, double& gx, double& gy) {
-  double Zp[N + 1], Zpp[N + 1], GXpp[N + 1], GYpp[N + 1], GXp[N + 1], GYp[N + 1];
-#pragma unroll
-  for (int i = 0; i <= N; ++i) Zp[i] = Zpp[i] = GXpp[i] = GYpp[i] = GXp[i] = GYp[i] = 0.0;
-  // seeds (:51-62): Z00 = 1, Z10 = y, Z11 = x
-  Zpp[0] = 1.0;
-  Zp[0] = y;
-  Zp[1] = x;
-  GXp[1] = 1.0;
-  GYp[0] = 1.0;
-  val = coef[0] + coef[1] * y + coef[2] * x;
-  gx = coef[2];
-  gy = coef[1];
-#pragma unroll
-  for (int n = 2; n <= N; ++n) {
-    double Zn[N + 1], GXn[N + 1], GYn[N + 1];
-#pragma unroll
-    for (int m = 0; m <= N; ++m) {
-      if (m > n) {
-        Zn[m] = GXn[m] = GYn[m] = 0.0;
-        continue;
-      }
-      double z, dx_, dy_;
-      const double dn = (double)n;
-      if (m == 0) {  // :79-95
-        z = x * Zp[0] + y * Zp[n - 1];
-        dx_ = dn * Zp[0];
-        dy_ = dn * Zp[n - 1];
-      } else if (m == n) {  // :97-110
-        z = x * Zp[n - 1] - y * Zp[0];
-        dx_ = dn * Zp[n - 1];
-        dy_ = -1.0 * dn * Zp[0];
-      } else if ((n % 2 != 0) && (2 * m == n - 1)) {  // :112-145
-        z = y * Zp[n - 1 - m] + x * Zp[m - 1] - y * Zp[n - m] - Zpp[m - 1];
-        dx_ = dn * Zp[m - 1] + GXpp[m - 1];
-        dy_ = dn * Zp[n - 1 - m] - dn * Zp[n - m] + GYpp[m - 1];
-      } else if ((n % 2 != 0) && (2 * m == n + 1)) {  // :147-177
-        z = x * Zp[m] + y * Zp[n - 1 - m] + x * Zp[m - 1] - Zpp[m - 1];
-        dx_ = dn * Zp[m] + dn * Zp[m - 1] + GXpp[m - 1];
-        dy_ = dn * Zp[n - 1 - m] + GYpp[m - 1];
-      } else if ((n % 2 == 0) && (2 * m == n)) {  // :179-209
-        z = 2.0 * x * Zp[m] + 2.0 * y * Zp[m - 1] - Zpp[m - 1];
-        dx_ = 2.0 * dn * Zp[m] + GXpp[m - 1];
-        dy_ = 2.0 * dn * Zp[n - 1 - m] + GYpp[m - 1];
-      } else {  // :211-246
-        z = x * Zp[m] + y * Zp[n - 1 - m] + x * Zp[m - 1] - y * Zp[n - m] - Zpp[m - 1];
-        dx_ = dn * Zp[m] + dn * Zp[m - 1] + GXpp[m - 1];
-        dy_ = dn * Zp[n - 1 - m] - dn * Zp[n - m] + GYpp[m - 1];
-      }
-      Zn[m] = z;
-      GXn[m] = dx_;
-      GYn[m] = dy_;
-      const double c = coef[n * (n + 1) / 2 + m];
-      val = fma(c, z, val);
-      gx = fma(c, dx_, gx);
-      gy = fma(c, dy_, gy);
-    }
-#pragma unroll
-    for (int m = 0; m <= N; ++m) {
-      Zpp[m] = Zp[m];
-      GXpp[m] = GXp[m];
-      GYpp[m] = GYp[m];
-      Zp[m] = Zn[m];
-      GXp[m] = GXn[m];
-      GYp[m] = GYn[m];
-    }
+// Zernike defects (ART/ModuleDefects.py:149-174; polynomials of ART/recursive_zernike_generator.py:35-254).
+// The host expands the summed surface into monomials (exact: the recurrences have integer coefficients) and stores
+// the polynomial and its two partial derivatives (table layout: art_hip.h).  Per ray this is a bivariate Horner
+// scheme whose coefficients every lane reads from the same LDS address (broadcast, conflict-free): no per-lane
+// arrays, ~20 live registers, cost (N+1)(N+2)/2 fused multiply-adds per polynomial.
+ART_HD double poly2_horner(const double* A, int N, double x, double y) {
+  double acc = 0.0;
+  for (int p = N; p >= 0; --p) {
+    const double* row = A + p * ART_ZERN_DIM;
+    double in = row[N - p];
+    for (int q = N - p - 1; q >= 0; --q) in = fma(in, y, row[q]);
+    acc = fma(acc, x, in);
   }
+  return acc;
 }
 
-// table layout: art_hip.h (ART_ZERN_STRIDE per defect).  x, y relative to the mirror centre, in mm.
-ART_HD void zernike_defect(const double* tab, double px, double py, double& h, double& gX, double& gY) {
-  const double R = tab[0];
-  const int order = (int)tab[1];
-  const double* coef = tab + 2;
-  const double iR = rcp_full(R);
+// h = get_offset (:168-174)
+ART_HD double zernike_offset(const double* tab, double px, double py) {
+  const double iR = rcp_full(tab[0]);
+  return poly2_horner(tab + 2, (int)tab[1], px * iR, py * iR);
+}
+
+// (gX, gY): get_normal (:159-166) returns (-gX, -gY, 1)
+ART_HD void zernike_slopes(const double* tab, double px, double py, double& gX, double& gY) {
+  const double iR = rcp_full(tab[0]);
+  const int N = (int)tab[1];
   const double x = px * iR, y = py * iR;
-  double v, gx, gy;
-  if (order <= 2) zernike_eval<2>(coef, x, y, v, gx, gy);
-  else if (order <= 4) zernike_eval<4>(coef, x, y, v, gx, gy);
-  else if (order <= 6) zernike_eval<6>(coef, x, y, v, gx, gy);
-  else if (order <= 8) zernike_eval<8>(coef, x, y, v, gx, gy);
-  else if (order <= 10) zernike_eval<10>(coef, x, y, v, gx, gy);
-  else zernike_eval<12>(coef, x, y, v, gx, gy);
-  h = v;          // get_offset  :168-174
-  gX = gx * iR;   // get_normal  :159-166 returns (-gX, -gY, 1)
-  gY = gy * iR;
+  // both derivative polynomials in one pass (two independent Horner chains), degree N-1
+  const double* GX = tab + 2 + ART_ZERN_DIM * ART_ZERN_DIM;
+  const double* GY = GX + ART_ZERN_DIM * ART_ZERN_DIM;
+  double ax = 0.0, ay = 0.0;
+  const int M = N - 1;
+  for (int p = M; p >= 0; --p) {
+    const double* rx = GX + p * ART_ZERN_DIM;
+    const double* ry = GY + p * ART_ZERN_DIM;
+    double ix = rx[M - p], iy = ry[M - p];
+    for (int q = M - p - 1; q >= 0; --q) {
+      ix = fma(ix, y, rx[q]);
+      iy = fma(iy, y, ry[q]);
+    }
+    ax = fma(ax, x, ix);
+    ay = fma(ay, x, iy);
+  }
+  gX = ax * iR;
+  gY = ay * iR;
 }
 
 // Gridded height map: bilinear lookup (ART/ModuleDefects.py:131-137; SciPy RegularGridInterpolator, linear)
@@ -536,11 +491,8 @@ ART_HD bool trace_ray(const ArtElementDesc& e, const double* zern, Ray& r) {
       // DeformedMirror._get_intersection, ModuleMirror.py:969-980: slide the hit point along the ray by
       // h / cos(alpha), h = summed defect offsets at (P - centre), alpha = angle(-u, base normal)
       double h = 0.0;
-      for (int d = 0; d < e.n_defects; ++d) {
-        double hd, gX, gY;
-        zernike_defect(zern + d * ART_ZERN_STRIDE, Px - e.centre[0], Py - e.centre[1], hd, gX, gY);
-        h += hd;
-      }
+      for (int d = 0; d < e.n_defects; ++d)
+        h += zernike_offset(zern + d * ART_ZERN_STRIDE, Px - e.centre[0], Py - e.centre[1]);
       for (int d = 0; d < e.n_grid; ++d) h += grid_offset(e.grid[d], Px - e.centre[0], Py - e.centre[1]);
       const double cosa = -dot3(ux, uy, uz, nx, ny, nz);
       const double s = div_full(h, cosa);
@@ -553,8 +505,8 @@ ART_HD bool trace_ray(const ArtElementDesc& e, const double* zern, Ray& r) {
         const double inz = rcp_full(nz);
         double gXs = -nx * inz, gYs = -ny * inz;
         for (int d = 0; d < e.n_defects; ++d) {
-          double hd, gX, gY;
-          zernike_defect(zern + d * ART_ZERN_STRIDE, Px - e.centre[0], Py - e.centre[1], hd, gX, gY);
+          double gX, gY;
+          zernike_slopes(zern + d * ART_ZERN_STRIDE, Px - e.centre[0], Py - e.centre[1], gX, gY);
           gXs += gX; gYs += gY;
         }
         const double inv = rsqrt_full(fma(gXs, gXs, fma(gYs, gYs, 1.0)));

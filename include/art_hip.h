@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ART_ABI_VERSION 2
+#define ART_ABI_VERSION 3
 
 /* error codes */
 #define ART_OK 0
@@ -58,13 +58,19 @@ enum ArtSupportKind {
 /* element flags */
 #define ART_FLAG_PERTURBED_NORMAL 1u /* IgnoreDefects=False: reflect off the defect-perturbed normal (ModuleMirror.py:933-936) */
 
-/* Zernike defect table (ART/ModuleDefects.py:149-174), a DEVICE array of doubles per element:
- *   for defect d in [0, n_defects):  base = d * ART_ZERN_STRIDE
- *     [base+0] = R  (Support._CircumCirc()),  [base+1] = max radial order N (2..ART_ZERN_MAX_ORDER)
- *     [base+2 + n(n+1)/2 + m] = coefficient of (n, m), m = 0..n, 0 where absent                       */
+/* Zernike defect table (ART/ModuleDefects.py:149-174), a DEVICE array of doubles per element.  The polynomials
+ * of ART/recursive_zernike_generator.py have integer monomial coefficients; the host expands
+ *     h(x,y) = sum_nm c_nm Z_nm(x,y) = sum_pq A[p][q] x^p y^q        (x, y = (P - centre) / R)
+ * exactly and stores A and its two partial derivatives, so that the kernels evaluate three bivariate Horner
+ * schemes out of LDS instead of carrying the recurrence rows in registers.  Layout, for defect d:
+ *   base = d * ART_ZERN_STRIDE
+ *   [base+0] = R (Support._CircumCirc()),  [base+1] = max total degree N (2..ART_ZERN_MAX_ORDER)
+ *   [base+2            + p*ART_ZERN_DIM + q] = A[p][q]        coefficient of x^p y^q of h
+ *   [base+2 +   DIM^2  + p*ART_ZERN_DIM + q] = dA/dx [p][q]   = (p+1) A[p+1][q]
+ *   [base+2 + 2*DIM^2  + p*ART_ZERN_DIM + q] = dA/dy [p][q]   = (q+1) A[p][q+1]                        */
 #define ART_ZERN_MAX_ORDER 12
-#define ART_ZERN_NCOEF ((ART_ZERN_MAX_ORDER + 1) * (ART_ZERN_MAX_ORDER + 2) / 2) /* 91 */
-#define ART_ZERN_STRIDE (2 + ART_ZERN_NCOEF)                                       /* 93 */
+#define ART_ZERN_DIM (ART_ZERN_MAX_ORDER + 1)                      /* 13 */
+#define ART_ZERN_STRIDE (2 + 3 * ART_ZERN_DIM * ART_ZERN_DIM)      /* 509 */
 #define ART_MAX_DEFECTS 4
 
 /* Gridded height-map defect (ART/ModuleDefects.py `Fourrier` :69-146; offset lookup :131-137 through SciPy's

@@ -177,3 +177,35 @@ def test_chain_cache_and_misalignment(twin):
         chain.rotate_OE(1, "sideways", 1.0)
     with pytest.raises(TypeError):
         chain.source_rays = "nope"
+
+
+def test_zernike_polynomial_tables_match_recurrences():
+    """The monomial expansion handed to the kernels (ModuleDefects.zernike_monomials, Zernike._abi_table) equals
+    the reference's recurrences (fixture zernike_tierA.npz, generated with no stand-in) for every (n, m) up to
+    order 9, values and both gradients."""
+    import ART.ModuleDefects as mdef
+    import ART.ModuleSupport as msupp
+    from attosecondraytracing_amd import _abi
+    _, a = load_golden("zernike_tierA")
+    x, y = a["x"], a["y"]
+    Zm = mdef.zernike_monomials(9)
+    for i, (n, m) in enumerate(a["nm"]):
+        C = Zm[(int(n), int(m))].astype(float)
+        P, Q = np.meshgrid(np.arange(C.shape[0]), np.arange(C.shape[1]), indexing="ij")
+        val = (C[None] * x[:, None, None] ** P[None] * y[:, None, None] ** Q[None]).sum(axis=(1, 2))
+        assert np.abs(val - a["val"][i]).max() <= 1e-12 * max(1.0, np.abs(a["val"][i]).max())
+    # the packed table: offset and slopes of a defect vs Zernike.get_offset / get_normal of the reference
+    S = msupp.SupportRectangle(40, 30)
+    Zd = mdef.Zernike(S, {(int(r[0]), int(r[1])): float(r[2]) for r in a["defect_coeffs"]})
+    t = Zd._abi_table()
+    D = _abi.ART_ZERN_DIM
+    R, N = t[0], int(t[1])
+    A, GX, GY = (t[2 + k * D * D: 2 + (k + 1) * D * D].reshape(D, D) for k in range(3))
+    px, py = a["defect_points"][:, 0] / R, a["defect_points"][:, 1] / R
+
+    def ev(M):
+        P, Q = np.meshgrid(np.arange(D), np.arange(D), indexing="ij")
+        return (M[None] * px[:, None, None] ** P[None] * py[:, None, None] ** Q[None]).sum(axis=(1, 2))
+    assert np.abs(ev(A) - a["defect_offset"]).max() <= 1e-15
+    assert np.abs(-ev(GX) / R - a["defect_normal"][:, 0]).max() <= 1e-15
+    assert np.abs(-ev(GY) / R - a["defect_normal"][:, 1]).max() <= 1e-15
