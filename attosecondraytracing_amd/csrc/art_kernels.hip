@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "art_device.h"
@@ -150,8 +151,8 @@ struct ChainArgs {
 };
 
 // whole chain, ray resident in registers; history written for every element whose view is non-null
-template <bool DEFECT>
-__global__ __launch_bounds__(kBlock) void k_trace_chain(const ChainArgs a, const ArtBundleView in, const int64_t n) {
+template <bool DEFECT, int WAVES>
+__global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain(const ChainArgs a, const ArtBundleView in, const int64_t n) {
   extern __shared__ double s_zern[];  // Zernike tables of all elements, staged once per workgroup
   if (DEFECT) {
     for (int k = 0; k < a.n_elems; ++k) {
@@ -507,11 +508,19 @@ int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundl
     }
     // the chunk's last bundle is the next chunk's input: it must exist
     if (!view_ok(&a.out[m - 1])) return fail(ART_ERR_BAD_ARG, "chains longer than 8 need a view every 8th element");
+    const char* wv = getenv("ART_CHAIN_WAVES");   // tuning knob: register budget of the fused kernel (waves per SIMD)
+    const int waves = wv ? atoi(wv) : 4;
+    const dim3 g(grid_for(n)), b(kBlock);
     if (any_defect)
-      hipLaunchKernelGGL(k_trace_chain<true>, dim3(grid_for(n)), dim3(kBlock), (size_t)a.zern_doubles * sizeof(double),
-                         s, a, *cur, n);
+      hipLaunchKernelGGL((k_trace_chain<true, 4>), g, b, (size_t)a.zern_doubles * sizeof(double), s, a, *cur, n);
+    else if (waves == 5)
+      hipLaunchKernelGGL((k_trace_chain<false, 5>), g, b, 0, s, a, *cur, n);
+    else if (waves == 6)
+      hipLaunchKernelGGL((k_trace_chain<false, 6>), g, b, 0, s, a, *cur, n);
+    else if (waves == 3)
+      hipLaunchKernelGGL((k_trace_chain<false, 3>), g, b, 0, s, a, *cur, n);
     else
-      hipLaunchKernelGGL(k_trace_chain<false>, dim3(grid_for(n)), dim3(kBlock), 0, s, a, *cur, n);
+      hipLaunchKernelGGL((k_trace_chain<false, 4>), g, b, 0, s, a, *cur, n);
     cur = &outs[k0 + m - 1];
   }
   hipError_t err = hipGetLastError();

@@ -23,7 +23,7 @@ def allreduce_stats(stats16, device):
     a device tensor; returns a tensor on `device` (nothing blocks the host)."""
     t = stats16 if torch.is_tensor(stats16) else torch.as_tensor(np.asarray(stats16, dtype=np.float64))
     t = t.to(device)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return t
     s, mn, mx = t[_SUM].clone(), t[_MIN].clone(), t[_MAX].clone()
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
@@ -45,7 +45,7 @@ def gather_readout(X, Y, opl, alive, dst=0, pack=None, sizes=None, async_op=Fals
     is returned: the caller overlaps them with further kernels and calls `.wait()` on each handle before it
     touches the pack's buffers again (the result then sits in pack['recv'] / pack['arecv'] on dst)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return torch.stack([X, Y, opl]), alive
     rank = dist.get_rank()
     n = X.numel()

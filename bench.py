@@ -105,13 +105,25 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=500_000, help="rays of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
+    # the contract is ONE JSON line on stdout: route everything libraries print there (RCCL prints a version banner
+    # on first use) to stderr until the result line is written
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
-    if world > 1:
+    # ART_FORCE_DIST=1 runs the multi-rank code path (process group, all-reduce, gather) even with one rank: a way to
+    # exercise the RCCL calls on a single-GPU box
+    use_dist = world > 1 or os.environ.get("ART_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(os.environ.get("ART_DIST_BACKEND", "nccl"), rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
     if world != args.gpus and rank == 0:
         log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
 
@@ -137,7 +149,7 @@ def main():
     del out
 
     packs, works = [], [None, None]
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         # double-buffered gather buffers: the gather of step i (RCCL, its own stream) overlaps the tracing of
         # step i+1; a buffer is reused only after the gather that read it has been waited for
@@ -154,7 +166,7 @@ def main():
         # nothing in a step blocks the host: launches queue up like the steps of a training loop
         o = mp.RayTracingCalculation(src, els, mode=mode)
         r = det.readout(o[-1], sync=False)
-        if world > 1:
+        if use_dist:
             r["stats_dev"] = sharding.allreduce_stats(r["stats_dev"], be.device)
             b = step_no[0] % 2
             step_no[0] += 1
@@ -175,7 +187,7 @@ def main():
     for _ in range(args.warmup):
         step()
     drain()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     be.trace_events = []          # HIP events bracketing every trace launch, on the launch stream
@@ -185,10 +197,10 @@ def main():
     t_enq = time.perf_counter() - t0   # host time to enqueue all steps (diagnostic: host-bound if ~ dt)
     drain()                       # every gather has landed on rank 0 before the clock stops
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=be.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -215,7 +227,7 @@ def main():
                                    f"(f=600 mm, 80 deg, 200x30 mm) -> detector; {n} rays/GPU x {args.mirrors} mirrors "
                                    f"= {inter_per_step_rank} intersections/GPU/step; full per-element history",
                        "rays_per_gpu": n, "mirrors": args.mirrors, "trace_mode": mode,
-                       "step": "RayTracingCalculation + Detector.readout" + (" + RCCL gather to rank 0" if world > 1 else "")},
+                       "step": "RayTracingCalculation + Detector.readout" + (" + stats all-reduce + RCCL gather to rank 0 (overlapped)" if use_dist else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None if tr is None else tr[0],
                          "traffic_source": None if tr is None else tr[1] + " (rocprofv3 PMC, bytes per launch)",
@@ -231,8 +243,11 @@ def main():
                                    "sample": f"oracle/art_oracle.py (NumPy, batched LAPACK eigvals; single thread) on "
                                              f"{args.cpu_sample} rays x {args.mirrors} mirrors + detector = {inter} "
                                              f"intersections in {secs:.1f} s; host has {os.cpu_count()} cores"}
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(res), flush=True)
-    if world > 1:
+        os.dup2(2, 1)
+    if use_dist:
         dist.destroy_process_group()
 
 
