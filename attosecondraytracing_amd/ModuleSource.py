@@ -1,8 +1,8 @@
 """Ray sources, API of ART/ModuleSource.py.  Every function returns a device-resident RayBundle.
 
 Point sources and plane-wave disks are generated on the GPU from the ray index (Vogel spiral,
-`art_make_source`).  ExtendedSource and the Gaussian intensity weights are (vectorised) host NumPy for now --
-they are scene construction, not the tracing path."""
+`art_make_source`) and so are the Gaussian intensity weights (`art_gaussian_intensity`: max-angle reduction +
+weights, nothing returns to the host).  ExtendedSource is (vectorised) host NumPy, then uploaded."""
 import numpy as np
 import torch
 
@@ -64,17 +64,6 @@ def ApplyGaussianIntensityToRayList(RayList, IntensityFraction=1 / np.e ** 2):
     from . import ModuleProcessing as mp
     B = RayList if isinstance(RayList, RayBundle) else RayBundle.from_ray_list(RayList)
     axis = mp.FindCentralRay(B).vector
-    V = B.data[3:6].cpu().numpy().T
-    a = np.linalg.norm(V - axis[None, :], axis=1)
-    b = np.linalg.norm(V + axis[None, :], axis=1)
-    ang = 2 * np.arctan2(a, b)
-    div = float(np.max(ang)) if len(ang) else 0.0
-    k = -0.5 * np.log(IntensityFraction)
-    if div > 1e-12:
-        inten = np.exp(-2 * (np.tan(ang) / div) ** 2 * k)
-    else:
-        d = np.linalg.norm(B.data[0:3].cpu().numpy().T, axis=1)
-        inten = np.exp(-2 * (d / np.max(d)) ** 2 * k)
-    B.intensity = B.backend.from_numpy(inten)
+    B.intensity = B.backend.gaussian_intensity(B.view(), axis, IntensityFraction, B.n_slots)
     B.touch()
     return B

@@ -139,6 +139,14 @@ class HipBackend:
                    "art_bundle_sums")
         return out.cpu().numpy()
 
+    def gaussian_intensity(self, view, axis, fraction, n):
+        w = self.empty(n)
+        a = (C.c_double * 3)(*[float(v) for v in axis])
+        self.check(self.fn["art_gaussian_intensity"](C.byref(view), a, float(fraction), n,
+                                                     self._red_scratch().data_ptr(), w.data_ptr(), self.stream_ptr()),
+                   "art_gaussian_intensity")
+        return w
+
     def compact(self, alive, n):
         """Returns (idx tensor int64 [count], count)."""
         ints = self.fn["art_compact_scratch_ints"](n)

@@ -26,10 +26,39 @@ class RayBundle:
         self.intensity = intensity    # torch float64 [n] or None
         self.wavelength = wavelength  # float or None (uniform, as every reference source produces)
         self.parent = parent          # bundle this one was traced from (for Ray.path tuples)
-        self.backend = backend or _lib.get_backend()
+        self._backend = backend or _lib.get_backend()
         self._index = None
         self._count = None
         self.version = 0              # bumped when the arrays are modified in place
+
+    # ------------------------------------------------------------------ backend / persistence
+    @property
+    def backend(self):
+        """The compute backend; a bundle restored from an archive is moved to the device on first use."""
+        if self._backend is None:
+            be = _lib.get_backend()
+            self.data = self.data.to(be.device)
+            self.alive = self.alive.to(be.device)
+            self.number = None if self.number is None else self.number.to(be.device)
+            self.intensity = None if self.intensity is None else self.intensity.to(be.device)
+            self._backend = be
+        return self._backend
+
+    def __getstate__(self):
+        """Archive form (mp.save_compressed, ART/ModuleProcessing.py:612-625): plain host arrays."""
+        host = lambda t: None if t is None else t.detach().cpu().numpy()
+        return {"data": host(self.data), "alive": host(self.alive), "number": host(self.number),
+                "intensity": host(self.intensity), "wavelength": self.wavelength, "parent": self.parent,
+                "version": self.version}
+
+    def __setstate__(self, st):
+        t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a))
+        self.data, self.alive = t(st["data"]), t(st["alive"])
+        self.number, self.intensity = t(st["number"]), t(st["intensity"])
+        self.wavelength, self.parent, self.version = st["wavelength"], st["parent"], st["version"]
+        self._backend = None
+        self._index = None
+        self._count = None
 
     # ------------------------------------------------------------------ construction
     @classmethod

@@ -6,6 +6,7 @@
 // ballot on the torus Newton loop.  No MFMA: the path is streaming fp64 VALU work against HBM.
 #include <hip/hip_runtime.h>
 
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -324,6 +325,55 @@ __global__ __launch_bounds__(kBlock) void k_sums_final(const double* scratch, co
   block_reduce_store<kSumSlots>(acc, ops, out);
 }
 
+// ------------------------------------------------------------------------------------------- source weights
+struct Axis3 { double x, y, z; };
+
+__device__ __forceinline__ double angle_to_axis(const Axis3 ax, double vx, double vy, double vz) {
+  // AngleBetweenTwoVectors(Axis, vector), ART/ModuleGeometry.py:40-44, with the norms as the reference applies them
+  const double u = sqrt(art::dot3(ax.x, ax.y, ax.z, ax.x, ax.y, ax.z)), v = sqrt(art::dot3(vx, vy, vz, vx, vy, vz));
+  const double ax_ = ax.x * v - vx * u, ay_ = ax.y * v - vy * u, az_ = ax.z * v - vz * u;
+  const double bx_ = ax.x * v + vx * u, by_ = ax.y * v + vy * u, bz_ = ax.z * v + vz * u;
+  return 2.0 * atan2(sqrt(art::dot3(ax_, ay_, az_, ax_, ay_, az_)), sqrt(art::dot3(bx_, by_, bz_, bx_, by_, bz_)));
+}
+
+__global__ __launch_bounds__(kBlock) void k_gauss_max_partial(const ArtBundleView b, const Axis3 ax, const int64_t n,
+                                                              double* scratch) {
+  const int ops[kSumSlots] = {RMAX, RMAX, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM};
+  double acc[kSumSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    if (b.alive[i] == 0) continue;
+    acc[0] = fmax(acc[0], angle_to_axis(ax, b.dx[i], b.dy[i], b.dz[i]));
+    acc[1] = fmax(acc[1], sqrt(art::dot3(b.ox[i], b.oy[i], b.oz[i], b.ox[i], b.oy[i], b.oz[i])));
+  }
+  block_reduce_store<kSumSlots>(acc, ops, scratch + (int64_t)blockIdx.x * kSumSlots);
+}
+
+__global__ __launch_bounds__(kBlock) void k_gauss_max_final(const double* scratch, const int nblocks, double* out) {
+  const int ops[kSumSlots] = {RMAX, RMAX, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM};
+  double acc[kSumSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int blk = threadIdx.x; blk < nblocks; blk += kBlock) {
+    acc[0] = fmax(acc[0], scratch[(int64_t)blk * kSumSlots + 0]);
+    acc[1] = fmax(acc[1], scratch[(int64_t)blk * kSumSlots + 1]);
+  }
+  block_reduce_store<kSumSlots>(acc, ops, out);
+}
+
+__global__ __launch_bounds__(kBlock) void k_gauss_weights(const ArtBundleView b, const Axis3 ax, const double kexp,
+                                                          const double* maxima, const int64_t n, double* w) {
+  const double div = maxima[0], maxdist = maxima[1];
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    double q;
+    if (div > 1e-12) {   // diverging bundle: profile in angle (ModuleSource.py:247-251)
+      q = tan(angle_to_axis(ax, b.dx[i], b.dy[i], b.dz[i])) / div;
+    } else {             // collimated: profile in distance from the origin (:252-259)
+      q = sqrt(art::dot3(b.ox[i], b.oy[i], b.oz[i], b.ox[i], b.oy[i], b.oz[i])) / maxdist;
+    }
+    w[i] = exp(-2.0 * q * q * kexp);
+  }
+}
+
 // ------------------------------------------------------------------------------------------- compaction
 // Stable stream compaction of the alive mask in three passes: per-tile counts, exclusive scan of the tile
 // counts by one workgroup, scatter with an intra-wave ballot/popcount rank.
@@ -583,6 +633,27 @@ int art_bundle_sums(const ArtBundleView* bv, const double* w, int64_t n, double*
   hipLaunchKernelGGL(k_sums_final, dim3(1), dim3(kBlock), 0, s, scratch, nb, out8);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_bundle_sums launch");
+  return ART_OK;
+}
+
+int art_gaussian_intensity(const ArtBundleView* bv, const double axis[3], double fraction, int64_t n, double* scratch,
+                           double* w_out, void* stream) {
+  if (!view_ok(bv) || !axis || !scratch || !w_out) return fail(ART_ERR_BAD_ARG, "NULL argument");
+  if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
+  if (!(fraction > 0.0 && fraction < 1.0)) return fail(ART_ERR_BAD_ARG, "fraction must be in (0, 1)");
+  if (n == 0) return ART_OK;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t b = (n + kBlock - 1) / kBlock;
+  const int nb = (int)(b < 1 ? 1 : (b > kRedBlocks ? kRedBlocks : b));
+  const Axis3 ax = {axis[0], axis[1], axis[2]};
+  // partials in scratch[0 .. nb*8), the two maxima right behind them
+  double* maxima = scratch + (int64_t)kRedBlocks * kSumSlots;
+  hipLaunchKernelGGL(k_gauss_max_partial, dim3(nb), dim3(kBlock), 0, s, *bv, ax, n, scratch);
+  hipLaunchKernelGGL(k_gauss_max_final, dim3(1), dim3(kBlock), 0, s, scratch, nb, maxima);
+  hipLaunchKernelGGL(k_gauss_weights, dim3(grid_for(n)), dim3(kBlock), 0, s, *bv, ax, -0.5 * log(fraction), maxima, n,
+                     w_out);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail_hip(err, "art_gaussian_intensity launch");
   return ART_OK;
 }
 

@@ -174,6 +174,13 @@ int art_detector_moments(const uint8_t* alive, const double* X, const double* Y,
 int art_bundle_sums(const ArtBundleView* b, const double* w, int64_t n, double* scratch, double* out8,
                     void* stream);
 
+/* Gaussian intensity weights of a source bundle (ApplyGaussianIntensityToRayList, ART/ModuleSource.py:219-261):
+ * w = 1 on the axis falling to `fraction` at the edge -- in angle (tan(angle)/max angle) for diverging bundles
+ * (max angle to `axis` > 1e-12), in distance from the origin (|point| / max |point|) for collimated ones.
+ * Two passes on the stream (max reduction, then weights); nothing returns to the host.  w_out: DEVICE, n doubles. */
+int art_gaussian_intensity(const ArtBundleView* b, const double axis[3], double fraction, int64_t n,
+                           double* scratch, double* w_out, void* stream);
+
 /* Stable compaction: idx_out[j] = slot of the j-th alive ray (source order kept, as the reference's
  * survivor lists ModuleMirror.py:928-939), *count_out = number alive.  block_counts: DEVICE scratch of
  * art_compact_scratch_ints(n) int32.                                                                    */

@@ -212,3 +212,45 @@ def test_gpu_error_paths(hip):
 def test_gpu_smoke_entry(hip):
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_gpu_oeplacement_and_sources_match_reference(hip):
+    """Scene construction end to end on the GPU (device-generated sources + device Gaussian weights + 1-ray
+    alignment traces) against the reference's poses and source bundles."""
+    import ART.ModuleProcessing as mp
+    for name in ("c1_singleparabola", "c2_fxf_chain05", "c3_twisted_chain09", "c4_mixed8", "c5_zernike_withdefects"):
+        scene, a = load_golden(name)
+        pl = scene.get("placement") or scene.get("placement_before_roll")
+        optics = [pc.build_optic(e, a) for e in scene["elements"]]
+        SP = dict(pl["SourceProperties"])
+        SP["NumberRays"] = int(SP["NumberRays"])
+        chain = mp.OEPlacement(SP, optics, list(pl["DistanceList"]), list(pl["IncidenceAngleList"]),
+                               list(pl["IncidencePlaneAngleList"]), "t")
+        if "placement" in scene:
+            for oe, e in zip(chain.optical_elements, scene["elements"]):
+                scale = max(1.0, np.abs(np.array(e["position"])).max())
+                assert np.abs(np.asarray(oe.position, float) - e["position"]).max() <= 1e-10 * scale
+                assert np.abs(oe.normal - e["normal"]).max() <= 1e-10
+                assert np.abs(oe.majoraxis - e["majoraxis"]).max() <= 1e-10
+        src = chain.source_rays
+        assert np.array_equal(src.numbers(), a["src_number"])
+        assert np.abs(src.points() - a["src_point"]).max() <= 1e-10 * max(1.0, np.abs(a["src_point"]).max())
+        assert np.abs(src.vectors() - a["src_vector"]).max() <= 1e-12
+        assert np.abs(src.intensities() - a["src_intensity"]).max() <= 1e-10
+
+
+def test_gpu_autofocus_matches_reference(hip):
+    import ART.ModuleProcessing as mp
+    import ART.ModuleDetector as mdet
+    scene, a = load_golden("autofocus_c3")
+    els = pc.build_elements(scene, a)
+    last = mp.RayTracingCalculation(pc.source_bundle(a, scene), els)[-1]
+    d = scene["detector"]
+    det = mdet.Detector(np.array(d["refpoint"]), np.array(d["centre"]), np.array(d["normal"]))
+    for key, (dist, spot, dur) in scene["autofocus"].items():
+        optfor, weighted = key.rsplit("_", 1)
+        D, s, t = mp.FindOptimalDistance(det, last, optfor, None, 3, bool(int(weighted)), False)
+        assert abs(D.get_distance() - dist) <= 1e-9 * dist, key
+        if not np.isnan(spot):
+            assert abs(s - spot) <= 1e-9 * max(spot, 1e-3), key
+        assert abs(t - dur) <= 1e-7 * max(dur, 1e-3), key

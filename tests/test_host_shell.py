@@ -209,3 +209,23 @@ def test_zernike_polynomial_tables_match_recurrences():
     assert np.abs(ev(A) - a["defect_offset"]).max() <= 1e-15
     assert np.abs(-ev(GX) / R - a["defect_normal"][:, 0]).max() <= 1e-15
     assert np.abs(-ev(GY) / R - a["defect_normal"][:, 1]).max() <= 1e-15
+
+
+def test_save_and_load_results(twin, tmp_path, monkeypatch):
+    """save_compressed / load_compressed (ART/ModuleProcessing.py:612-633) round-trip a kept_data dictionary with
+    device-resident bundles: archived as host arrays, usable again after loading."""
+    import ART.ModuleProcessing as mp
+    import ART.ModuleOpticalChain as moc
+    monkeypatch.chdir(tmp_path)
+    scene, a = load_golden("c2_fxf_chain05")
+    chain = moc.OpticalChain(pc.source_bundle(a, scene), pc.build_elements(scene, a), "archive me")
+    out = chain.get_output_rays()
+    mp.save_compressed({"OpticalChain": [chain], "x": 1.5}, "kept")
+    back = mp.load_compressed("kept_0")
+    ch = back["OpticalChain"][0]
+    assert back["x"] == 1.5 and ch.description == "archive me"
+    o2 = ch._output_rays
+    assert len(o2[-1]) == len(out[-1]) == 490
+    assert np.array_equal(o2[-1].points(), out[-1].points())
+    assert np.array_equal(o2[-1].path_segments(), out[-1].path_segments())
+    assert [r.number for r in o2[-1][:3]] == [r.number for r in out[-1][:3]]

@@ -110,6 +110,24 @@ class TwinBackend:
         out[7] = w.numpy()[a].sum() if w is not None else 0.0
         return out
 
+    def gaussian_intensity(self, view, axis, fraction, n):
+        def arr(ptr, ty=C.c_double):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ty)), shape=(n,))
+        a = arr(view.alive, C.c_uint8).astype(bool)
+        V = np.stack([arr(view.dx), arr(view.dy), arr(view.dz)], axis=1)
+        P = np.stack([arr(view.ox), arr(view.oy), arr(view.oz)], axis=1)
+        axis = np.asarray(axis, float)
+        u, v = np.linalg.norm(axis), np.linalg.norm(V, axis=1)[:, None]
+        ang = 2 * np.arctan2(np.linalg.norm(axis[None, :] * v - V * u, axis=1), np.linalg.norm(axis[None, :] * v + V * u, axis=1))
+        div = ang[a].max() if a.any() else 0.0
+        k = -0.5 * np.log(fraction)
+        if div > 1e-12:
+            w = np.exp(-2 * (np.tan(ang) / div) ** 2 * k)
+        else:
+            d = np.linalg.norm(P, axis=1)
+            w = np.exp(-2 * (d / d[a].max()) ** 2 * k)
+        return torch.from_numpy(w)
+
     def compact(self, alive, n):
         idx = torch.nonzero(alive, as_tuple=False).reshape(-1)
         return idx, int(idx.numel())
