@@ -117,6 +117,9 @@ class HipBackend:
         return self.scratch("red", self.fn["art_reduce_scratch_doubles"](), torch.float64)
 
     def detector_stats(self, alive, X, Y, opl, w, n, to_host=True):
+        if n == 0:
+            out = self.zeros(16)
+            return out.cpu().numpy() if to_host else out
         out = self.empty(16)
         ptr = lambda t: None if t is None else t.data_ptr()
         self.check(self.fn["art_detector_stats"](alive.data_ptr(), ptr(X), ptr(Y), ptr(opl), ptr(w), n,
@@ -125,6 +128,8 @@ class HipBackend:
         return out.cpu().numpy() if to_host else out
 
     def detector_moments(self, alive, X, Y, opl, w, n, cx, cy, co):
+        if n == 0:
+            return np.zeros(8)
         out = self.empty(8)
         ptr = lambda t: None if t is None else t.data_ptr()
         self.check(self.fn["art_detector_moments"](alive.data_ptr(), ptr(X), ptr(Y), ptr(opl), ptr(w), n,
@@ -133,6 +138,8 @@ class HipBackend:
         return out.cpu().numpy()
 
     def bundle_sums(self, view, w, n):
+        if n == 0:
+            return np.zeros(8)
         out = self.empty(8)
         self.check(self.fn["art_bundle_sums"](C.byref(view), None if w is None else w.data_ptr(), n,
                                               self._red_scratch().data_ptr(), out.data_ptr(), self.stream_ptr()),
@@ -149,6 +156,8 @@ class HipBackend:
 
     def compact(self, alive, n):
         """Returns (idx tensor int64 [count], count)."""
+        if n == 0:
+            return torch.empty(0, dtype=torch.int64, device=self.device), 0
         ints = self.fn["art_compact_scratch_ints"](n)
         sc = self.scratch("compact", ints, torch.int32)
         idx = torch.empty(int(max(n, 1)), dtype=torch.int64, device=self.device)

@@ -42,9 +42,10 @@ inline int grid_for(int64_t n) {
 // in a 32-bit VGPR.  The hardware range check gives branch-free predication: a lane whose offset is out of range
 // loads 0 / stores nothing.  That is what lets dead rays skip their 8 output stores WITHOUT a branch around the
 // stores -- a branch would make the compiler drain every outstanding store (s_waitcnt vmcnt(0)) at the join and
-// undo the software pipelining below.  One launch covers at most kMaxRaysPerLaunch rays (32-bit byte offsets).
+// undo the software pipelining below.  One launch covers at most 2^28 rays (32-bit byte offsets); the C ABI splits
+// larger bundles into several launches.
 typedef int v2i32 __attribute__((ext_vector_type(2)));
-constexpr int64_t kMaxRaysPerLaunch = (int64_t)1 << 28;  // 2^28 rays * 8 B = 2 GiB per stream
+constexpr int64_t kMaxRaysPerLaunchHw = (int64_t)1 << 28;  // 2^28 rays * 8 B = 2 GiB per stream
 constexpr unsigned kDropOffset = 0xFFFFFFFFu;
 
 struct BundleRsrc {
@@ -456,6 +457,25 @@ __global__ __launch_bounds__(kBlock) void k_make_source(const int32_t kind, cons
   }
 }
 
+// rays per launch: the hardware limit, or less when ART_MAX_RAYS_PER_LAUNCH is set (lets tests cover the chunking)
+int64_t max_rays_per_launch() {
+  const char* v = getenv("ART_MAX_RAYS_PER_LAUNCH");
+  if (v) {
+    const long long x = atoll(v);
+    if (x >= 64 && x < kMaxRaysPerLaunchHw) return (int64_t)x;
+  }
+  return kMaxRaysPerLaunchHw;
+}
+
+// slot-offset copy of a view (launch chunking: one launch addresses at most max_rays_per_launch() slots)
+ArtBundleView view_at(const ArtBundleView& v, int64_t off) {
+  ArtBundleView r = v;
+  if (v.alive == nullptr) return r;  // absent history view stays absent
+  r.ox += off; r.oy += off; r.oz += off; r.dx += off; r.dy += off; r.dz += off;
+  r.path += off; r.incidence += off; r.alive += off;
+  return r;
+}
+
 bool view_ok(const ArtBundleView* v) {
   return v && v->ox && v->oy && v->oz && v->dx && v->dy && v->dz && v->path && v->incidence && v->alive;
 }
@@ -511,18 +531,23 @@ int art_trace_element(const ArtElementDesc* e, const ArtBundleView* in, const Ar
                       void* stream) {
   int rc = check_elem(e);
   if (rc) return rc;
-  if (!view_ok(in) || !view_ok(out)) return fail(ART_ERR_BAD_ARG, "bundle view has a NULL array");
   if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
-  if (n == 0) return ART_OK;
+  if (n == 0) return ART_OK;  // an empty bundle has no arrays to point to
+  if (!view_ok(in) || !view_ok(out)) return fail(ART_ERR_BAD_ARG, "bundle view has a NULL array");
   hipStream_t s = (hipStream_t)stream;
-  switch (e->kind) {
-    case ART_PLANE: launch_element<ART_PLANE>(*e, *in, *out, n, s); break;
-    case ART_SPHERE: launch_element<ART_SPHERE>(*e, *in, *out, n, s); break;
-    case ART_PARABOLA: launch_element<ART_PARABOLA>(*e, *in, *out, n, s); break;
-    case ART_TORUS: launch_element<ART_TORUS>(*e, *in, *out, n, s); break;
-    case ART_ELLIPSOID: launch_element<ART_ELLIPSOID>(*e, *in, *out, n, s); break;
-    case ART_CYLINDER: launch_element<ART_CYLINDER>(*e, *in, *out, n, s); break;
-    default: launch_element<ART_MASK>(*e, *in, *out, n, s); break;
+  const int64_t chunk = max_rays_per_launch();
+  for (int64_t off = 0; off < n; off += chunk) {
+    const int64_t m = (n - off < chunk) ? n - off : chunk;
+    const ArtBundleView vi = view_at(*in, off), vo = view_at(*out, off);
+    switch (e->kind) {
+      case ART_PLANE: launch_element<ART_PLANE>(*e, vi, vo, m, s); break;
+      case ART_SPHERE: launch_element<ART_SPHERE>(*e, vi, vo, m, s); break;
+      case ART_PARABOLA: launch_element<ART_PARABOLA>(*e, vi, vo, m, s); break;
+      case ART_TORUS: launch_element<ART_TORUS>(*e, vi, vo, m, s); break;
+      case ART_ELLIPSOID: launch_element<ART_ELLIPSOID>(*e, vi, vo, m, s); break;
+      case ART_CYLINDER: launch_element<ART_CYLINDER>(*e, vi, vo, m, s); break;
+      default: launch_element<ART_MASK>(*e, vi, vo, m, s); break;
+    }
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_trace_element launch");
@@ -532,46 +557,53 @@ int art_trace_element(const ArtElementDesc* e, const ArtBundleView* in, const Ar
 int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundleView* in, const ArtBundleView* outs,
                     int64_t n, void* stream) {
   if (!elems || !outs || n_elems <= 0) return fail(ART_ERR_BAD_ARG, "empty chain");
-  if (!view_ok(in)) return fail(ART_ERR_BAD_ARG, "input bundle view has a NULL array");
   if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
   for (int k = 0; k < n_elems; ++k) {
     int rc = check_elem(&elems[k]);
     if (rc) return rc;
-    if (outs[k].alive != nullptr && !view_ok(&outs[k])) return fail(ART_ERR_BAD_ARG, "history view partially NULL");
   }
+  if (n == 0) return ART_OK;  // an empty bundle has no arrays to point to
+  if (!view_ok(in)) return fail(ART_ERR_BAD_ARG, "input bundle view has a NULL array");
+  for (int k = 0; k < n_elems; ++k)
+    if (outs[k].alive != nullptr && !view_ok(&outs[k])) return fail(ART_ERR_BAD_ARG, "history view partially NULL");
   if (!view_ok(&outs[n_elems - 1])) return fail(ART_ERR_BAD_ARG, "the last output view is mandatory");
-  if (n == 0) return ART_OK;
   hipStream_t s = (hipStream_t)stream;
-  const ArtBundleView* cur = in;
   for (int k0 = 0; k0 < n_elems; k0 += kChainMax) {
-    ChainArgs a;
-    memset(&a, 0, sizeof(a));
-    bool any_defect = false;
     const int m = (n_elems - k0 < kChainMax) ? n_elems - k0 : kChainMax;
-    a.n_elems = m;
-    for (int k = 0; k < m; ++k) {
-      a.e[k] = elems[k0 + k];
-      a.out[k] = outs[k0 + k];
-      a.zoff[k] = a.zern_doubles;
-      a.zern_doubles += a.e[k].n_defects * ART_ZERN_STRIDE;
-      if (a.e[k].n_defects > 0 || a.e[k].n_grid > 0) any_defect = true;
-    }
     // the chunk's last bundle is the next chunk's input: it must exist
-    if (!view_ok(&a.out[m - 1])) return fail(ART_ERR_BAD_ARG, "chains longer than 8 need a view every 8th element");
-    const char* wv = getenv("ART_CHAIN_WAVES");   // tuning knob: register budget of the fused kernel (waves per SIMD)
-    const int waves = wv ? atoi(wv) : 4;
-    const dim3 g(grid_for(n)), b(kBlock);
-    if (any_defect)
-      hipLaunchKernelGGL((k_trace_chain<true, 4>), g, b, (size_t)a.zern_doubles * sizeof(double), s, a, *cur, n);
-    else if (waves == 5)
-      hipLaunchKernelGGL((k_trace_chain<false, 5>), g, b, 0, s, a, *cur, n);
-    else if (waves == 6)
-      hipLaunchKernelGGL((k_trace_chain<false, 6>), g, b, 0, s, a, *cur, n);
-    else if (waves == 3)
-      hipLaunchKernelGGL((k_trace_chain<false, 3>), g, b, 0, s, a, *cur, n);
-    else
-      hipLaunchKernelGGL((k_trace_chain<false, 4>), g, b, 0, s, a, *cur, n);
-    cur = &outs[k0 + m - 1];
+    if (!view_ok(&outs[k0 + m - 1])) return fail(ART_ERR_BAD_ARG, "chains longer than 8 need a view every 8th element");
+  }
+  const char* wv = getenv("ART_CHAIN_WAVES");   // tuning knob: register budget of the fused kernel (waves per SIMD)
+  const int waves = wv ? atoi(wv) : 4;
+  const int64_t chunk = max_rays_per_launch();
+  for (int64_t off = 0; off < n; off += chunk) {
+    const int64_t cnt = (n - off < chunk) ? n - off : chunk;
+    ArtBundleView cur = view_at(*in, off);
+    for (int k0 = 0; k0 < n_elems; k0 += kChainMax) {
+      ChainArgs a;
+      memset(&a, 0, sizeof(a));
+      bool any_defect = false;
+      const int m = (n_elems - k0 < kChainMax) ? n_elems - k0 : kChainMax;
+      a.n_elems = m;
+      for (int k = 0; k < m; ++k) {
+        a.e[k] = elems[k0 + k];
+        a.out[k] = view_at(outs[k0 + k], off);
+        a.zoff[k] = a.zern_doubles;
+        a.zern_doubles += a.e[k].n_defects * ART_ZERN_STRIDE;
+        if (a.e[k].n_defects > 0 || a.e[k].n_grid > 0) any_defect = true;
+      }
+      if ((size_t)a.zern_doubles * sizeof(double) > 64 * 1024)
+        return fail(ART_ERR_UNSUPPORTED, "Zernike tables of one fused launch exceed 64 KiB of LDS: trace this chain "
+                                         "element by element (art_trace_element)");
+      const dim3 g(grid_for(cnt)), b(kBlock);
+      if (any_defect)
+        hipLaunchKernelGGL((k_trace_chain<true, 4>), g, b, (size_t)a.zern_doubles * sizeof(double), s, a, cur, cnt);
+      else if (waves == 3)
+        hipLaunchKernelGGL((k_trace_chain<false, 3>), g, b, 0, s, a, cur, cnt);
+      else
+        hipLaunchKernelGGL((k_trace_chain<false, 4>), g, b, 0, s, a, cur, cnt);
+      cur = a.out[m - 1];
+    }
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_trace_chain launch");
@@ -581,6 +613,7 @@ int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundl
 int art_detector(const ArtDetectorDesc* d, const ArtBundleView* b, int64_t n, double* p3x, double* p3y, double* p3z,
                  double* X, double* Y, double* opl, void* stream) {
   if (!d) return fail(ART_ERR_BAD_ARG, "detector descriptor is NULL");
+  if (n == 0) return ART_OK;
   if (!view_ok(b)) return fail(ART_ERR_BAD_ARG, "bundle view has a NULL array");
   if ((p3x || p3y || p3z) && !(p3x && p3y && p3z)) return fail(ART_ERR_BAD_ARG, "p3x/p3y/p3z must be all set or all NULL");
   if ((X || Y) && !(X && Y)) return fail(ART_ERR_BAD_ARG, "X/Y must be both set or both NULL");

@@ -1,0 +1,91 @@
+"""Edge cases shared by the CPU-twin and GPU suites: empty and tiny bundles, sizes around the wave width, all-miss,
+in-place tracing, non-finite inputs, rays parallel to a plane, launch chunking."""
+import numpy as np
+
+import ART.ModuleMirror as mmirror
+import ART.ModuleMask as mmask
+import ART.ModuleOpticalElement as moe
+import ART.ModuleProcessing as mp
+import ART.ModuleSupport as msupp
+from attosecondraytracing_amd.bundle import RayBundle
+
+
+def _plane_element(radius=10.0):
+    return moe.OpticalElement(mmirror.MirrorPlane(msupp.SupportRound(radius)), np.array([0.0, 0.0, 50.0]),
+                              np.array([0.0, 0.0, -1.0]), np.array([1.0, 0.0, 0.0]))
+
+
+def _bundle(n, seed=0):
+    rng = np.random.default_rng(seed)
+    p = np.stack([rng.uniform(-5, 5, n), rng.uniform(-5, 5, n), np.zeros(n)], axis=1)
+    v = np.stack([rng.normal(0, 0.02, n), rng.normal(0, 0.02, n), np.ones(n)], axis=1)
+    return RayBundle.from_arrays(p, v, np.arange(n), np.ones(n), 800e-6)
+
+
+def run_edge_cases():
+    oe = _plane_element()
+    for mode in ("chain", "element"):
+        # empty bundle
+        out = mp.RayTracingCalculation(_bundle(0), [oe, oe], mode=mode)
+        assert [len(o) for o in out] == [0, 0] and out[-1].points().shape == (0, 3)
+        # sizes around the 64-lane wave and the 256-thread workgroup
+        for n in (1, 2, 63, 64, 65, 255, 256, 257, 1000):
+            b = _bundle(n, n)
+            out = mp.RayTracingCalculation(b, [oe], mode=mode)
+            assert len(out[0]) == n
+            P = out[0].points()
+            assert np.abs(P[:, 2] - 50.0).max() <= 1e-12
+            t = 50.0 / b.vectors()[:, 2]
+            assert np.abs(out[0].paths_total() - t).max() <= 1e-11
+            assert np.abs(out[0].vectors()[:, 2] + b.vectors()[:, 2]).max() <= 1e-14   # mirrored z component
+        # everything misses (mirror behind the rays): empty survivor lists down the chain, no crash
+        behind = moe.OpticalElement(mmirror.MirrorPlane(msupp.SupportRound(10)), np.array([0.0, 0.0, -50.0]),
+                                    np.array([0.0, 0.0, 1.0]), np.array([1.0, 0.0, 0.0]))
+        out = mp.RayTracingCalculation(_bundle(300), [behind, oe], mode=mode)
+        assert [len(o) for o in out] == [0, 0]
+        # a fully closed mask (support covers everything)
+        wall = moe.OpticalElement(mmask.Mask(msupp.SupportRound(1e6)), np.array([0.0, 0.0, 10.0]),
+                                  np.array([0.0, 0.0, -1.0]), np.array([1.0, 0.0, 0.0]))
+        assert [len(o) for o in mp.RayTracingCalculation(_bundle(300), [wall, oe], mode=mode)] == [0, 0]
+    # non-finite inputs and rays parallel to the mirror plane are dropped, finite neighbours unaffected
+    n = 130
+    b = _bundle(n, 5)
+    host = b.data.cpu().numpy().copy()
+    host[0, 3] = np.nan          # NaN origin
+    host[5, 7] = np.inf          # infinite direction component
+    host[3:6, 11] = [1.0, 0.0, 0.0]   # parallel to the mirror: t = -z/0
+    ref = mp.RayTracingCalculation(_bundle(n, 5), [oe], mode="element")[0]
+    b2 = RayBundle.from_arrays(host[0:3].T, np.nan_to_num(host[3:6].T, nan=1.0, posinf=1.0), np.arange(n), np.ones(n))
+    b2.data[:] = b.backend.from_numpy(host)
+    out = mp.RayTracingCalculation(b2, [oe], mode="element")[0]
+    nums = set(out.numbers().tolist())
+    assert 3 not in nums and 7 not in nums and 11 not in nums
+    keep = [i for i in range(n) if i not in (3, 7, 11)]
+    assert out.numbers().tolist() == keep
+    assert np.array_equal(out.points(), ref.points()[keep])
+    # in-place single-element trace through the C ABI (in == out): same result as out-of-place
+    from attosecondraytracing_amd import ModuleProcessing as impl
+    b = _bundle(777, 9)
+    ref = mp.RayTracingCalculation(b, [oe], mode="element")[0]
+    c = b.copy()
+    d, _ = impl.element_descriptor(oe)
+    c.backend.trace_element(d, c.view(), c.view(), c.n_slots)
+    c.touch()
+    assert np.array_equal(c.points(), ref.points()) and np.array_equal(c.alive.cpu().numpy(), ref.alive.cpu().numpy())
+
+
+def run_chunking(setenv):
+    """Bundles larger than one launch's addressing range are split by the C ABI; forced small here."""
+    oe = _plane_element(4.0)      # some rays miss the 4 mm aperture
+    R, r = mmirror.ReturnOptimalToroidalRadii(300, 75)
+    tor = moe.OpticalElement(mmirror.MirrorToroidal(R, r, msupp.SupportRectangle(400, 60)), np.array([0.0, 0.0, 50.0]),
+                             np.array([0.3, 0.0, -1.0]), np.array([1.0, 0.0, 0.3]))
+    b = _bundle(5000, 3)
+    ref = {m: mp.RayTracingCalculation(b, [tor, oe], mode=m) for m in ("chain", "element")}
+    setenv("ART_MAX_RAYS_PER_LAUNCH", "1024")
+    for m in ("chain", "element"):
+        out = mp.RayTracingCalculation(b, [tor, oe], mode=m)
+        for o, q in zip(out, ref[m]):
+            assert np.array_equal(o.alive.cpu().numpy(), q.alive.cpu().numpy())
+            assert np.array_equal(o.points(), q.points()) and np.array_equal(o.paths_total(), q.paths_total())
+        assert 0 < len(out[-1]) < 5000

@@ -254,3 +254,13 @@ def test_gpu_autofocus_matches_reference(hip):
         if not np.isnan(spot):
             assert abs(s - spot) <= 1e-9 * max(spot, 1e-3), key
         assert abs(t - dur) <= 1e-7 * max(dur, 1e-3), key
+
+
+def test_gpu_edge_cases(hip):
+    import edge_cases
+    edge_cases.run_edge_cases()
+
+
+def test_gpu_launch_chunking(hip, monkeypatch):
+    import edge_cases
+    edge_cases.run_chunking(monkeypatch.setenv)

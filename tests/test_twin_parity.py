@@ -58,3 +58,8 @@ def test_twin_detector_matches_reference(twin, name):
     assert abs(spot - scene["SpotSizeSD"]) <= 1e-9 * scale
     assert abs(dur - scene["DurationSD"]) <= 1e-10 * mean_t_fs
     assert abs(mplots.getETransmission(src, last) - scene["ETransmission"]) <= 1e-9
+
+
+def test_twin_edge_cases(twin):
+    import edge_cases
+    edge_cases.run_edge_cases()
