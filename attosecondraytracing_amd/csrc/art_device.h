@@ -296,54 +296,42 @@ ART_HD void base_normal(const ArtElementDesc& e, double x, double y, double z, d
 template <int SIDE>
 ART_HD void torus_F(double R, double r2, double x, double y, double z, double ux, double uy, double uz,
                     double& F, double& dF) {
-  const double rho2 = fma(x, x, z * z);
-  double rho = 0.0, irho = 0.0;
-  if (rho2 > 0.0) sqrt_rsqrt(rho2, rho, irho);
-  const double drho = fma(x, ux, z * uz) * irho;  // d rho / dt (0 on the axis)
-  if (SIDE < 0) {
-    const double a = rho - R;
-    if (a > 0.0) {
-      F = fma(a, a, fma(y, y, -r2));
-      dF = 2.0 * fma(a, drho, y * uy);
-    } else {  // above/below the flat disk: distance is |y|
-      F = fma(y, y, -r2);
-      dF = 2.0 * y * uy;
-    }
-  } else {
-    const double a = rho + R;
-    F = fma(a, a, fma(y, y, -r2));
-    dF = 2.0 * fma(a, drho, y * uy);
-  }
+  // branch-free: on the torus axis (rho = 0) the clamp keeps 1/rho finite and the side selection below ignores it
+  const double rho2 = fmax(fma(x, x, z * z), 1e-300);
+  double rho, irho;
+  sqrt_rsqrt(rho2, rho, irho);
+  const double drho = fma(x, ux, z * uz) * irho;  // d rho / dt
+  // SIDE < 0: distance to the disk is |y| above/below it (rho <= R) -> a = max(rho - R, 0);  SIDE > 0: a = rho + R
+  const double a = (SIDE < 0) ? fmax(rho - R, 0.0) : rho + R;
+  F = fma(a, a, fma(y, y, -r2));
+  dF = 2.0 * fma(a, drho, y * uy);
 }
 
 // Monotone Newton on the convex F from `t` towards the root on the side given by `dir`
 // (+1: start right of the exit root, move left; -1: start left of the entry root, move right).
-// Returns true and the root in t, or false when the line misses the body.
+// Returns true and the root in t, or false when the line misses the body.  The body is written with selects, not
+// branches: all lanes of a wavefront run the same few iterations and leave together through the ballot.
 template <int SIDE>
 ART_HD bool torus_newton(double R, double r2, double Ax, double Ay, double Az, double ux, double uy, double uz,
                          double dir, bool want, double& t) {
   bool active = want, found = false;
   int it = 0;
   while (ART_WAVE_ANY(active)) {
-    if (active) {
-      double F, dF;
-      torus_F<SIDE>(R, r2, fma(t, ux, Ax), fma(t, uy, Ay), fma(t, uz, Az), ux, uy, uz, F, dF);
-      if (!(dF * dir > 0.0)) {
-        // slope has the wrong sign: we are past the minimum of a convex function without having met a
-        // root on this side -> no intersection
-        active = false;
-      } else {
-        // the step may use the 1e-7-accurate hardware reciprocal: Newton corrects itself, and the LAST step
-        // (|dt| <= 1e-7 |t|) then carries an error <= 1e-7 |dt| ~ 1e-14 |t|
-        const double dt = F * rcp_seed(dF);
-        t -= dt;
-        if (fabs(dt) <= 1e-7 * (1.0 + fabs(t)) || ++it >= 60) {
-          // quadratic convergence: the step just taken leaves an error ~ dt^2 * F''/(2F') ~ 1e-14 (1+|t|)^2/(r cos)
-          found = true;
-          active = false;
-        }
-      }
-    }
+    double F, dF;
+    torus_F<SIDE>(R, r2, fma(t, ux, Ax), fma(t, uy, Ay), fma(t, uz, Az), ux, uy, uz, F, dF);
+    // slope of the wrong sign: past the minimum of a convex function without having met a root on this side
+    const bool miss = !(dF * dir > 0.0);
+    // the step may use the 1e-7-accurate hardware reciprocal: Newton corrects itself, and the LAST step
+    // (|dt| <= 1e-7 |t|) then carries an error <= 1e-7 |dt| ~ 1e-14 |t|
+    const double dt = F * rcp_seed(dF);
+    const double tn = t - dt;
+    ++it;
+    // quadratic convergence: the step just taken leaves an error ~ dt^2 * F''/(2F') ~ 1e-14 (1+|t|)^2/(r cos)
+    const bool conv = (fabs(dt) <= 1e-7 * (1.0 + fabs(tn))) || (it >= 60);
+    const bool step = active && !miss;
+    t = step ? tn : t;
+    found = found || (step && conv);
+    active = step && !conv;
   }
   return found;
 }
