@@ -12,7 +12,7 @@ import torch
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libart_hip.so")
+LIB_PATH = os.environ.get("ART_HIP_LIB", os.path.join(_HERE, "libart_hip.so"))  # override: diagnostic builds
 
 _BACKEND = None
 

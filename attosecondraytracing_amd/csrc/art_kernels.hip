@@ -85,7 +85,11 @@ __device__ __forceinline__ void load_slot(const BundleRsrc& b, int64_t i, art::R
 }
 __device__ __forceinline__ void store_slot(const BundleRsrc& b, int64_t i, const art::Ray& r, bool ok) {
   const unsigned o1 = (unsigned)i;
+#ifdef ART_DIAG_NOSTORE   // timing-only build: keep the compute, drop the 8 data stores (results are wrong)
+  const unsigned o8 = (ok && r.path == -1.2345e300) ? o1 * 8u : kDropOffset;
+#else
   const unsigned o8 = ok ? o1 * 8u : kDropOffset;  // dead rays: the range check drops the 8 stores
+#endif
   st_f64(b.ox, o8, r.ox); st_f64(b.oy, o8, r.oy); st_f64(b.oz, o8, r.oz);
   st_f64(b.dx, o8, r.dx); st_f64(b.dy, o8, r.dy); st_f64(b.dz, o8, r.dz);
   st_f64(b.path, o8, r.path);
@@ -136,7 +140,11 @@ __global__ __launch_bounds__(kBlock) void k_trace_element(const ArtElementDesc e
     uint8_t an;
     load_slot(bi, inext, rn, an);
     bool ok = a != 0;
+#ifdef ART_DIAG_NOCOMPUTE   // timing-only build: memory traffic without the intersection math (results are wrong)
+    r.path += e.mp[0];
+#else
     if (ok) ok = art::trace_ray<KIND, DEFECT>(e, zern, r);
+#endif
     store_slot(bo, i, r, ok);
     r = rn;
     a = an;
@@ -178,7 +186,11 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain(const ChainArgs a
     load_slot(bi, inext, rn, an);
     bool ok = al != 0;
     for (int k = 0; k < a.n_elems; ++k) {
+#ifdef ART_DIAG_NOCOMPUTE
+      r.path += a.e[k].mp[0];
+#else
       if (ok) ok = art::trace_ray_dyn<DEFECT>(a.e[k], s_zern + a.zoff[k], r);
+#endif
       // no history view for this element -> zero-length descriptors: every store is dropped by the range check
       store_slot(make_rsrc(a.out[k], a.out[k].alive != nullptr ? n : 0), i, r, ok);
     }
