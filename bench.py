@@ -88,9 +88,10 @@ def profiled_traffic(kernel, n, mirrors, mode):
             j = json.load(open(f))
         except Exception:
             continue
-        k = kernel.replace("ART_TORUS,", "3, ")
-        if j.get("rays_per_gpu") == n and k in j.get("per_launch", {}):
-            best = (j["per_launch"][k]["total_bytes"], os.path.relpath(f, ROOT))
+        stem = "k_trace_chain<false" if mode == "chain" else "k_trace_element<3, false"
+        hits = [k for k in j.get("per_launch", {}) if k.startswith(stem)]
+        if j.get("rays_per_gpu") == n and hits:
+            best = (j["per_launch"][hits[0]]["total_bytes"], os.path.relpath(f, ROOT))
     return best
 
 
@@ -102,7 +103,7 @@ def main():
     ap.add_argument("--rays", type=int, default=10_000_000, help="rays per GPU")
     ap.add_argument("--mirrors", type=int, default=4)
     ap.add_argument("--mode", default=None, choices=[None, "chain", "element"])
-    ap.add_argument("--cpu-sample", type=int, default=500_000, help="rays of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="rays of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
     # the contract is ONE JSON line on stdout: route everything libraries print there (RCCL prints a version banner
@@ -216,7 +217,7 @@ def main():
     achieved = ALGO_BYTES_PER_INTERSECTION * inter_per_launch / (kernel_ms * 1e-3) / 1e9
 
     if rank == 0:
-        kname = "k_trace_chain<false>" if mode == "chain" else "k_trace_element<ART_TORUS,false>"
+        kname = "k_trace_chain<false, 4>" if mode == "chain" else "k_trace_element<ART_TORUS, false>"
         tr = profiled_traffic(kname, n, args.mirrors, mode)
         value = inter_per_step_rank * world * args.steps / dt
         res = {
