@@ -55,7 +55,10 @@ class Detector:
 
     # ------------------------------------------------------------------ placement
     def copy_detector(self):
-        return Detector(self.refpoint, self.centre, self.normal)
+        c = Detector(self.refpoint, self.centre, self.normal)
+        if hasattr(self, "_path_estimate"):
+            c._path_estimate = self._path_estimate
+        return c
 
     def autoplace(self, RayList, DistanceDetector: float):
         """Normal to the central ray of RayList, DistanceDetector away from its origin (ART/ModuleDetector.py:109-137)."""
@@ -100,33 +103,47 @@ class Detector:
         d.rot[:] = cached[1]
         return d
 
-    def readout(self, RayList, points3d=False, sync=True):
-        """Device tensors of the read-out, one entry per slot of the bundle (valid where alive):
-        dict with 'X', 'Y' (detector-plane coordinates about Detector.centre, ART/ModuleDetector.py:212-234),
-        'opl' (optical path to the detector, :272-275), optionally 'P3' (3 tensors, :191-210), and 'stats'
-        (art_detector_stats: host array, or with sync=False a device tensor 'stats_dev' so that nothing blocks)."""
+    def readout(self, RayList, points3d=False, sync=True, path_centre=0.0, store=True):
+        """One fused pass on the device (art_detector_readout): per-slot tensors 'X', 'Y' (detector-plane coordinates
+        about Detector.centre, ART/ModuleDetector.py:212-234), 'opl' (optical path to the detector, :272-275),
+        optionally 'P3' (3-D hit points, :191-210), valid where the bundle is alive, and the 24 statistics
+        ('stats': host array; with sync=False 'stats_dev', a device tensor, so that nothing blocks the host).
+        `path_centre`: provisional centre for the second moments of the path (see include/art_hip.h);
+        store=False skips the per-ray outputs (statistics only)."""
         self._iscomplete()
         B = RayList if isinstance(RayList, RayBundle) else RayBundle.from_ray_list(RayList)
         be = B.backend
         n = B.n_slots
-        X, Y, opl = be.empty(n), be.empty(n), be.empty(n)
-        P3 = [be.empty(n), be.empty(n), be.empty(n)] if points3d else None
-        be.detector(self._desc(), B.view(), n, P3, (X, Y), opl)
-        stats = be.detector_stats(B.alive, X, Y, opl, B.intensity, n, to_host=sync)
+        X = Y = opl = P3 = None
+        if store:
+            X, Y, opl = be.empty(n), be.empty(n), be.empty(n)
+            P3 = [be.empty(n), be.empty(n), be.empty(n)] if points3d else None
+        stats = be.detector_readout(self._desc(), B.view(), B.intensity, n, (0.0, 0.0, path_centre), P3,
+                                    (X, Y) if store else None, opl, to_host=sync)
         return {"bundle": B, "X": X, "Y": Y, "opl": opl, "P3": P3, ("stats" if sync else "stats_dev"): stats}
 
     def _spot_and_duration(self, RayList, weighted, need_spot=True, need_duration=True):
-        """Std of the centred 2D points and of the delays (ART/ModuleProcessing.py:327-341), on device."""
-        r = self.readout(RayList)
-        B, s = r["bundle"], r["stats"]
-        w = B.intensity if weighted else None
+        """Std of the 2-D points and of the delays (ART/ModuleProcessing.py:327-341): one statistics-only pass when a
+        good estimate of the mean path is known from the previous call (detector scans), two otherwise."""
+        est = getattr(self, "_path_estimate", None)
+        key = (id(RayList), getattr(RayList, "version", None))
+        if est is None or est[0] != key:
+            s0 = self.readout(RayList, store=False)["stats"]
+            est = (key, s0[1] / s0[0], self._centre.copy())
+        # the mean path moves with the detector: + shift along the normal (exact for rays along the normal)
+        co = est[1] + float(np.dot(est[2] - self._centre, self.normal))
+        s = self.readout(RayList, store=False, path_centre=co)["stats"]
+        i0 = 19 if weighted else 16
         wsum = s[8] if weighted else s[0]
         mx = (s[9] if weighted else s[6]) / wsum
         my = (s[10] if weighted else s[7]) / wsum
         mo = (s[11] if weighted else s[1]) / wsum
-        m = B.backend.detector_moments(B.alive, r["X"], r["Y"], r["opl"], w, B.n_slots, mx, my, mo)
-        spot = float(np.sqrt((m[1] + m[2]) / m[0])) if need_spot else np.nan
-        dur = float(np.sqrt(m[3] / m[0]) / LightSpeed * 1e15) if need_duration else np.nan
+        vx = s[i0] / wsum - mx * mx                    # centres (0, 0, co): E[(x-c)^2] - (E[x]-c)^2
+        vy = s[i0 + 1] / wsum - my * my
+        vo = s[i0 + 2] / wsum - (mo - co) ** 2
+        self._path_estimate = (key, (s[1] / s[0]), self._centre.copy())
+        spot = float(np.sqrt(max(vx + vy, 0.0))) if need_spot else np.nan
+        dur = float(np.sqrt(max(vo, 0.0)) / LightSpeed * 1e15) if need_duration else np.nan
         return spot, dur
 
     # ------------------------------------------------------------------ reference API (host arrays of survivors)

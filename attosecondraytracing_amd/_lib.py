@@ -113,6 +113,20 @@ class HipBackend:
         self.check(self.fn["art_detector"](C.byref(ddesc), C.byref(view), n, p[0], p[1], p[2], xy[0], xy[1], o,
                                            self.stream_ptr()), "art_detector")
 
+    def detector_readout(self, ddesc, view, w, n, centres=(0.0, 0.0, 0.0), p3=None, XY=None, opl=None, to_host=True):
+        """Fused read-out + statistics (art_detector_readout); returns the 24 statistics."""
+        out = self.zeros(24) if n == 0 else self.empty(24)
+        if n > 0:
+            p = [t.data_ptr() for t in p3] if p3 is not None else [None, None, None]
+            xy = [t.data_ptr() for t in XY] if XY is not None else [None, None]
+            self.check(self.fn["art_detector_readout"](C.byref(ddesc), C.byref(view), None if w is None else w.data_ptr(),
+                                                       n, float(centres[0]), float(centres[1]), float(centres[2]),
+                                                       p[0], p[1], p[2], xy[0], xy[1],
+                                                       None if opl is None else opl.data_ptr(),
+                                                       self._red_scratch().data_ptr(), out.data_ptr(),
+                                                       self.stream_ptr()), "art_detector_readout")
+        return out.cpu().numpy() if to_host else out
+
     def _red_scratch(self):
         return self.scratch("red", self.fn["art_reduce_scratch_doubles"](), torch.float64)
 

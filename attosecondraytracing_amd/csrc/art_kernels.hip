@@ -292,6 +292,58 @@ __global__ __launch_bounds__(kBlock) void k_stats_final(const double* scratch, c
 }
 
 constexpr int kSumSlots = 8;
+constexpr int kReadoutSlots = 24;
+
+// detector read-out fused with its reductions: one pass over the bundle, statistics accumulated in registers
+__global__ __launch_bounds__(kBlock) void k_detector_readout(const ArtDetectorDesc d, const ArtBundleView b,
+                                                             const double* w, const int64_t n, const double cx,
+                                                             const double cy, const double co, double* p3x, double* p3y,
+                                                             double* p3z, double* X, double* Y, double* opl,
+                                                             double* scratch) {
+  const int ops[kReadoutSlots] = {RSUM, RSUM, RMIN, RMAX, RMIN, RMAX, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM,
+                                  RMIN, RMAX, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM};
+  double acc[kReadoutSlots];
+#pragma unroll
+  for (int k = 0; k < kReadoutSlots; ++k) acc[k] = (ops[k] == RSUM) ? 0.0 : (ops[k] == RMIN ? INFINITY : -INFINITY);
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    if (b.alive[i] == 0) continue;
+    art::Ray r;
+    load_ray(b, i, r);
+    double Ix, Iy, Iz, x, y, o;
+    art::detector_ray(d, r, Ix, Iy, Iz, x, y, o);
+    if (p3x) { p3x[i] = Ix; p3y[i] = Iy; p3z[i] = Iz; }
+    if (X) { X[i] = x; Y[i] = y; }
+    if (opl) opl[i] = o;
+    const double ww = w ? w[i] : 1.0;
+    acc[0] += 1.0; acc[1] += o;
+    acc[2] = fmin(acc[2], x); acc[3] = fmax(acc[3], x);
+    acc[4] = fmin(acc[4], y); acc[5] = fmax(acc[5], y);
+    acc[6] += x; acc[7] += y;
+    acc[8] += ww; acc[9] = fma(ww, x, acc[9]); acc[10] = fma(ww, y, acc[10]); acc[11] = fma(ww, o, acc[11]);
+    acc[12] = fmin(acc[12], o); acc[13] = fmax(acc[13], o);
+    const double ex = x - cx, ey = y - cy, eo = o - co;
+    acc[16] = fma(ex, ex, acc[16]); acc[17] = fma(ey, ey, acc[17]); acc[18] = fma(eo, eo, acc[18]);
+    acc[19] = fma(ww * ex, ex, acc[19]); acc[20] = fma(ww * ey, ey, acc[20]); acc[21] = fma(ww * eo, eo, acc[21]);
+  }
+  block_reduce_store<kReadoutSlots>(acc, ops, scratch + (int64_t)blockIdx.x * kReadoutSlots);
+}
+
+__global__ __launch_bounds__(kBlock) void k_readout_final(const double* scratch, const int nblocks, double* out) {
+  const int ops[kReadoutSlots] = {RSUM, RSUM, RMIN, RMAX, RMIN, RMAX, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM,
+                                  RMIN, RMAX, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM};
+  double acc[kReadoutSlots];
+#pragma unroll
+  for (int k = 0; k < kReadoutSlots; ++k) acc[k] = (ops[k] == RSUM) ? 0.0 : (ops[k] == RMIN ? INFINITY : -INFINITY);
+  for (int blk = threadIdx.x; blk < nblocks; blk += kBlock) {
+#pragma unroll
+    for (int k = 0; k < kReadoutSlots; ++k) {
+      const double v = scratch[(int64_t)blk * kReadoutSlots + k];
+      acc[k] = (ops[k] == RSUM) ? acc[k] + v : (ops[k] == RMIN ? fmin(acc[k], v) : fmax(acc[k], v));
+    }
+  }
+  block_reduce_store<kReadoutSlots>(acc, ops, out);
+}
 
 __global__ __launch_bounds__(kBlock) void k_moments_partial(const uint8_t* alive, const double* X, const double* Y,
                                                             const double* opl, const double* w, const int64_t n,
@@ -638,7 +690,31 @@ int art_detector(const ArtDetectorDesc* d, const ArtBundleView* b, int64_t n, do
   return ART_OK;
 }
 
-int64_t art_reduce_scratch_doubles(void) { return (int64_t)kRedBlocks * kRedSlots; }
+int art_detector_readout(const ArtDetectorDesc* d, const ArtBundleView* b, const double* w, int64_t n, double cx,
+                         double cy, double co, double* p3x, double* p3y, double* p3z, double* X, double* Y,
+                         double* opl, double* scratch, double* out24, void* stream) {
+  if (!d || !scratch || !out24) return fail(ART_ERR_BAD_ARG, "descriptor/scratch/out24 must not be NULL");
+  if ((p3x || p3y || p3z) && !(p3x && p3y && p3z)) return fail(ART_ERR_BAD_ARG, "p3x/p3y/p3z must be all set or all NULL");
+  if ((X || Y) && !(X && Y)) return fail(ART_ERR_BAD_ARG, "X/Y must be both set or both NULL");
+  if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    hipError_t e0 = hipMemsetAsync(out24, 0, kReadoutSlots * sizeof(double), s);
+    if (e0 != hipSuccess) return fail_hip(e0, "hipMemsetAsync");
+    return ART_OK;
+  }
+  if (!view_ok(b)) return fail(ART_ERR_BAD_ARG, "bundle view has a NULL array");
+  // 2048 workgroups of partials: scratch must hold 2048 * 24 doubles (art_reduce_scratch_doubles covers it)
+  const int nb = grid_for(n);
+  hipLaunchKernelGGL(k_detector_readout, dim3(nb), dim3(kBlock), 0, s, *d, *b, w, n, cx, cy, co, p3x, p3y, p3z, X, Y,
+                     opl, scratch);
+  hipLaunchKernelGGL(k_readout_final, dim3(1), dim3(kBlock), 0, s, scratch, nb, out24);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail_hip(err, "art_detector_readout launch");
+  return ART_OK;
+}
+
+int64_t art_reduce_scratch_doubles(void) { return (int64_t)kMaxBlocks * kReadoutSlots + 64; }
 
 int art_detector_stats(const uint8_t* alive, const double* X, const double* Y, const double* opl, const double* w,
                        int64_t n, double* scratch, double* out16, void* stream) {

@@ -151,6 +151,18 @@ int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundl
 int art_detector(const ArtDetectorDesc* d, const ArtBundleView* b, int64_t n,
                  double* p3x, double* p3y, double* p3z, double* X, double* Y, double* opl, void* stream);
 
+/* Read-out and statistics in ONE pass over the bundle (what Detector.readout uses): the outputs of art_detector
+ * plus, accumulated while the values are still in registers, the statistics of art_detector_stats in out24[0..15]
+ * and second moments about provisional centres (cx, cy, co) in out24[16..23]:
+ *   [16] sum (X-cx)^2  [17] sum (Y-cy)^2  [18] sum (opl-co)^2
+ *   [19] sum w (X-cx)^2 [20] sum w (Y-cy)^2 [21] sum w (opl-co)^2  [22..23] 0
+ * Variances follow as E[(x-c)^2] - (E[x]-c)^2; with c within a few standard deviations of the mean (cx = cy = 0 is
+ * the detector centre, co an estimate of the mean path) the cancellation is harmless.  w = weights or NULL (w = 1).
+ * out24: DEVICE, 24 doubles.  scratch: DEVICE, art_reduce_scratch_doubles() doubles.                              */
+int art_detector_readout(const ArtDetectorDesc* d, const ArtBundleView* b, const double* w, int64_t n, double cx,
+                         double cy, double co, double* p3x, double* p3y, double* p3z, double* X, double* Y,
+                         double* opl, double* scratch, double* out24, void* stream);
+
 /* Masked reductions over alive rays, deterministic (fixed two-level tree, no float atomics).
  * out16 (DEVICE, 16 doubles):
  *   [0] count  [1] sum opl  [2] min X [3] max X [4] min Y [5] max Y  [6] sum X [7] sum Y

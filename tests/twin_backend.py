@@ -69,6 +69,21 @@ class TwinBackend:
         o = opl.data_ptr() if opl is not None else None
         assert self.lib.art_cpu_detector(C.byref(ddesc), C.byref(view), n, p[0], p[1], p[2], xy[0], xy[1], o) == 0
 
+    def detector_readout(self, ddesc, view, w, n, centres=(0.0, 0.0, 0.0), p3=None, XY=None, opl=None, to_host=True):
+        X = XY[0] if XY is not None else torch.empty(n, dtype=torch.float64)
+        Y = XY[1] if XY is not None else torch.empty(n, dtype=torch.float64)
+        O = opl if opl is not None else torch.empty(n, dtype=torch.float64)
+        self.detector(ddesc, view, n, p3, (X, Y), O)
+        alive = torch.from_numpy(np.ctypeslib.as_array(C.cast(view.alive, C.POINTER(C.c_uint8)), shape=(max(n, 1),))[:n].copy())
+        out = np.zeros(24)
+        out[:16] = self.detector_stats(alive, X, Y, O, w, n)
+        a = alive.numpy().astype(bool)
+        ww = w.numpy()[a] if w is not None else np.ones(int(a.sum()))
+        ex, ey, eo = X.numpy()[a] - centres[0], Y.numpy()[a] - centres[1], O.numpy()[a] - centres[2]
+        out[16:22] = [(ex ** 2).sum(), (ey ** 2).sum(), (eo ** 2).sum(), (ww * ex ** 2).sum(), (ww * ey ** 2).sum(),
+                      (ww * eo ** 2).sum()]
+        return out if to_host else torch.from_numpy(out)
+
     @staticmethod
     def _np(t):
         return None if t is None else t.numpy()
