@@ -7,8 +7,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-# slots of art_detector_stats (include/art_hip.h) by reduction operator
-_SUM = [0, 1, 6, 7, 8, 9, 10, 11]
+# slots of the read-out statistics (include/art_hip.h: art_detector_stats [0..15], art_detector_readout [16..23]) by
+# reduction operator
 _MIN = [2, 4, 12]
 _MAX = [3, 5, 13]
 
@@ -18,20 +18,39 @@ def shard_range(n_total, rank, world):
     return (n_total * rank) // world, (n_total * (rank + 1)) // world
 
 
-def allreduce_stats(stats16, device):
-    """Combine per-shard art_detector_stats vectors into the global one (same layout).  Accepts a host array or
-    a device tensor; returns a tensor on `device` (nothing blocks the host)."""
-    t = stats16 if torch.is_tensor(stats16) else torch.as_tensor(np.asarray(stats16, dtype=np.float64))
+class PendingStats:
+    """Handle of an in-flight statistics exchange (allreduce_stats(..., async_op=True)): `.result()` waits for the
+    collective (on the caller's stream, not the host) and folds the per-rank vectors."""
+
+    def __init__(self, work, flat, world, nslots):
+        self.work, self.flat, self.world, self.nslots = work, flat, world, nslots
+
+    def result(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        allv = self.flat.view(self.world, self.nslots)
+        out = allv.sum(dim=0)
+        out[_MIN] = allv[:, _MIN].min(dim=0).values
+        out[_MAX] = allv[:, _MAX].max(dim=0).values
+        return out
+
+
+def allreduce_stats(stats, device, async_op=False):
+    """Combine per-shard read-out statistics (16 or 24 slots, layout of include/art_hip.h) into the global ones.
+    ONE collective: an all-gather of the small vectors, folded on the device (sum slots added, min/max slots
+    min/max-ed) -- cheaper than one all-reduce per operator.  Accepts a host array or a device tensor; returns a
+    tensor on `device` (or, with async_op=True, a PendingStats whose collective runs on RCCL's stream while the
+    caller's stream goes on tracing); nothing blocks the host."""
+    t = stats if torch.is_tensor(stats) else torch.as_tensor(np.asarray(stats, dtype=np.float64))
     t = t.to(device)
     if not (dist.is_available() and dist.is_initialized()):
         return t
-    s, mn, mx = t[_SUM].clone(), t[_MIN].clone(), t[_MAX].clone()
-    dist.all_reduce(s, op=dist.ReduceOp.SUM)
-    dist.all_reduce(mn, op=dist.ReduceOp.MIN)
-    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-    out = torch.zeros(16, dtype=torch.float64, device=device)
-    out[_SUM], out[_MIN], out[_MAX] = s, mn, mx
-    return out
+    world = dist.get_world_size()
+    flat = torch.empty(world * t.numel(), dtype=torch.float64, device=device)
+    work = dist.all_gather_into_tensor(flat, t.contiguous().reshape(-1), async_op=async_op)
+    pending = PendingStats(work if async_op else None, flat, world, t.numel())
+    return pending if async_op else pending.result()
 
 
 def gather_readout(X, Y, opl, alive, dst=0, pack=None, sizes=None, async_op=False):

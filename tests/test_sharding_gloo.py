@@ -55,6 +55,8 @@ def _worker(rank, world, port, n_total, q):
     try:
         r, last, det = _run_shard(rank, world, n_total)
         stats = sharding.allreduce_stats(r["stats_dev"], torch.device("cpu"))
+        again = sharding.allreduce_stats(r["stats_dev"], torch.device("cpu"), async_op=True).result()
+        assert torch.equal(stats, again)
         XYO, alive = sharding.gather_readout(r["X"], r["Y"], r["opl"], last.alive, 0)
         # the overlapped form bench.py uses: preallocated pack, known sizes, handles waited for later
         sizes = [b - a for a, b in (sharding.shard_range(n_total, k, world) for k in range(world))]
