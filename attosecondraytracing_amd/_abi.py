@@ -1,7 +1,7 @@
 """ctypes mirror of include/art_hip.h (structs, enums, prototypes).  Keep in sync with ART_ABI_VERSION."""
 import ctypes as C
 
-ART_ABI_VERSION = 3
+ART_ABI_VERSION = 4
 
 ART_OK = 0
 ART_ERR_BAD_ARG = -1
@@ -16,7 +16,7 @@ ART_SUP_ROUND, ART_SUP_ROUNDHOLE, ART_SUP_RECT, ART_SUP_RECTHOLE, ART_SUP_RECTRE
 
 ART_FLAG_PERTURBED_NORMAL = 1
 
-ART_ZERN_MAX_ORDER = 12
+ART_ZERN_MAX_ORDER = 16
 ART_ZERN_DIM = ART_ZERN_MAX_ORDER + 1
 ART_ZERN_STRIDE = 2 + 3 * ART_ZERN_DIM * ART_ZERN_DIM
 ART_MAX_DEFECTS = 4

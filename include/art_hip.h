@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ART_ABI_VERSION 3
+#define ART_ABI_VERSION 4
 
 /* error codes */
 #define ART_OK 0
@@ -68,9 +68,9 @@ enum ArtSupportKind {
  *   [base+2            + p*ART_ZERN_DIM + q] = A[p][q]        coefficient of x^p y^q of h
  *   [base+2 +   DIM^2  + p*ART_ZERN_DIM + q] = dA/dx [p][q]   = (p+1) A[p+1][q]
  *   [base+2 + 2*DIM^2  + p*ART_ZERN_DIM + q] = dA/dy [p][q]   = (q+1) A[p][q+1]                        */
-#define ART_ZERN_MAX_ORDER 12
-#define ART_ZERN_DIM (ART_ZERN_MAX_ORDER + 1)                      /* 13 */
-#define ART_ZERN_STRIDE (2 + 3 * ART_ZERN_DIM * ART_ZERN_DIM)      /* 509 */
+#define ART_ZERN_MAX_ORDER 16
+#define ART_ZERN_DIM (ART_ZERN_MAX_ORDER + 1)                      /* 17 */
+#define ART_ZERN_STRIDE (2 + 3 * ART_ZERN_DIM * ART_ZERN_DIM)      /* 869 */
 #define ART_MAX_DEFECTS 4
 
 /* Gridded height-map defect (ART/ModuleDefects.py `Fourrier` :69-146; offset lookup :131-137 through SciPy's
