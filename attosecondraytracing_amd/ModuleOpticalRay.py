@@ -1,90 +1,87 @@
-"""Host-side `Ray` record with the reference's constructor and attributes (ART/ModuleOpticalRay.py:11-156).
+"""Host-side `Ray` record with the constructor signature and attributes of the reference's Ray
+(ART/ModuleOpticalRay.py:11-156).
 
-A Ray is only a *view* of one slot of a device-resident RayBundle (or a single hand-made ray, e.g. the
-alignment ray of OEPlacement); bundles are never stored as lists of these objects."""
+Here a Ray is only a *view* of one slot of a device-resident RayBundle (bundle.py), or a single hand-made ray such as
+the alignment ray of OEPlacement; bundles are never stored as lists of these objects.  The validation rules are the
+reference's: 3-vectors must be numpy arrays, the direction is normalised on assignment and must be longer than 1e-9,
+`number` is fixed at construction."""
 import numpy as np
+
+_NUMERIC = (int, float, np.float64)
+
+
+def _is_vec3(v):
+    return isinstance(v, np.ndarray) and len(v) == 3
+
+
+def _checked(name, allowed, message):
+    """Property whose setter accepts only the listed scalar types (TypeError otherwise)."""
+    slot = "_" + name
+
+    def fget(self):
+        return getattr(self, slot)
+
+    def fset(self, value):
+        if type(value) not in allowed:
+            raise TypeError(message)
+        setattr(self, slot, value)
+
+    return property(fget, fset)
 
 
 class Ray:
     __slots__ = ("_point", "_vector", "_path", "_number", "_wavelength", "_incidence", "_intensity")
 
     def __init__(self, Point, Vector, Path=(0.0,), Number=None, Wavelength=None, Incidence=None, Intensity=None):
-        self.point = Point
-        self.vector = Vector  # normalised by the setter, as in the reference (:85-90)
-        self._path = Path
-        self._wavelength = Wavelength
-        self._incidence = Incidence
-        self._intensity = Intensity
         if Number is not None and not isinstance(Number, (int, np.integer)):
             raise TypeError("Ray Number must be an integer.")
+        self.point, self.vector = Point, Vector
+        # the optional attributes bypass their setters at construction, so None is allowed (:57-60)
+        self._path, self._wavelength, self._incidence, self._intensity = Path, Wavelength, Incidence, Intensity
         self._number = None if Number is None else int(Number)
 
-    @property
-    def point(self):
+    # origin of the ray
+    def _get_point(self):
         return self._point
 
-    @point.setter
-    def point(self, Point):
-        if not (isinstance(Point, np.ndarray) and len(Point) == 3):
+    def _set_point(self, Point):
+        if not _is_vec3(Point):
             raise TypeError("Ray Point must be a 3D numpy.ndarray, but it is  %s." % type(Point))
         self._point = Point
 
-    @property
-    def vector(self):
+    point = property(_get_point, _set_point)
+
+    # unit direction; re-normalised whenever it is assigned
+    def _get_vector(self):
         return self._vector
 
-    @vector.setter
-    def vector(self, Vector):
-        if not (isinstance(Vector, np.ndarray) and len(Vector) == 3 and np.linalg.norm(Vector) > 1e-9):
+    def _set_vector(self, Vector):
+        length = np.linalg.norm(Vector) if _is_vec3(Vector) else 0.0
+        if not length > 1e-9:
             raise TypeError("Ray Vector must be a 3D numpy.ndarray with finite length.")
-        self._vector = Vector / np.linalg.norm(Vector)
+        self._vector = Vector / length
 
-    @property
-    def path(self):
+    vector = property(_get_vector, _set_vector)
+
+    # tuple of the segment lengths travelled so far
+    def _get_path(self):
         return self._path
 
-    @path.setter
-    def path(self, Path):
+    def _set_path(self, Path):
         self._path = Path
 
-    @property
-    def number(self):
-        return self._number
+    path = property(_get_path, _set_path)
 
-    @property
-    def wavelength(self):
-        return self._wavelength
-
-    @wavelength.setter
-    def wavelength(self, Wavelength):
-        if type(Wavelength) not in (int, float, np.float64):
-            raise TypeError("Ray Wavelength must be int or float or None.")
-        self._wavelength = Wavelength
-
-    @property
-    def incidence(self):
-        return self._incidence
-
-    @incidence.setter
-    def incidence(self, Incidence):
-        if type(Incidence) not in (float, np.float64):
-            raise TypeError("Ray Incidence must be a float or None.")
-        self._incidence = Incidence
-
-    @property
-    def intensity(self):
-        return self._intensity
-
-    @intensity.setter
-    def intensity(self, Intensity):
-        if type(Intensity) not in (int, float, np.float64):
-            raise TypeError("Ray Intensity must be int or float or None.")
-        self._intensity = Intensity
+    number = property(lambda self: self._number)   # read-only: links a ray to its source ray
+    wavelength = _checked("wavelength", _NUMERIC, "Ray Wavelength must be int or float or None.")
+    incidence = _checked("incidence", (float, np.float64), "Ray Incidence must be a float or None.")
+    intensity = _checked("intensity", _NUMERIC, "Ray Intensity must be int or float or None.")
 
     def copy_ray(self):
-        """New Ray with the same properties (:145-149)."""
-        return Ray(self.point, self.vector, self.path, self.number, self.wavelength, self.incidence, self.intensity)
+        """A new Ray carrying the same seven attributes (:145-149)."""
+        return Ray(self._point, self._vector, self._path, self._number, self._wavelength, self._incidence,
+                   self._intensity)
 
     def __hash__(self):
-        return hash(tuple(self.point) + tuple(self.vector)
-                    + (self.path, self.number, self.wavelength, self.incidence, self.intensity))
+        return hash((*self._point, *self._vector, self._path, self._number, self._wavelength, self._incidence,
+                     self._intensity))
