@@ -327,7 +327,11 @@ ART_HD bool torus_newton(double R, double r2, double Ax, double Ay, double Az, d
     const double tn = t - dt;
     ++it;
     // quadratic convergence: the step just taken leaves an error ~ dt^2 * F''/(2F') ~ 1e-14 (1+|t|)^2/(r cos)
+#ifdef ART_DIAG_NEWTON1
+    const bool conv = true;
+#else
     const bool conv = (fabs(dt) <= 1e-7 * (1.0 + fabs(tn))) || (it >= 60);
+#endif
     const bool step = active && !miss;
     t = step ? tn : t;
     found = found || (step && conv);
@@ -474,7 +478,11 @@ ART_HD bool trace_ray(const ArtElementDesc& e, const double* zern, Ray& r) {
     inc = kahan_angle_unit(ux, uy, uz, 0.0, 0.0, 1.0);
   } else {
     double nx, ny, nz;
+#ifdef ART_DIAG_NONORMAL
+    nx = 0.0; ny = 0.0; nz = 1.0 + 1e-30 * Px;
+#else
     base_normal<KIND>(e, Px, Py, Pz, nx, ny, nz);
+#endif
     if (DEFECT && (e.n_defects > 0 || e.n_grid > 0)) {
       // DeformedMirror._get_intersection, ModuleMirror.py:969-980: slide the hit point along the ray by
       // h / cos(alpha), h = summed defect offsets at (P - centre), alpha = angle(-u, base normal)
@@ -504,7 +512,11 @@ ART_HD bool trace_ray(const ArtElementDesc& e, const double* zern, Ray& r) {
     // _ReflectionMirrorRay, ModuleMirror.py:878-906: v' = rot(n, pi) applied to -v  ==  v - 2 (n.v) n
     const double dn = dot3(ux, uy, uz, nx, ny, nz);
     vx = fma(-2.0 * dn, nx, ux); vy = fma(-2.0 * dn, ny, uy); vz = fma(-2.0 * dn, nz, uz);
+#ifdef ART_DIAG_NOINC
+    inc = dn;
+#else
     inc = kahan_angle_unit(-ux, -uy, -uz, nx, ny, nz);
+#endif
   }
   // optic -> lab frame (:306-309)
   double ox, oy, oz, dx, dy, dz;
