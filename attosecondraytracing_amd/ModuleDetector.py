@@ -55,10 +55,7 @@ class Detector:
 
     # ------------------------------------------------------------------ placement
     def copy_detector(self):
-        c = Detector(self.refpoint, self.centre, self.normal)
-        if hasattr(self, "_path_estimate"):
-            c._path_estimate = self._path_estimate
-        return c
+        return Detector(self.refpoint, self.centre, self.normal)
 
     def autoplace(self, RayList, DistanceDetector: float):
         """Normal to the central ray of RayList, DistanceDetector away from its origin (ART/ModuleDetector.py:109-137)."""
@@ -122,29 +119,27 @@ class Detector:
                                     (X, Y) if store else None, opl, to_host=sync)
         return {"bundle": B, "X": X, "Y": Y, "opl": opl, "P3": P3, ("stats" if sync else "stats_dev"): stats}
 
-    def _spot_and_duration(self, RayList, weighted, need_spot=True, need_duration=True):
-        """Std of the 2-D points and of the delays (ART/ModuleProcessing.py:327-341): one statistics-only pass when a
-        good estimate of the mean path is known from the previous call (detector scans), two otherwise."""
-        est = getattr(self, "_path_estimate", None)
-        key = (id(RayList), getattr(RayList, "version", None))
-        if est is None or est[0] != key:
-            s0 = self.readout(RayList, store=False)["stats"]
-            est = (key, s0[1] / s0[0], self._centre.copy())
-        # the mean path moves with the detector: + shift along the normal (exact for rays along the normal)
-        co = est[1] + float(np.dot(est[2] - self._centre, self.normal))
-        s = self.readout(RayList, store=False, path_centre=co)["stats"]
-        i0 = 19 if weighted else 16
-        wsum = s[8] if weighted else s[0]
-        mx = (s[9] if weighted else s[6]) / wsum
-        my = (s[10] if weighted else s[7]) / wsum
-        mo = (s[11] if weighted else s[1]) / wsum
-        vx = s[i0] / wsum - mx * mx                    # centres (0, 0, co): E[(x-c)^2] - (E[x]-c)^2
-        vy = s[i0 + 1] / wsum - my * my
-        vo = s[i0 + 2] / wsum - (mo - co) ** 2
-        self._path_estimate = (key, (s[1] / s[0]), self._centre.copy())
-        spot = float(np.sqrt(max(vx + vy, 0.0))) if need_spot else np.nan
-        dur = float(np.sqrt(max(vo, 0.0)) / LightSpeed * 1e15) if need_duration else np.nan
-        return spot, dur
+    def _scan_moments(self, RayList):
+        """Moment sums from which spot size and duration follow at ANY shift of this detector along its normal
+        (art_detector_scan_moments).  Two passes over the bundle: the first only finds the mean path used to centre
+        the second."""
+        self._iscomplete()
+        B = RayList if isinstance(RayList, RayBundle) else RayBundle.from_ray_list(RayList)
+        be, n, d = B.backend, B.n_slots, self._desc()
+        first = be.detector_scan_moments(d, B.view(), B.intensity, n, 0.0)
+        co = first[11] / first[0]
+        return {"m": be.detector_scan_moments(d, B.view(), B.intensity, n, co), "co": co}
+
+    @staticmethod
+    def _spot_duration_from_moments(mom, s, weighted):
+        """(spot size std, duration std in fs) of the detector shifted by s, from the sums of _scan_moments."""
+        m = mom["m"][16:] if weighted else mom["m"][:16]
+        var = []
+        for k in range(3):
+            q, sq, qq, qs, ss = m[1 + 5 * k: 6 + 5 * k]
+            mean = (q + s * sq) / m[0]
+            var.append(max((qq + 2 * s * qs + s * s * ss) / m[0] - mean * mean, 0.0))
+        return float(np.sqrt(var[0] + var[1])), float(np.sqrt(var[2]) / LightSpeed * 1e15)
 
     # ------------------------------------------------------------------ reference API (host arrays of survivors)
     def get_PointList3D(self, RayList):

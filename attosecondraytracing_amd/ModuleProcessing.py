@@ -311,20 +311,20 @@ def ReturnAiryRadius(Wavelength: float, NumericalAperture: float) -> float:
 
 # ------------------------------------------------------------------------------------------- autofocus
 def _scan(detector, Amplitude, Step, RayList, OptFor, IntensityWeighted):
-    """One pass of the detector scan (ART/ModuleProcessing.py:317-366): every position is evaluated on the
-    device (detector read-out + two reduction passes), all rays, no Python loop over rays."""
-    sizes, durations, fitness = [], [], []
+    """One pass of the detector scan (ART/ModuleProcessing.py:317-366).  The read-out of every ray is linear in the
+    detector shift, so the spot size and duration at all scan positions follow from one set of moment sums computed
+    on the device (Detector._scan_moments: two passes over the bundle, all rays) instead of one pass per position."""
     detector.shiftByDistance(-Amplitude)
     n = int(2 * Amplitude / Step)
-    for _ in range(n):
-        spot, dur = detector._spot_and_duration(RayList, IntensityWeighted, need_spot=OptFor in ("intensity", "spotsize"),
-                                                need_duration=OptFor in ("intensity", "duration"))
-        sizes.append(spot)
-        durations.append(dur)
+    mom = detector._scan_moments(RayList)
+    sizes, durations, fitness = [], [], []
+    for i in range(n):
+        spot, dur = detector._spot_duration_from_moments(mom, i * Step, IntensityWeighted)
+        sizes.append(spot if OptFor in ("intensity", "spotsize") else np.nan)
+        durations.append(dur if OptFor in ("intensity", "duration") else np.nan)
         fitness.append(spot ** 2 * dur if OptFor == "intensity" else (dur if OptFor == "duration" else spot))
-        detector.shiftByDistance(Step)
     ind = int(np.argmin(fitness))
-    detector.shiftByDistance(-(n - ind) * Step)
+    detector.shiftByDistance(ind * Step)
     return detector, sizes[ind], durations[ind]
 
 

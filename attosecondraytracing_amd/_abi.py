@@ -80,6 +80,8 @@ PROTOTYPES = {
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "art_detector_readout": (C.c_int, [C.POINTER(ArtDetectorDesc), C.POINTER(ArtBundleView), C.c_void_p, C.c_int64,
                                        C.c_double, C.c_double, C.c_double] + [C.c_void_p] * 9),
+    "art_detector_scan_moments": (C.c_int, [C.POINTER(ArtDetectorDesc), C.POINTER(ArtBundleView), C.c_void_p,
+                                            C.c_int64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "art_reduce_scratch_doubles": (C.c_int64, []),
     "art_detector_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -127,6 +127,17 @@ class HipBackend:
                                                        self.stream_ptr()), "art_detector_readout")
         return out.cpu().numpy() if to_host else out
 
+    def detector_scan_moments(self, ddesc, view, w, n, co):
+        """32 moment sums for a detector scan along its normal (art_detector_scan_moments); host array."""
+        if n == 0:
+            return np.zeros(32)
+        out = self.empty(32)
+        self.check(self.fn["art_detector_scan_moments"](C.byref(ddesc), C.byref(view),
+                                                        None if w is None else w.data_ptr(), n, float(co),
+                                                        self._red_scratch().data_ptr(), out.data_ptr(),
+                                                        self.stream_ptr()), "art_detector_scan_moments")
+        return out.cpu().numpy()
+
     def _red_scratch(self):
         return self.scratch("red", self.fn["art_reduce_scratch_doubles"](), torch.float64)
 

@@ -563,6 +563,25 @@ ART_HD void detector_ray(const ArtDetectorDesc& d, const Ray& r, double& Ix, dou
   opl = fabs(t) * sqrt(dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz)) + r.path;
 }
 
+// Read-out at the current detector position and its derivative with respect to a shift s along -normal
+// (Detector.shiftByDistance(s), ART/ModuleDetector.py:163-177): everything is linear in s.
+ART_HD void detector_ray_scan(const ArtDetectorDesc& d, const Ray& r, double& X, double& Y, double& opl, double& sx,
+                              double& sy, double& so) {
+  double Ix, Iy, Iz;
+  detector_ray(d, r, Ix, Iy, Iz, X, Y, opl);
+  const double den = dot3(r.dx, r.dy, r.dz, d.normal[0], d.normal[1], d.normal[2]);
+  const double nn = dot3(d.normal[0], d.normal[1], d.normal[2], d.normal[0], d.normal[1], d.normal[2]);
+  const double dt = -nn / den;  // d t / d s: the plane recedes by s*normal, t = n.(C - s n - A)/(u.n)
+  // d(I - C_s)/ds = dt*u + normal
+  double rx, ry, rz;
+  mat3_apply(d.rot, fma(dt, r.dx, d.normal[0]), fma(dt, r.dy, d.normal[1]), fma(dt, r.dz, d.normal[2]), rx, ry, rz);
+  sx = rx; sy = ry;
+  const double num = dot3(d.normal[0], d.normal[1], d.normal[2], d.centre[0] - r.ox, d.centre[1] - r.oy,
+                          d.centre[2] - r.oz);
+  const double sgn = (num / den >= 0.0) ? 1.0 : -1.0;  // opl = |t| |u| + path
+  so = sgn * dt * sqrt(dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz));
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Sources (ART/ModuleSource.py:23-81, :135-169; SpiralVogel ART/ModuleGeometry.py:61-76) for ray index k
 ART_HD void source_ray(int kind, double size, const double* rot, const double* S, int64_t k, int64_t n_total,

@@ -329,6 +329,56 @@ __global__ __launch_bounds__(kBlock) void k_detector_readout(const ArtDetectorDe
   block_reduce_store<kReadoutSlots>(acc, ops, scratch + (int64_t)blockIdx.x * kReadoutSlots);
 }
 
+constexpr int kScanSlots = 32;
+
+__global__ __launch_bounds__(kBlock) void k_scan_moments_partial(const ArtDetectorDesc d, const ArtBundleView b,
+                                                                 const double* w, const int64_t n, const double co,
+                                                                 double* scratch) {
+  double acc[kScanSlots];
+#pragma unroll
+  for (int k = 0; k < kScanSlots; ++k) acc[k] = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    if (b.alive[i] == 0) continue;
+    art::Ray r;
+    load_ray(b, i, r);
+    double q0[3], sq[3];
+    art::detector_ray_scan(d, r, q0[0], q0[1], q0[2], sq[0], sq[1], sq[2]);
+    q0[2] -= co;
+    sq[2] -= 1.0;
+    const double ww = w ? w[i] : 1.0;
+    acc[0] += 1.0;
+    acc[16] += ww;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int o = 1 + 5 * k;
+      acc[o] += q0[k]; acc[o + 1] += sq[k];
+      acc[o + 2] = fma(q0[k], q0[k], acc[o + 2]); acc[o + 3] = fma(q0[k], sq[k], acc[o + 3]);
+      acc[o + 4] = fma(sq[k], sq[k], acc[o + 4]);
+      const double wq = ww * q0[k], ws = ww * sq[k];
+      acc[16 + o] += wq; acc[16 + o + 1] += ws;
+      acc[16 + o + 2] = fma(wq, q0[k], acc[16 + o + 2]); acc[16 + o + 3] = fma(wq, sq[k], acc[16 + o + 3]);
+      acc[16 + o + 4] = fma(ws, sq[k], acc[16 + o + 4]);
+    }
+  }
+  int ops[kScanSlots];
+#pragma unroll
+  for (int k = 0; k < kScanSlots; ++k) ops[k] = RSUM;
+  block_reduce_store<kScanSlots>(acc, ops, scratch + (int64_t)blockIdx.x * kScanSlots);
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_moments_final(const double* scratch, const int nblocks, double* out) {
+  double acc[kScanSlots];
+  int ops[kScanSlots];
+#pragma unroll
+  for (int k = 0; k < kScanSlots; ++k) { acc[k] = 0.0; ops[k] = RSUM; }
+  for (int blk = threadIdx.x; blk < nblocks; blk += kBlock) {
+#pragma unroll
+    for (int k = 0; k < kScanSlots; ++k) acc[k] += scratch[(int64_t)blk * kScanSlots + k];
+  }
+  block_reduce_store<kScanSlots>(acc, ops, out);
+}
+
 __global__ __launch_bounds__(kBlock) void k_readout_final(const double* scratch, const int nblocks, double* out) {
   const int ops[kReadoutSlots] = {RSUM, RSUM, RMIN, RMAX, RMIN, RMAX, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM,
                                   RMIN, RMAX, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM};
@@ -711,6 +761,26 @@ int art_detector_readout(const ArtDetectorDesc* d, const ArtBundleView* b, const
   hipLaunchKernelGGL(k_readout_final, dim3(1), dim3(kBlock), 0, s, scratch, nb, out24);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_detector_readout launch");
+  return ART_OK;
+}
+
+int art_detector_scan_moments(const ArtDetectorDesc* d, const ArtBundleView* b, const double* w, int64_t n, double co,
+                              double* scratch, double* out32, void* stream) {
+  if (!d || !scratch || !out32) return fail(ART_ERR_BAD_ARG, "descriptor/scratch/out32 must not be NULL");
+  if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    hipError_t e0 = hipMemsetAsync(out32, 0, kScanSlots * sizeof(double), s);
+    if (e0 != hipSuccess) return fail_hip(e0, "hipMemsetAsync");
+    return ART_OK;
+  }
+  if (!view_ok(b)) return fail(ART_ERR_BAD_ARG, "bundle view has a NULL array");
+  int64_t nbk = (n + kBlock - 1) / kBlock;
+  const int nb = (int)(nbk > kRedBlocks ? kRedBlocks : nbk);
+  hipLaunchKernelGGL(k_scan_moments_partial, dim3(nb), dim3(kBlock), 0, s, *d, *b, w, n, co, scratch);
+  hipLaunchKernelGGL(k_scan_moments_final, dim3(1), dim3(kBlock), 0, s, scratch, nb, out32);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail_hip(err, "art_detector_scan_moments launch");
   return ART_OK;
 }
 

@@ -163,6 +163,17 @@ int art_detector_readout(const ArtDetectorDesc* d, const ArtBundleView* b, const
                          double cy, double co, double* p3x, double* p3y, double* p3z, double* X, double* Y,
                          double* opl, double* scratch, double* out24, void* stream);
 
+/* Moments for a detector SCAN along its normal (autofocus, ART/ModuleProcessing.py:317-460).  For a detector shifted
+ * by s along -normal (Detector.shiftByDistance(s)) every ray's read-out is exactly linear in s:
+ *     X(s) = X0 + s*sx,  Y(s) = Y0 + s*sy,  opl(s) = opl0 + s*so,   so = -1/(u.normal), (sx, sy) = rot*(so*u + normal)
+ * so the spot-size and duration variances at ANY s follow from global sums of per-ray products: one pass over the
+ * bundle replaces one pass per scan position.  The path is centred for conditioning: O = opl0 - co, sO = so - 1.
+ * out32 (DEVICE, 32 doubles), first block with weight 1, second block (+16) with weight w (= 1 if w is NULL):
+ *   [0] sum 1   then for q in (X, Y, O), base = 1 + 5*k:  [base] sum q0  [base+1] sum sq  [base+2] sum q0^2
+ *   [base+3] sum q0*sq  [base+4] sum sq^2                                                                        */
+int art_detector_scan_moments(const ArtDetectorDesc* d, const ArtBundleView* b, const double* w, int64_t n, double co,
+                              double* scratch, double* out32, void* stream);
+
 /* Masked reductions over alive rays, deterministic (fixed two-level tree, no float atomics).
  * out16 (DEVICE, 16 doubles):
  *   [0] count  [1] sum opl  [2] min X [3] max X [4] min Y [5] max Y  [6] sum X [7] sum Y

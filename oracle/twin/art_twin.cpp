@@ -71,6 +71,17 @@ int art_cpu_detector(const ArtDetectorDesc* d, const ArtBundleView* b, int64_t n
   return 0;
 }
 
+int art_cpu_detector_scan(const ArtDetectorDesc* d, const ArtBundleView* b, int64_t n, double* X, double* Y,
+                          double* O, double* sx, double* sy, double* so) {
+  for (int64_t i = 0; i < n; ++i) {
+    if (b->alive[i] == 0) continue;
+    art::Ray r;
+    load_ray(*b, i, r);
+    art::detector_ray_scan(*d, r, X[i], Y[i], O[i], sx[i], sy[i], so[i]);
+  }
+  return 0;
+}
+
 int art_cpu_make_source(int32_t kind, double size, const double* rot, const double* S, int64_t first, int64_t n,
                         int64_t n_total, const ArtBundleView* out) {
   for (int64_t i = 0; i < n; ++i) {

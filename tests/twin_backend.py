@@ -37,6 +37,9 @@ class TwinBackend:
         self.lib.art_cpu_detector.restype = C.c_int
         self.lib.art_cpu_detector.argtypes = [C.POINTER(_abi.ArtDetectorDesc), C.POINTER(_abi.ArtBundleView),
                                               C.c_int64] + [C.c_void_p] * 6
+        self.lib.art_cpu_detector_scan.restype = C.c_int
+        self.lib.art_cpu_detector_scan.argtypes = [C.POINTER(_abi.ArtDetectorDesc), C.POINTER(_abi.ArtBundleView),
+                                                   C.c_int64] + [C.c_void_p] * 6
         self.lib.art_cpu_make_source.restype = C.c_int
         self.lib.art_cpu_make_source.argtypes = [C.c_int32, C.c_double, _abi.c_double_p, _abi.c_double_p, C.c_int64,
                                                  C.c_int64, C.c_int64, C.POINTER(_abi.ArtBundleView)]
@@ -83,6 +86,23 @@ class TwinBackend:
         out[16:22] = [(ex ** 2).sum(), (ey ** 2).sum(), (eo ** 2).sum(), (ww * ex ** 2).sum(), (ww * ey ** 2).sum(),
                       (ww * eo ** 2).sum()]
         return out if to_host else torch.from_numpy(out)
+
+    def detector_scan_moments(self, ddesc, view, w, n, co):
+        arrs = [np.zeros(n) for _ in range(6)]
+        assert self.lib.art_cpu_detector_scan(C.byref(ddesc), C.byref(view), n, *[a.ctypes.data for a in arrs]) == 0
+        a = np.ctypeslib.as_array(C.cast(view.alive, C.POINTER(C.c_uint8)), shape=(max(n, 1),))[:n].astype(bool)
+        X, Y, O, sx, sy, so = (v[a] for v in arrs)
+        O = O - co
+        so = so - 1.0
+        ww = w.numpy()[a] if w is not None else np.ones(int(a.sum()))
+        out = np.zeros(32)
+        for base, wt in ((0, np.ones_like(ww)), (16, ww)):
+            out[base] = wt.sum()
+            for k, (q0, sq) in enumerate(((X, sx), (Y, sy), (O, so))):
+                o = base + 1 + 5 * k
+                out[o:o + 5] = [(wt * q0).sum(), (wt * sq).sum(), (wt * q0 * q0).sum(), (wt * q0 * sq).sum(),
+                                (wt * sq * sq).sum()]
+        return out
 
     @staticmethod
     def _np(t):
