@@ -78,11 +78,12 @@ def setup_detector(OpticalChain, DetectorOptions, RayList=None):
 def optimize_detector(RayListAnalysed, Detector, DetectorOptions, verbose=True, maxRaystoConsider=1000,
                       IntensityWeighted=False, Amplitude=None, Precision=3):
     """Autofocus (ARTmain.py:147-190).  The reference sub-samples `maxRaystoConsider` random rays to keep its
-    Python loops affordable; the scan runs on the GPU here, so the sub-sampling is kept only for parity of the
-    search (index sampling replaces np.random.choice on a list of Ray objects)."""
+    Python loops affordable; that is still honoured when a number is given (index sampling replaces
+    np.random.choice on a list of Ray objects), but `run_ART` passes None: the scan costs two passes over the bundle
+    on the GPU, so all rays are used and the result is deterministic."""
     rays = RayListAnalysed
     if maxRaystoConsider is not None and len(rays) > maxRaystoConsider:
-        rays = rays.subset(np.random.choice(len(rays), maxRaystoConsider, replace=False))
+        rays = rays.subset(np.random.default_rng().choice(len(rays), maxRaystoConsider, replace=False))
     det, spot, dur = mp.FindOptimalDistance(Detector, rays, DetectorOptions["OptFor"], Amplitude, Precision,
                                             IntensityWeighted, verbose)
     if verbose:
@@ -131,7 +132,7 @@ def run_ART(OpticalChain, SourceProperties, DetectorOptions, AnalysisOptions, lo
     Detector = setup_detector(OpticalChain, DetectorOptions, RayListAnalysed)
     if DetectorOptions["AutoDetectorDistance"]:
         Detector, SpotSizeSD, DurationSD = optimize_detector(RayListAnalysed, Detector, DetectorOptions,
-                                                             AnalysisOptions["verbose"], maxRaystoConsider=1000,
+                                                             AnalysisOptions["verbose"], maxRaystoConsider=None,
                                                              IntensityWeighted=True)
     else:
         SpotSizeSD, DurationSD = mplots.GetResultSummary(Detector, RayListAnalysed, AnalysisOptions["verbose"])

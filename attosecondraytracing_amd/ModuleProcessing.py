@@ -293,13 +293,14 @@ def WeightedStandardDeviation(List, Weights) -> float:
 
 
 def ReturnNumericalAperture(RayList, RefractiveIndex: float = 1) -> float:
-    """n sin(theta_max) about the central ray (ART/ModuleProcessing.py:536-566)."""
+    """n sin(theta_max) about the central ray (ART/ModuleProcessing.py:536-566); the max-angle reduction runs on
+    the device for bundles."""
     central = FindCentralRay(RayList).vector
-    V = RayList.vectors() if isinstance(RayList, RayBundle) else np.array([r.vector for r in RayList])
-    c = np.linalg.norm(central)
-    a = np.linalg.norm(V * c - central[None, :] * 1.0, axis=1)
-    b = np.linalg.norm(V * c + central[None, :] * 1.0, axis=1)
-    return float(np.sin(np.amax(2 * np.arctan2(a, b))) * RefractiveIndex)
+    if isinstance(RayList, RayBundle):
+        amax, _ = RayList.backend.bundle_max_angle(RayList.view(), central, RayList.n_slots)
+    else:
+        amax = max(mgeo.AngleBetweenTwoVectors(central, r.vector) for r in RayList)
+    return float(np.sin(amax) * RefractiveIndex)
 
 
 def ReturnAiryRadius(Wavelength: float, NumericalAperture: float) -> float:
@@ -337,7 +338,7 @@ def FindOptimalDistance(Detector, RayList, OptFor="intensity", Amplitude: float 
         raise NameError("I don`t recognize what you want to optimize the detector distance for. OptFor must be "
                         "either 'intensity', 'size' or 'duration'.")
     FirstDistance = Detector.get_distance()
-    SizeSpot = 2 * StandardDeviation(Detector.get_PointList2DCentre(RayList))
+    SizeSpot = 2 * Detector._spot_duration_from_moments(Detector._scan_moments(RayList), 0.0, False)[0]
     NumericalAperture = ReturnNumericalAperture(RayList, 1)
     if Amplitude is None:
         Amplitude = min(4 * np.ceil(SizeSpot / np.tan(np.arcsin(NumericalAperture))), FirstDistance)

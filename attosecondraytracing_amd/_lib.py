@@ -179,6 +179,17 @@ class HipBackend:
                    "art_gaussian_intensity")
         return w
 
+    def bundle_max_angle(self, view, axis, n):
+        """(largest angle to `axis`, largest |point|) over the alive rays; host floats."""
+        if n == 0:
+            return 0.0, 0.0
+        out = self.empty(2)
+        a = (C.c_double * 3)(*[float(v) for v in axis])
+        self.check(self.fn["art_bundle_max_angle"](C.byref(view), a, n, self._red_scratch().data_ptr(),
+                                                   out.data_ptr(), self.stream_ptr()), "art_bundle_max_angle")
+        o = out.cpu().numpy()
+        return float(o[0]), float(o[1])
+
     def compact(self, alive, n):
         """Returns (idx tensor int64 [count], count)."""
         if n == 0:

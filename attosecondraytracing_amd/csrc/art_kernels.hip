@@ -848,6 +848,30 @@ int art_gaussian_intensity(const ArtBundleView* bv, const double axis[3], double
   return ART_OK;
 }
 
+int art_bundle_max_angle(const ArtBundleView* bv, const double axis[3], int64_t n, double* scratch, double* out2,
+                         void* stream) {
+  if (!axis || !scratch || !out2) return fail(ART_ERR_BAD_ARG, "NULL argument");
+  if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    hipError_t e0 = hipMemsetAsync(out2, 0, 2 * sizeof(double), s);
+    if (e0 != hipSuccess) return fail_hip(e0, "hipMemsetAsync");
+    return ART_OK;
+  }
+  if (!view_ok(bv)) return fail(ART_ERR_BAD_ARG, "bundle view has a NULL array");
+  int64_t b = (n + kBlock - 1) / kBlock;
+  const int nb = (int)(b > kRedBlocks ? kRedBlocks : b);
+  const Axis3 ax = {axis[0], axis[1], axis[2]};
+  double* tmp = scratch + (int64_t)kRedBlocks * kSumSlots;   // 8 doubles: the folded partials
+  hipLaunchKernelGGL(k_gauss_max_partial, dim3(nb), dim3(kBlock), 0, s, *bv, ax, n, scratch);
+  hipLaunchKernelGGL(k_gauss_max_final, dim3(1), dim3(kBlock), 0, s, scratch, nb, tmp);
+  hipError_t e1 = hipMemcpyAsync(out2, tmp, 2 * sizeof(double), hipMemcpyDeviceToDevice, s);
+  if (e1 != hipSuccess) return fail_hip(e1, "hipMemcpyAsync");
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail_hip(err, "art_bundle_max_angle launch");
+  return ART_OK;
+}
+
 int64_t art_compact_scratch_ints(int64_t n) {
   const int64_t tiles = (n + kTile - 1) / kTile;
   // int32 counts [tiles] followed by int64 offsets [tiles] (8-byte aligned: round counts up to even)

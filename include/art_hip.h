@@ -204,6 +204,11 @@ int art_bundle_sums(const ArtBundleView* b, const double* w, int64_t n, double* 
 int art_gaussian_intensity(const ArtBundleView* b, const double axis[3], double fraction, int64_t n,
                            double* scratch, double* w_out, void* stream);
 
+/* Largest angle between `axis` and the direction of any alive ray, and largest |point| (ReturnNumericalAperture,
+ * ART/ModuleProcessing.py:536-566; also the first pass of art_gaussian_intensity).  out2: DEVICE, 2 doubles.          */
+int art_bundle_max_angle(const ArtBundleView* b, const double axis[3], int64_t n, double* scratch, double* out2,
+                         void* stream);
+
 /* Stable compaction: idx_out[j] = slot of the j-th alive ray (source order kept, as the reference's
  * survivor lists ModuleMirror.py:928-939), *count_out = number alive.  block_counts: DEVICE scratch of
  * art_compact_scratch_ints(n) int32.                                                                    */

@@ -163,6 +163,17 @@ class TwinBackend:
             w = np.exp(-2 * (d / d[a].max()) ** 2 * k)
         return torch.from_numpy(w)
 
+    def bundle_max_angle(self, view, axis, n):
+        def arr(ptr, ty=C.c_double):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ty)), shape=(n,))
+        a = arr(view.alive, C.c_uint8).astype(bool)
+        V = np.stack([arr(view.dx), arr(view.dy), arr(view.dz)], axis=1)[a]
+        P = np.stack([arr(view.ox), arr(view.oy), arr(view.oz)], axis=1)[a]
+        axis = np.asarray(axis, float)
+        u, v = np.linalg.norm(axis), np.linalg.norm(V, axis=1)[:, None]
+        ang = 2 * np.arctan2(np.linalg.norm(axis[None, :] * v - V * u, axis=1), np.linalg.norm(axis[None, :] * v + V * u, axis=1))
+        return (float(ang.max()), float(np.linalg.norm(P, axis=1).max())) if len(V) else (0.0, 0.0)
+
     def compact(self, alive, n):
         idx = torch.nonzero(alive, as_tuple=False).reshape(-1)
         return idx, int(idx.numel())
