@@ -33,18 +33,30 @@ def getETransmission(RayListIn, RayListOut) -> float:
 
 
 def GetResultSummary(Detector, RayListAnalysed, verbose=False):
-    """Spot-size and duration standard deviations at the detector (ART/ModuleAnalysisAndPlots.py:81-129)."""
-    P = Detector.get_PointList2DCentre(RayListAnalysed)
-    FocalSpotSizeSD = mp.StandardDeviation(P)
-    DelayList = Detector.get_Delays(RayListAnalysed)
-    DurationSD = mp.StandardDeviation(DelayList)
+    """Spot-size and duration standard deviations at the detector (ART/ModuleAnalysisAndPlots.py:81-129).
+    For a RayBundle everything is reduced on the device (moment sums + bounding box); no per-ray array is copied."""
+    if isinstance(RayListAnalysed, RayBundle):
+        from .ModuleDetector import LightSpeed
+        FocalSpotSizeSD, DurationSD = Detector._spot_duration_from_moments(Detector._scan_moments(RayListAnalysed),
+                                                                           0.0, False)
+        if verbose:
+            s = Detector.readout(RayListAnalysed, store=False)["stats"]
+            FocalSpotSize = max(s[3] - s[2], s[5] - s[4])
+            delay_range = (s[13] - s[12]) / LightSpeed * 1e15
+    else:
+        P = Detector.get_PointList2DCentre(RayListAnalysed)
+        FocalSpotSizeSD = mp.StandardDeviation(P)
+        DelayList = Detector.get_Delays(RayListAnalysed)
+        DurationSD = mp.StandardDeviation(DelayList)
+        if verbose:
+            FocalSpotSize = mgeo.DiameterPointList(P)
+            delay_range = max(DelayList) - min(DelayList)
     if verbose:
-        FocalSpotSize = mgeo.DiameterPointList(P)
         print("At the detector distance of " + "{:.3f}".format(Detector.get_distance()) + " mm we get:\n"
               + "Spatial std : " + "{:.3f}".format(FocalSpotSizeSD * 1e3) + " μm and min-max: "
               + "{:.3f}".format(FocalSpotSize * 1e3) + " μm\n"
               + "Temporal std : " + "{:.3e}".format(DurationSD) + " fs and min-max : "
-              + "{:.3e}".format(max(DelayList) - min(DelayList)) + " fs")
+              + "{:.3e}".format(delay_range) + " fs")
     return FocalSpotSizeSD, DurationSD
 
 
