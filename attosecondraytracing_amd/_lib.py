@@ -106,6 +106,12 @@ class HipBackend:
         self.check(self._timed(lambda: self.fn["art_trace_chain"](darr, m, C.byref(view_in), varr, n, sp)),
                    "art_trace_chain")
 
+    def transform_bundle(self, M, T, rotate_points, view_in, view_out, n):
+        m = (C.c_double * 9)(*[float(v) for v in np.asarray(M).reshape(9)])
+        t = (C.c_double * 3)(*[float(v) for v in np.asarray(T).reshape(3)])
+        self.check(self.fn["art_transform_bundle"](m, t, int(bool(rotate_points)), C.byref(view_in), C.byref(view_out),
+                                                   n, self.stream_ptr()), "art_transform_bundle")
+
     def detector(self, ddesc, view, n, p3=None, XY=None, opl=None):
         p = [t.data_ptr() for t in p3] if p3 is not None else [None, None, None]
         xy = [t.data_ptr() for t in XY] if XY is not None else [None, None]

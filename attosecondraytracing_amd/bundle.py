@@ -233,17 +233,12 @@ class RayBundle:
         return RayBundle(self.data, alive, self.number, self.intensity, self.wavelength, self.parent, self.backend)
 
     def transformed(self, M, T, rotate_points=True):
-        """Affine map of the whole bundle (scene-manipulation helper, not on the tracing path):
-        point' = M point + T (or point + T), vector' = M vector."""
-        M = torch.as_tensor(np.asarray(M, dtype=np.float64), device=self.backend.device)
-        Tt = torch.as_tensor(np.asarray(T, dtype=np.float64), device=self.backend.device)
-        data = self.data.clone()
-        if rotate_points:
-            data[0:3] = M @ self.data[0:3]
-        data[0:3] += Tt[:, None]
-        data[3:6] = M @ self.data[3:6]
-        return RayBundle(data, self.alive.clone(), self.number, self.intensity, self.wavelength, self.parent,
-                         self.backend)
+        """Affine map of the whole bundle on the device (art_transform_bundle): point' = M point + T (or
+        point + T), vector' = normalize(M vector).  Scene-manipulation helper, not on the tracing path."""
+        out = RayBundle.allocate(self.n_slots, like=self, backend=self.backend)
+        out.parent = self.parent
+        self.backend.transform_bundle(M, T, rotate_points, self.view(), out.view(), self.n_slots)
+        return out
 
     def copy(self):
         return RayBundle(self.data.clone(), self.alive.clone(), self.number, self.intensity, self.wavelength,

@@ -200,6 +200,27 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain(const ChainArgs a
   }
 }
 
+// ------------------------------------------------------------------------------------------- affine map
+__global__ __launch_bounds__(kBlock) void k_transform(const ArtDetectorDesc mt, const int rotate_points,
+                                                      const ArtBundleView in, const ArtBundleView out, const int64_t n) {
+  // mt.rot = M, mt.centre = T (ArtDetectorDesc reused as a POD carrier)
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    art::Ray r;
+    load_ray(in, i, r);
+    r.inc = in.incidence[i];
+    const uint8_t a = in.alive[i];
+    double px = r.ox, py = r.oy, pz = r.oz, vx, vy, vz;
+    if (rotate_points) art::mat3_apply(mt.rot, r.ox, r.oy, r.oz, px, py, pz);
+    art::mat3_apply(mt.rot, r.dx, r.dy, r.dz, vx, vy, vz);
+    const double inv = 1.0 / sqrt(art::dot3(vx, vy, vz, vx, vy, vz));   // Ray.vector setter
+    r.ox = px + mt.centre[0]; r.oy = py + mt.centre[1]; r.oz = pz + mt.centre[2];
+    r.dx = vx * inv; r.dy = vy * inv; r.dz = vz * inv;
+    store_ray(out, i, r);
+    out.alive[i] = a;
+  }
+}
+
 // ------------------------------------------------------------------------------------------- detector
 __global__ __launch_bounds__(kBlock) void k_detector(const ArtDetectorDesc d, const ArtBundleView b, const int64_t n,
                                                      double* p3x, double* p3y, double* p3z, double* X, double* Y,
@@ -721,6 +742,23 @@ int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundl
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_trace_chain launch");
+  return ART_OK;
+}
+
+int art_transform_bundle(const double M[9], const double T[3], int32_t rotate_points, const ArtBundleView* in,
+                         const ArtBundleView* out, int64_t n, void* stream) {
+  if (!M || !T) return fail(ART_ERR_BAD_ARG, "NULL matrix or translation");
+  if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
+  if (n == 0) return ART_OK;
+  if (!view_ok(in) || !view_ok(out)) return fail(ART_ERR_BAD_ARG, "bundle view has a NULL array");
+  ArtDetectorDesc mt;
+  memset(&mt, 0, sizeof(mt));
+  memcpy(mt.rot, M, 9 * sizeof(double));
+  memcpy(mt.centre, T, 3 * sizeof(double));
+  hipLaunchKernelGGL(k_transform, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, mt, (int)rotate_points, *in,
+                     *out, n);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail_hip(err, "art_transform_bundle launch");
   return ART_OK;
 }
 

@@ -145,6 +145,13 @@ int art_trace_element(const ArtElementDesc* e, const ArtBundleView* in, const Ar
 int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundleView* in,
                     const ArtBundleView* outs, int64_t n, void* stream);
 
+/* Rigid / affine map of a whole bundle: TranslationRayList, RotationRayList, RotationAroundAxisRayList
+ * (ART/ModuleGeometry.py:308-314, :372-391) -- used by the source (mis-)alignment helpers, not by tracing:
+ *   point' = (rotate_points ? M * point : point) + T,   vector' = normalize(M * vector);
+ * path, incidence and alive are copied.  M row-major.  `out` may alias `in`.                                        */
+int art_transform_bundle(const double M[9], const double T[3], int32_t rotate_points, const ArtBundleView* in,
+                         const ArtBundleView* out, int64_t n, void* stream);
+
 /* Detector read-out (ART/ModuleDetector.py:191-234, :272-275): for every alive ray
  *   I = IntersectionLinePlane (ModuleGeometry.py:48-57);  (X,Y) = first two components of rot*(I-centre);
  *   opl = |A - I| + path.  Any of p3x..p3z / X,Y / opl may be NULL to skip that output.               */

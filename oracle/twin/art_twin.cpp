@@ -82,6 +82,24 @@ int art_cpu_detector_scan(const ArtDetectorDesc* d, const ArtBundleView* b, int6
   return 0;
 }
 
+int art_cpu_transform_bundle(const double* M, const double* T, int32_t rotate_points, const ArtBundleView* in,
+                             const ArtBundleView* out, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) {
+    art::Ray r;
+    load_ray(*in, i, r);
+    r.inc = in->incidence[i];
+    double px = r.ox, py = r.oy, pz = r.oz, vx, vy, vz;
+    if (rotate_points) art::mat3_apply(M, r.ox, r.oy, r.oz, px, py, pz);
+    art::mat3_apply(M, r.dx, r.dy, r.dz, vx, vy, vz);
+    const double inv = 1.0 / sqrt(art::dot3(vx, vy, vz, vx, vy, vz));
+    r.ox = px + T[0]; r.oy = py + T[1]; r.oz = pz + T[2];
+    r.dx = vx * inv; r.dy = vy * inv; r.dz = vz * inv;
+    store_ray(*out, i, r);
+    out->alive[i] = in->alive[i];
+  }
+  return 0;
+}
+
 int art_cpu_make_source(int32_t kind, double size, const double* rot, const double* S, int64_t first, int64_t n,
                         int64_t n_total, const ArtBundleView* out) {
   for (int64_t i = 0; i < n; ++i) {

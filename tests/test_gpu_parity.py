@@ -264,3 +264,20 @@ def test_gpu_edge_cases(hip):
 def test_gpu_launch_chunking(hip, monkeypatch):
     import edge_cases
     edge_cases.run_chunking(monkeypatch.setenv)
+
+
+def test_gpu_source_misalignment_helpers(hip):
+    """shift_source / tilt_source (ART/ModuleOpticalChain.py:219-369) go through art_transform_bundle."""
+    import ART.ModuleOpticalChain as moc
+    scene, a = load_golden("c2_fxf_chain05")
+    chain = moc.OpticalChain(pc.source_bundle(a, scene), pc.build_elements(scene, a), "misalign")
+    p0, v0 = chain.source_rays.points(), chain.source_rays.vectors()
+    chain.shift_source(np.array([0.0, 0.0, 2.0]), 0.5)
+    assert np.abs(chain.source_rays.points() - (p0 + [0, 0, 0.5])).max() <= 1e-15
+    assert np.array_equal(chain.source_rays.vectors(), v0)
+    chain.tilt_source(np.array([0.0, 1.0, 0.0]), 0.1)
+    th = np.deg2rad(0.1)
+    Rm = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+    assert np.abs(chain.source_rays.vectors() - v0 @ Rm.T).max() <= 1e-15
+    assert np.abs(chain.source_rays.points() - (p0 + [0, 0, 0.5])).max() <= 1e-15     # tilt leaves origins alone
+    assert len(chain.get_output_rays()[-1]) > 0

@@ -66,6 +66,15 @@ class TwinBackend:
         varr = (_abi.ArtBundleView * m)(*vouts)
         assert self.lib.art_cpu_trace_chain(darr, m, C.byref(vin), varr, n) == 0
 
+    def transform_bundle(self, M, T, rotate_points, vin, vout, n):
+        m = (C.c_double * 9)(*[float(v) for v in np.asarray(M).reshape(9)])
+        t = (C.c_double * 3)(*[float(v) for v in np.asarray(T).reshape(3)])
+        f = self.lib.art_cpu_transform_bundle
+        f.restype = C.c_int
+        f.argtypes = [_abi.c_double_p, _abi.c_double_p, C.c_int32, C.POINTER(_abi.ArtBundleView),
+                      C.POINTER(_abi.ArtBundleView), C.c_int64]
+        assert f(m, t, int(bool(rotate_points)), C.byref(vin), C.byref(vout), n) == 0
+
     def detector(self, ddesc, view, n, p3=None, XY=None, opl=None):
         p = [t.data_ptr() for t in p3] if p3 is not None else [None, None, None]
         xy = [t.data_ptr() for t in XY] if XY is not None else [None, None]
