@@ -274,7 +274,7 @@ def test_gpu_source_misalignment_helpers(hip):
     p0, v0 = chain.source_rays.points(), chain.source_rays.vectors()
     chain.shift_source(np.array([0.0, 0.0, 2.0]), 0.5)
     assert np.abs(chain.source_rays.points() - (p0 + [0, 0, 0.5])).max() <= 1e-15
-    assert np.abs(chain.source_rays.vectors() - v0).max() <= 2e-16    # re-normalised like the Ray setter
+    assert np.abs(chain.source_rays.vectors() - v0).max() <= 5e-16    # re-normalised like the Ray setter
     chain.tilt_source(np.array([0.0, 1.0, 0.0]), 0.1)
     th = np.deg2rad(0.1)
     Rm = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
