@@ -15,7 +15,10 @@ from . import _abi
 from . import _lib
 from .ModuleOpticalRay import Ray
 
+import itertools
+
 ROW_OX, ROW_OY, ROW_OZ, ROW_DX, ROW_DY, ROW_DZ, ROW_PATH, ROW_INC = range(8)
+_SERIAL = itertools.count(1)   # identity of a bundle for change detection (id() values can be recycled)
 
 
 class RayBundle:
@@ -30,6 +33,7 @@ class RayBundle:
         self._index = None
         self._count = None
         self.version = 0              # bumped when the arrays are modified in place
+        self._serial = next(_SERIAL)
 
     # ------------------------------------------------------------------ backend / persistence
     @property
@@ -59,6 +63,7 @@ class RayBundle:
         self._backend = None
         self._index = None
         self._count = None
+        self._serial = next(_SERIAL)
 
     # ------------------------------------------------------------------ construction
     @classmethod
@@ -248,4 +253,4 @@ class RayBundle:
         return self.copy()
 
     def __hash__(self):
-        return hash((id(self.data), self.version))
+        return hash((self._serial, self.version))
