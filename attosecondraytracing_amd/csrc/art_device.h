@@ -383,29 +383,55 @@ ART_HD int torus_body_roots(double R, double r2, double rb, double Ax, double Ay
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Candidate bookkeeping of `_get_intersection`: KeepPositiveSolution (ModuleGeometry.py:110-120), the side-of-surface
+// rule and support test of each mirror class, then _IntersectionRayMirror (ModuleMirror.py:27-38) with ClosestPoint
+// (ModuleGeometry.py:138-147): one accepted candidate -> it, two -> the closer one (a strictly closer earlier
+// candidate wins, otherwise the later), none or more than two -> the ray is lost.  Written with selects so that the
+// roots can be folded in as they are found, without an indexed array.
+struct Candidates {
+  int cnt;
+  double best;
+};
+
+template <int KIND>
+ART_HD void consider(const ArtElementDesc& e, double Ax, double Ay, double Az, double ux, double uy, double uz,
+                     double t, bool valid, Candidates& c) {
+  if (!ART_WAVE_ANY(valid)) return;  // nothing to test in this wavefront (e.g. no entry root: origin inside the tube)
+  const double x = fma(t, ux, Ax), y = fma(t, uy, Ay), z = fma(t, uz, Az);
+  bool ok = valid && (t > 1e-12);
+  if (KIND == ART_SPHERE || KIND == ART_CYLINDER) ok = ok && (z < 0.0) && include_support(e.support_kind, e.sp, x, y);  // :175, :841
+  else if (KIND == ART_PARABOLA) ok = ok && include_support(e.support_kind, e.sp, x - e.centre[0], y - e.centre[1]);     // :344
+  else if (KIND == ART_ELLIPSOID) ok = ok && (z < 0.0) && include_support(e.support_kind, e.sp, x - e.centre[0], y - e.centre[1]);  // :678
+  else ok = ok && (z < -e.mp[0]) && include_support(e.support_kind, e.sp, x, y);                                           // :473
+  const bool take = ok && (c.cnt == 0 || !(c.best < t));
+  c.best = take ? t : c.best;
+  c.cnt += ok ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // `_get_intersection` of the undeformed optic in the optic frame.  A = origin, u = unit direction.
 // Returns hit and the ray parameter t (P = A + t u).
 template <int KIND>
 ART_HD bool intersect(const ArtElementDesc& e, double Ax, double Ay, double Az, double ux, double uy, double uz,
                       double& t_hit) {
-  const int sk = e.support_kind;
   if (KIND == ART_PLANE || KIND == ART_MASK) {
     // ModuleMirror.py:73-82 (t > 0, no epsilon) ; ModuleMask.py:51-61 (passes where the support is NOT hit)
     const double t = -Az / uz;
-    const bool inside = include_support(sk, e.sp, fma(t, ux, Ax), fma(t, uy, Ay));
+    const bool inside = include_support(e.support_kind, e.sp, fma(t, ux, Ax), fma(t, uy, Ay));
     t_hit = t;
     return (t > 0.0) && (KIND == ART_PLANE ? inside : !inside);
   }
-  double tc[4] = {0.0, 0.0, 0.0, 0.0};
-  int nroots = 0;
+  Candidates c = {0, 0.0};
   if (KIND == ART_TORUS) {
     const double R = e.mp[0], r = e.mp[1], r2 = r * r;
-    nroots = torus_body_roots<-1>(R, r2, R + r, Ax, Ay, Az, ux, uy, uz, tc[0], tc[1]);
+    double ta = 0.0, tb = 0.0;
+    int n = torus_body_roots<-1>(R, r2, R + r, Ax, Ay, Az, ux, uy, uz, ta, tb);
+    consider<KIND>(e, Ax, Ay, Az, ux, uy, uz, ta, n > 0, c);
+    consider<KIND>(e, Ax, Ay, Az, ux, uy, uz, tb, n > 1, c);
     if (r > R) {  // self-intersecting torus: the quartic's second factor has real roots too
-      double t2a = 0.0, t2b = 0.0;
-      const int n2 = torus_body_roots<+1>(R, r2, r - R, Ax, Ay, Az, ux, uy, uz, t2a, t2b);
-      if (n2 > 0) tc[nroots++] = t2a;
-      if (n2 > 1) tc[nroots++] = t2b;
+      n = torus_body_roots<+1>(R, r2, r - R, Ax, Ay, Az, ux, uy, uz, ta, tb);
+      consider<KIND>(e, Ax, Ay, Az, ux, uy, uz, ta, n > 0, c);
+      consider<KIND>(e, Ax, Ay, Az, ux, uy, uz, tb, n > 1, c);
     }
   } else {
     double qa, qb, qc;
@@ -428,32 +454,13 @@ ART_HD bool intersect(const ArtElementDesc& e, double Ax, double Ay, double Az, 
       qb = 2.0 * fma(uy, Ay, uz * Az);
       qc = fma(Ay, Ay, Az * Az) - e.mp[0] * e.mp[0];
     }
-    nroots = quadratic_roots(qa, qb, qc, tc[0], tc[1]);
+    double t1 = 0.0, t2 = 0.0;
+    const int n = quadratic_roots(qa, qb, qc, t1, t2);
+    consider<KIND>(e, Ax, Ay, Az, ux, uy, uz, t1, n > 0, c);
+    consider<KIND>(e, Ax, Ay, Az, ux, uy, uz, t2, n > 1, c);
   }
-  // KeepPositiveSolution (ModuleGeometry.py:110-120), side-of-surface rule and support test per class,
-  // then _IntersectionRayMirror (ModuleMirror.py:27-38): one candidate -> it, two -> the closer one,
-  // none or more than two -> the ray is lost.
-  int cnt = 0;
-  double best = 0.0;
-#pragma unroll
-  for (int k = 0; k < (KIND == ART_TORUS ? 4 : 2); ++k) {
-    if (k >= nroots) break;
-    const double t = tc[k];
-    if (!(t > 1e-12)) continue;
-    const double x = fma(t, ux, Ax), y = fma(t, uy, Ay), z = fma(t, uz, Az);
-    bool ok;
-    if (KIND == ART_SPHERE || KIND == ART_CYLINDER) ok = (z < 0.0) && include_support(sk, e.sp, x, y);      // :175, :841
-    else if (KIND == ART_PARABOLA) ok = include_support(sk, e.sp, x - e.centre[0], y - e.centre[1]);        // :344
-    else if (KIND == ART_ELLIPSOID) ok = (z < 0.0) && include_support(sk, e.sp, x - e.centre[0], y - e.centre[1]);  // :678
-    else ok = (z < -e.mp[0]) && include_support(sk, e.sp, x, y);                                              // :473
-    if (ok) {
-      // ClosestPoint (ModuleGeometry.py:138-147): strictly closer first candidate wins, otherwise the second
-      if (cnt == 0 || !(best < t)) best = t;
-      ++cnt;
-    }
-  }
-  t_hit = best;
-  return cnt == 1 || cnt == 2;
+  t_hit = c.best;
+  return c.cnt == 1 || c.cnt == 2;
 }
 
 // ---------------------------------------------------------------------------------------------------------
