@@ -281,3 +281,78 @@ def test_gpu_source_misalignment_helpers(hip):
     assert np.abs(chain.source_rays.vectors() - v0 @ Rm.T).max() <= 1e-15
     assert np.abs(chain.source_rays.points() - (p0 + [0, 0, 0.5])).max() <= 1e-15     # tilt leaves origins alone
     assert len(chain.get_output_rays()[-1]) > 0
+
+
+def _oracle_elements(chain):
+    """Oracle description of the product's elements (kinds, parameters, supports, Zernike defects, poses)."""
+    from oracle import art_oracle as orc
+    kinds = {0: "plane", 1: "sphere", 2: "parabola", 3: "torus", 4: "ellipsoid", 5: "cylinder", 6: "mask"}
+    sups = {0: "round", 1: "roundhole", 2: "rect", 3: "recthole", 4: "rectrecthole"}
+    els = []
+    for oe in chain.optical_elements:
+        o = oe.type
+        base = getattr(o, "Mirror", o)
+        kind = kinds[o._abi_kind]
+        params = {}
+        if kind in ("sphere", "cylinder"):
+            params = {"R": base.radius}
+        elif kind == "parabola":
+            params = {"feff": base.feff, "offaxis_rad": base.offaxisangle, "p": base.p}
+        elif kind == "torus":
+            params = {"R": base.majorradius, "r": base.minorradius}
+        elif kind == "ellipsoid":
+            params = {"a": base.a, "b": base.b, "offaxis_rad": base._offaxisangle}
+        defects = [orc.ZernikeDefect(dict(d.coefficients), d.R) for d in getattr(o, "DeformationList", [])]
+        els.append(orc.Element(orc.Optic(kind, orc.Support(sups[o.support._abi_kind], o.support._abi_params()), params,
+                                         defects, o.type), np.asarray(oe.position, float), oe.normal, oe.majoraxis))
+    return els
+
+
+@pytest.mark.parametrize("scene", ["c3", "mixed8", "c5_zernike"])
+def test_gpu_full_size_sampled_against_oracle(hip, scene):
+    """BASELINE sizes (1e7 / 1.25e7 rays): 20 000 randomly chosen slots of the full-size GPU run against the CPU
+    oracle tracing exactly those rays (rays are independent, so a slot-wise comparison is exact) -- catches
+    indexing, stride and launch-geometry errors that small cases cannot."""
+    import torch
+    import ART.ModuleProcessing as mp
+    from oracle import art_oracle as orc
+    sys_path = __import__("sys").path
+    root = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    if root not in sys_path:
+        sys_path.insert(0, root)
+    from tools import sweep
+    ignore = True
+    if scene == "c3":
+        chain = _c3_chain(10_000_000)
+        src = chain.source_rays
+    elif scene == "mixed8":
+        els, div = sweep.scene_mixed8(0)
+        src = sweep.point_source(12_500_000, div, hip)
+
+        class _C:  # minimal holder
+            optical_elements = els
+        chain = _C()
+    else:
+        class _C:
+            optical_elements = sweep.scene_c5(0, False)
+        chain = _C()
+        src = sweep.plane_source(10_000_000, 20.0, hip)
+        ignore = False
+    out = mp.RayTracingCalculation(src, chain.optical_elements, IgnoreDefects=ignore)
+    n = src.n_slots
+    rng = np.random.default_rng(123)
+    slots = np.sort(rng.choice(n, 20_000, replace=False))
+    st = torch.from_numpy(slots).to(hip.device)
+    host = src.data.index_select(1, st).cpu().numpy()
+    B = orc.make_bundle(host[0:3].T, host[3:6].T, slots, np.ones(len(slots)))
+    ref = orc.ray_tracing_calculation(B, _oracle_elements(chain), IgnoreDefects=ignore)
+    scale = 2000.0
+    for o, q in zip(out, ref):
+        alive = o.alive.index_select(0, st).cpu().numpy().astype(bool)
+        assert np.array_equal(slots[alive], q.number), "survivors differ on the sampled slots"
+        d = o.data.index_select(1, st).cpu().numpy()[:, alive]
+        assert np.abs(d[0:3].T - q.point).max() <= 1e-10 * scale
+        assert np.abs(d[3:6].T - q.vector).max() <= 1e-10
+        assert np.abs(d[6] - q.path.sum(axis=1)).max() <= 1e-10 * max(q.path.sum(axis=1).mean(), 1.0)
+        assert np.abs(d[7] - q.incidence).max() <= 1e-9
+    assert len(ref[-1]) > 5_000
