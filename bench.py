@@ -138,6 +138,11 @@ def main():
     if world != args.gpus and rank == 0:
         log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
 
+    if rank == 0 or not use_dist:
+        import __graft_entry__
+        __graft_entry__.ensure_built()       # no-op when libart_hip.so is up to date
+    if use_dist:
+        dist.barrier()
     from attosecondraytracing_amd import _lib, sharding
     import ART.ModuleProcessing as mp
     import ART.ModuleDetector as mdet

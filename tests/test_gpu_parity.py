@@ -14,8 +14,10 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def hip():
     import torch
+    import __graft_entry__
     from attosecondraytracing_amd import _lib
     assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    __graft_entry__.ensure_built()
     _lib._BACKEND = None
     be = _lib.get_backend()
     assert be.name == "hip"
