@@ -1,0 +1,78 @@
+"""GPU (-m gpu): two worker processes share the one GPU of the test box, each traces its index-range shard of a
+point source with the HIP kernels (source generated on the device from the global ray index), the read-out is
+staged to the host and exchanged over gloo (RCCL refuses two ranks on one device); the assembled result must equal
+the single-process run bit for bit.  Exercises the one-process-per-GPU code path end to end except RCCL itself."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as tmp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _trace_shard(rank, world, n_total):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.cuda.set_device(0)
+    from attosecondraytracing_amd import _lib, sharding, ModuleGeometry as mgeo
+    from attosecondraytracing_amd.bundle import RayBundle
+    import ART.ModuleProcessing as mp
+    import ART.ModuleDetector as mdet
+    from test_sharding_gloo import _scene
+    be = _lib.get_backend()
+    chain = _scene(n_total)
+    lo, hi = sharding.shard_range(n_total, rank, world)
+    src = RayBundle.allocate(hi - lo, backend=be)
+    rot = mgeo.rotation_matrix(np.array([0.0, 0.0, 1.0]), np.array([1.0, 0.0, 0.0]))
+    be.make_source(0, 0.025, rot, np.zeros(3), lo, hi - lo, n_total, src.view())
+    src.intensity = torch.ones(hi - lo, dtype=torch.float64, device=be.device)
+    out = mp.RayTracingCalculation(src, chain.optical_elements)
+    det = mdet.Detector(np.zeros(3), np.array([1900.0, 30.0, 0.0]), np.array([-0.9, -0.1, 0.2]))
+    r = det.readout(out[-1], sync=False)
+    return (torch.stack([r["X"], r["Y"], r["opl"]]).cpu(), out[-1].alive.cpu(), r["stats_dev"].cpu())
+
+
+def _worker(rank, world, port, n_total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from attosecondraytracing_amd import sharding
+        XYO, alive, stats = _trace_shard(rank, world, n_total)
+        g = sharding.allreduce_stats(stats, torch.device("cpu"))
+        full, al = sharding.gather_readout(XYO[0], XYO[1], XYO[2], alive, 0)
+        if rank == 0:
+            q.put((g.numpy(), full.numpy(), al.numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_one_gpu_match_single_process():
+    n_total = 200_003
+    ref_xyo, ref_alive, ref_stats = _trace_shard(0, 1, n_total)
+    ctx = tmp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 200)
+    procs = [ctx.Process(target=_worker, args=(rk, 2, port, n_total, q)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    stats, XYO, alive = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert np.array_equal(alive, ref_alive.numpy())
+    m = alive.astype(bool)
+    assert 0 < m.sum() < n_total
+    assert np.array_equal(XYO[:, m], ref_xyo.numpy()[:, m])
+    rs = ref_stats.numpy()
+    assert stats[0] == rs[0]
+    for k in (2, 3, 4, 5, 12, 13):
+        assert stats[k] == rs[k]
+    for k in (1, 6, 7, 8, 11):
+        assert abs(stats[k] - rs[k]) <= 1e-12 * abs(rs[k])
