@@ -76,6 +76,7 @@ PROTOTYPES = {
                                     C.c_int64, C.c_void_p]),
     "art_trace_chain": (C.c_int, [C.POINTER(ArtElementDesc), C.c_int32, C.POINTER(ArtBundleView),
                                   C.POINTER(ArtBundleView), C.c_int64, C.c_void_p]),
+    "art_pack_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(ArtBundleView), C.c_void_p]),
     "art_transform_bundle": (C.c_int, [c_double_p, c_double_p, C.c_int32, C.POINTER(ArtBundleView),
                                        C.POINTER(ArtBundleView), C.c_int64, C.c_void_p]),
     "art_detector": (C.c_int, [C.POINTER(ArtDetectorDesc), C.POINTER(ArtBundleView), C.c_int64, C.c_void_p,

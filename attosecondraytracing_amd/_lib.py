@@ -106,6 +106,11 @@ class HipBackend:
         self.check(self._timed(lambda: self.fn["art_trace_chain"](darr, m, C.byref(view_in), varr, n, sp)),
                    "art_trace_chain")
 
+    def pack_rays(self, points, vectors, path0, n, view):
+        self.check(self.fn["art_pack_rays"](points.data_ptr(), vectors.data_ptr(),
+                                            None if path0 is None else path0.data_ptr(), n, C.byref(view),
+                                            self.stream_ptr()), "art_pack_rays")
+
     def transform_bundle(self, M, T, rotate_points, view_in, view_out, n):
         m = (C.c_double * 9)(*[float(v) for v in np.asarray(M).reshape(9)])
         t = (C.c_double * 3)(*[float(v) for v in np.asarray(T).reshape(3)])

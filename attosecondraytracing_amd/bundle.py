@@ -86,21 +86,22 @@ class RayBundle:
 
     @classmethod
     def from_arrays(cls, point, vector, number=None, intensity=None, wavelength=None, path0=None, backend=None):
+        """Bundle from host (n,3) arrays: the two arrays are uploaded as they are and transposed to SoA and
+        normalised on the device (art_pack_rays)."""
         be = backend or _lib.get_backend()
         point = np.ascontiguousarray(point, dtype=np.float64).reshape(-1, 3)
         vector = np.ascontiguousarray(vector, dtype=np.float64).reshape(-1, 3)
-        vector = vector / np.linalg.norm(vector, axis=1)[:, None]          # Ray.vector setter
         n = point.shape[0]
-        host = np.empty((8, n), dtype=np.float64)
-        host[0:3] = point.T
-        host[3:6] = vector.T
-        host[6] = 0.0 if path0 is None else path0
-        host[7] = np.nan
-        data = be.from_numpy(host)
-        alive = torch.ones(n, dtype=torch.uint8, device=be.device)
-        num = None if number is None else be.from_numpy(np.asarray(number, dtype=np.int64))
-        inten = None if intensity is None else be.from_numpy(np.asarray(intensity, dtype=np.float64))
-        return cls(data, alive, num, inten, wavelength, None, be)
+        b = cls.allocate(n, backend=be)
+        if n > 0:
+            p0 = None
+            if path0 is not None:
+                p0 = be.from_numpy(np.broadcast_to(np.asarray(path0, dtype=np.float64), (n,)).copy())
+            be.pack_rays(be.from_numpy(point), be.from_numpy(vector), p0, n, b.view())
+        b.number = None if number is None else be.from_numpy(np.asarray(number, dtype=np.int64))
+        b.intensity = None if intensity is None else be.from_numpy(np.asarray(intensity, dtype=np.float64))
+        b.wavelength = wavelength
+        return b
 
     @classmethod
     def from_ray_list(cls, rays, backend=None):

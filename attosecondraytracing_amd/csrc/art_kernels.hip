@@ -200,6 +200,24 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain(const ChainArgs a
   }
 }
 
+// ------------------------------------------------------------------------------------------- AoS -> SoA
+__global__ __launch_bounds__(kBlock) void k_pack_rays(const double* __restrict__ points, const double* __restrict__ vectors,
+                                                      const double* __restrict__ path0, const int64_t n,
+                                                      const ArtBundleView out) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    art::Ray r;
+    r.ox = points[3 * i]; r.oy = points[3 * i + 1]; r.oz = points[3 * i + 2];
+    const double vx = vectors[3 * i], vy = vectors[3 * i + 1], vz = vectors[3 * i + 2];
+    const double inv = 1.0 / sqrt(art::dot3(vx, vy, vz, vx, vy, vz));
+    r.dx = vx * inv; r.dy = vy * inv; r.dz = vz * inv;
+    r.path = path0 ? path0[i] : 0.0;
+    r.inc = NAN;
+    store_ray(out, i, r);
+    out.alive[i] = 1;
+  }
+}
+
 // ------------------------------------------------------------------------------------------- affine map
 __global__ __launch_bounds__(kBlock) void k_transform(const ArtDetectorDesc mt, const int rotate_points,
                                                       const ArtBundleView in, const ArtBundleView out, const int64_t n) {
@@ -742,6 +760,18 @@ int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundl
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_trace_chain launch");
+  return ART_OK;
+}
+
+int art_pack_rays(const double* points, const double* vectors, const double* path0, int64_t n, const ArtBundleView* out,
+                  void* stream) {
+  if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
+  if (n == 0) return ART_OK;
+  if (!points || !vectors || !view_ok(out)) return fail(ART_ERR_BAD_ARG, "NULL argument");
+  hipLaunchKernelGGL(k_pack_rays, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, points, vectors, path0, n,
+                     *out);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail_hip(err, "art_pack_rays launch");
   return ART_OK;
 }
 

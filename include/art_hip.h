@@ -145,6 +145,12 @@ int art_trace_element(const ArtElementDesc* e, const ArtBundleView* in, const Ar
 int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundleView* in,
                     const ArtBundleView* outs, int64_t n, void* stream);
 
+/* Bundle from array-of-structs input (the layout a caller holding ART Ray lists / (n,3) NumPy arrays has):
+ * points[n][3], vectors[n][3] (DEVICE, row-major) -> SoA view; directions normalised like the Ray.vector setter
+ * (ART/ModuleOpticalRay.py:85-90), path = path0[i] (or 0 if NULL), incidence = NaN, alive = 1.                      */
+int art_pack_rays(const double* points, const double* vectors, const double* path0, int64_t n,
+                  const ArtBundleView* out, void* stream);
+
 /* Rigid / affine map of a whole bundle: TranslationRayList, RotationRayList, RotationAroundAxisRayList
  * (ART/ModuleGeometry.py:308-314, :372-391) -- used by the source (mis-)alignment helpers, not by tracing:
  *   point' = (rotate_points ? M * point : point) + T,   vector' = normalize(M * vector);

@@ -100,6 +100,22 @@ int art_cpu_transform_bundle(const double* M, const double* T, int32_t rotate_po
   return 0;
 }
 
+int art_cpu_pack_rays(const double* points, const double* vectors, const double* path0, int64_t n,
+                      const ArtBundleView* out) {
+  for (int64_t i = 0; i < n; ++i) {
+    art::Ray r;
+    r.ox = points[3 * i]; r.oy = points[3 * i + 1]; r.oz = points[3 * i + 2];
+    const double vx = vectors[3 * i], vy = vectors[3 * i + 1], vz = vectors[3 * i + 2];
+    const double inv = 1.0 / sqrt(art::dot3(vx, vy, vz, vx, vy, vz));
+    r.dx = vx * inv; r.dy = vy * inv; r.dz = vz * inv;
+    r.path = path0 ? path0[i] : 0.0;
+    r.inc = NAN;
+    store_ray(*out, i, r);
+    out->alive[i] = 1;
+  }
+  return 0;
+}
+
 int art_cpu_make_source(int32_t kind, double size, const double* rot, const double* S, int64_t first, int64_t n,
                         int64_t n_total, const ArtBundleView* out) {
   for (int64_t i = 0; i < n; ++i) {

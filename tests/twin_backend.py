@@ -66,6 +66,12 @@ class TwinBackend:
         varr = (_abi.ArtBundleView * m)(*vouts)
         assert self.lib.art_cpu_trace_chain(darr, m, C.byref(vin), varr, n) == 0
 
+    def pack_rays(self, points, vectors, path0, n, view):
+        f = self.lib.art_cpu_pack_rays
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(_abi.ArtBundleView)]
+        assert f(points.data_ptr(), vectors.data_ptr(), None if path0 is None else path0.data_ptr(), n, C.byref(view)) == 0
+
     def transform_bundle(self, M, T, rotate_points, vin, vout, n):
         m = (C.c_double * 9)(*[float(v) for v in np.asarray(M).reshape(9)])
         t = (C.c_double * 3)(*[float(v) for v in np.asarray(T).reshape(3)])
