@@ -150,7 +150,8 @@ ART_HD double kahan_angle_unit(double ux, double uy, double uz, double vx, doubl
   // tan(angle/2) = sqrt(a2/b2); evaluate atan on the ratio <= 1 and reflect for obtuse angles
   const double lo = fmin(a2, b2), hi = fmax(a2, b2);
   if (!(hi > 0.0)) return 0.0;
-  const double q = (lo > 0.0) ? lo * rsqrt_full(lo * hi) : 0.0;   // sqrt(lo/hi) = lo / sqrt(lo*hi)
+  // sqrt(lo/hi) = lo / sqrt(lo*hi); angles below ~1e-145 rad (lo in the denormal range) read as 0
+  const double q = (lo > 1e-290) ? lo * rsqrt_full(lo * hi) : 0.0;
   const double h = atan01(q);
   return (a2 <= b2) ? 2.0 * h : 3.14159265358979323846 - 2.0 * h;
 }
