@@ -37,6 +37,11 @@ def _truth_t(A, u, R, r, t0):
 
 @pytest.mark.parametrize("name", ["c2_fxf_chain05", "c3_twisted_chain04"])
 def test_torus_hit_distance_vs_long_double_truth(twin, name):
+    check_against_truth(name)
+
+
+def check_against_truth(name):
+    """Shared with the GPU suite (tests/test_gpu_parity.py), where the hardware-seeded 1/x, 1/sqrt(x) paths run."""
     import ART.ModuleProcessing as mp
     from attosecondraytracing_amd import ModuleGeometry as mgeo
     if np.finfo(LD).eps > 1e-18:

@@ -358,3 +358,10 @@ def test_gpu_full_size_sampled_against_oracle(hip, scene):
         assert np.abs(d[6] - q.path.sum(axis=1)).max() <= 1e-10 * max(q.path.sum(axis=1).mean(), 1.0)
         assert np.abs(d[7] - q.incidence).max() <= 1e-9
     assert len(ref[-1]) > 5_000
+
+
+@pytest.mark.parametrize("name", ["c2_fxf_chain05", "c3_twisted_chain04"])
+def test_gpu_torus_hit_distance_vs_long_double_truth(hip, name):
+    """The kernels' hardware-seeded reciprocal / rsqrt paths against an 80-bit truth (tests/test_accuracy_truth.py)."""
+    from test_accuracy_truth import check_against_truth
+    check_against_truth(name)
