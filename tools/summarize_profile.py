@@ -24,7 +24,13 @@ def short(name):
 def main():
     src, dst = sys.argv[1], sys.argv[2]
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 10_000_000
-    out = ["# rocprofv3 summary: " + os.path.basename(src), ""]
+    extra = sys.argv[4] if len(sys.argv) > 4 else "--steps 20 --warmup 5"
+    out = ["# rocprofv3 summary: " + os.path.basename(src), "",
+           "commands (tools/prof.sh; three separate runs of the same bench line, profiled runs are not the headline):", "```",
+           "rocprofv3 --kernel-trace --stats --output-format csv -d <out>/trace -- python3 bench.py --cpu-sample 0 " + extra,
+           "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <out>/pmc_fetch -- python3 bench.py --cpu-sample 0 " + extra,
+           "rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d <out>/pmc_write -- python3 bench.py --cpu-sample 0 " + extra,
+           "```", ""]
     bj = os.path.join(src, "bench_trace.json")
     if os.path.exists(bj):
         try:
