@@ -75,6 +75,21 @@ __device__ __forceinline__ void st_f64(__amdgpu_buffer_rsrc_t rs, unsigned off, 
   __builtin_memcpy(&d, &v, 8);
   __builtin_amdgcn_raw_buffer_store_b64(d, rs, (int)off, 0, 0);
 }
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+struct D2 { double a, b; };
+__device__ __forceinline__ D2 ld_2f64(__amdgpu_buffer_rsrc_t rs, unsigned off) {   // 16 B per lane: two consecutive slots
+  const v4i32 d = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+  D2 v;
+  __builtin_memcpy(&v, &d, 16);
+  return v;
+}
+__device__ __forceinline__ void st_2f64(__amdgpu_buffer_rsrc_t rs, unsigned off, double a, double b) {
+  D2 v = {a, b};
+  v4i32 d;
+  __builtin_memcpy(&d, &v, 16);
+  __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)off, 0, 0);
+}
+
 // slot index -> byte offsets; out-of-range slots (i >= n) fall outside every descriptor automatically
 __device__ __forceinline__ void load_slot(const BundleRsrc& b, int64_t i, art::Ray& r, uint8_t& alive) {
   const unsigned o1 = (unsigned)i, o8 = o1 * 8u;
@@ -292,6 +307,21 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NS], const int 
   }
 }
 
+// Final fold of per-block partials laid out [block][ns]: launched with ns blocks, block k folds slot k in a fixed
+// order (thread t takes partials t, t+256, ...; then the shuffle tree) — deterministic, and ns blocks work in
+// parallel instead of one block walking the whole table.
+__device__ __forceinline__ void fold_slot(const double* scratch, const int nblocks, const int ns, const int op_k,
+                                          double* out) {
+  const int k = blockIdx.x;
+  const int op[1] = {op_k};
+  double acc[1] = {(op_k == RSUM) ? 0.0 : (op_k == RMIN ? INFINITY : -INFINITY)};
+  for (int blk = threadIdx.x; blk < nblocks; blk += kBlock) {
+    const double v = scratch[(int64_t)blk * ns + k];
+    acc[0] = (op_k == RSUM) ? acc[0] + v : (op_k == RMIN ? fmin(acc[0], v) : fmax(acc[0], v));
+  }
+  block_reduce_store<1>(acc, op, out + k);
+}
+
 __global__ __launch_bounds__(kBlock) void k_stats_partial(const uint8_t* alive, const double* X, const double* Y,
                                                           const double* opl, const double* w, const int64_t n,
                                                           double* scratch) {
@@ -317,17 +347,7 @@ __global__ __launch_bounds__(kBlock) void k_stats_partial(const uint8_t* alive, 
 __global__ __launch_bounds__(kBlock) void k_stats_final(const double* scratch, const int nblocks, double* out) {
   const int ops[kRedSlots] = {RSUM, RSUM, RMIN, RMAX, RMIN, RMAX, RSUM, RSUM,
                               RSUM, RSUM, RSUM, RSUM, RMIN, RMAX, RSUM, RSUM};
-  double acc[kRedSlots];
-#pragma unroll
-  for (int k = 0; k < kRedSlots; ++k) acc[k] = (ops[k] == RSUM) ? 0.0 : (ops[k] == RMIN ? INFINITY : -INFINITY);
-  for (int b = threadIdx.x; b < nblocks; b += kBlock) {
-#pragma unroll
-    for (int k = 0; k < kRedSlots; ++k) {
-      const double v = scratch[(int64_t)b * kRedSlots + k];
-      acc[k] = (ops[k] == RSUM) ? acc[k] + v : (ops[k] == RMIN ? fmin(acc[k], v) : fmax(acc[k], v));
-    }
-  }
-  block_reduce_store<kRedSlots>(acc, ops, out);
+  fold_slot(scratch, nblocks, kRedSlots, ops[blockIdx.x], out);
 }
 
 constexpr int kSumSlots = 8;
@@ -344,26 +364,52 @@ __global__ __launch_bounds__(kBlock) void k_detector_readout(const ArtDetectorDe
   double acc[kReadoutSlots];
 #pragma unroll
   for (int k = 0; k < kReadoutSlots; ++k) acc[k] = (ops[k] == RSUM) ? 0.0 : (ops[k] == RMIN ? INFINITY : -INFINITY);
+  // Two consecutive slots per lane and iteration: every stream is read with one 16-byte access per lane (1 KiB per
+  // wave instruction) and the three outputs are written the same way; per-dword range checking of the raw buffer
+  // descriptors takes care of an odd tail.  Dead rays contribute nothing through selects (no divergent skip); their
+  // output slots receive unspecified values.
+  const BundleRsrc bi = make_rsrc(b, n);
+  const unsigned nb8 = (unsigned)(n * 8);
+  const __amdgpu_buffer_rsrc_t rw = rsrc_of(const_cast<double*>(w), w ? nb8 : 0u);
+  const __amdgpu_buffer_rsrc_t r3x = rsrc_of(p3x, p3x ? nb8 : 0u), r3y = rsrc_of(p3y, p3y ? nb8 : 0u),
+                               r3z = rsrc_of(p3z, p3z ? nb8 : 0u), rX = rsrc_of(X, X ? nb8 : 0u),
+                               rY = rsrc_of(Y, Y ? nb8 : 0u), rO = rsrc_of(opl, opl ? nb8 : 0u);
+  const int64_t npairs = (n + 1) / 2;
   const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    if (b.alive[i] == 0) continue;
-    art::Ray r;
-    load_ray(b, i, r);
-    double Ix, Iy, Iz, x, y, o;
-    art::detector_ray(d, r, Ix, Iy, Iz, x, y, o);
-    if (p3x) { p3x[i] = Ix; p3y[i] = Iy; p3z[i] = Iz; }
-    if (X) { X[i] = x; Y[i] = y; }
-    if (opl) opl[i] = o;
-    const double ww = w ? w[i] : 1.0;
-    acc[0] += 1.0; acc[1] += o;
-    acc[2] = fmin(acc[2], x); acc[3] = fmax(acc[3], x);
-    acc[4] = fmin(acc[4], y); acc[5] = fmax(acc[5], y);
-    acc[6] += x; acc[7] += y;
-    acc[8] += ww; acc[9] = fma(ww, x, acc[9]); acc[10] = fma(ww, y, acc[10]); acc[11] = fma(ww, o, acc[11]);
-    acc[12] = fmin(acc[12], o); acc[13] = fmax(acc[13], o);
-    const double ex = x - cx, ey = y - cy, eo = o - co;
-    acc[16] = fma(ex, ex, acc[16]); acc[17] = fma(ey, ey, acc[17]); acc[18] = fma(eo, eo, acc[18]);
-    acc[19] = fma(ww * ex, ex, acc[19]); acc[20] = fma(ww * ey, ey, acc[20]); acc[21] = fma(ww * eo, eo, acc[21]);
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < npairs; j += stride) {
+    const unsigned o16 = (unsigned)j * 16u, o2 = (unsigned)j * 2u;
+    const D2 ox = ld_2f64(bi.ox, o16), oy = ld_2f64(bi.oy, o16), oz = ld_2f64(bi.oz, o16);
+    const D2 dx = ld_2f64(bi.dx, o16), dy = ld_2f64(bi.dy, o16), dz = ld_2f64(bi.dz, o16);
+    const D2 pa = ld_2f64(bi.path, o16), wv = ld_2f64(rw, o16);
+    // two byte loads: a 16-bit load straddling the end of an odd-length array is dropped as a whole
+    const unsigned char al[2] = {__builtin_amdgcn_raw_buffer_load_b8(bi.alive, (int)o2, 0, 0),
+                                 __builtin_amdgcn_raw_buffer_load_b8(bi.alive, (int)o2 + 1, 0, 0)};
+    double xo[2], yo[2], oo[2], p3[3][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      art::Ray r;
+      r.ox = h ? ox.b : ox.a; r.oy = h ? oy.b : oy.a; r.oz = h ? oz.b : oz.a;
+      r.dx = h ? dx.b : dx.a; r.dy = h ? dy.b : dy.a; r.dz = h ? dz.b : dz.a;
+      r.path = h ? pa.b : pa.a;
+      const bool live = al[h] != 0;
+      double x, y, o;
+      art::detector_ray(d, r, p3[0][h], p3[1][h], p3[2][h], x, y, o);
+      xo[h] = x; yo[h] = y; oo[h] = o;
+      const double wi = h ? wv.b : wv.a;
+      const double ww = live ? (w ? wi : 1.0) : 0.0, one = live ? 1.0 : 0.0;
+      const double xs = live ? x : 0.0, ys = live ? y : 0.0, os = live ? o : 0.0;
+      acc[0] += one; acc[1] += os;
+      acc[2] = fmin(acc[2], live ? x : INFINITY); acc[3] = fmax(acc[3], live ? x : -INFINITY);
+      acc[4] = fmin(acc[4], live ? y : INFINITY); acc[5] = fmax(acc[5], live ? y : -INFINITY);
+      acc[6] += xs; acc[7] += ys;
+      acc[8] += ww; acc[9] = fma(ww, xs, acc[9]); acc[10] = fma(ww, ys, acc[10]); acc[11] = fma(ww, os, acc[11]);
+      acc[12] = fmin(acc[12], live ? o : INFINITY); acc[13] = fmax(acc[13], live ? o : -INFINITY);
+      const double ex = live ? x - cx : 0.0, ey = live ? y - cy : 0.0, eo = live ? o - co : 0.0;
+      acc[16] = fma(ex, ex, acc[16]); acc[17] = fma(ey, ey, acc[17]); acc[18] = fma(eo, eo, acc[18]);
+      acc[19] = fma(ww * ex, ex, acc[19]); acc[20] = fma(ww * ey, ey, acc[20]); acc[21] = fma(ww * eo, eo, acc[21]);
+    }
+    st_2f64(r3x, o16, p3[0][0], p3[0][1]); st_2f64(r3y, o16, p3[1][0], p3[1][1]); st_2f64(r3z, o16, p3[2][0], p3[2][1]);
+    st_2f64(rX, o16, xo[0], xo[1]); st_2f64(rY, o16, yo[0], yo[1]); st_2f64(rO, o16, oo[0], oo[1]);
   }
   block_reduce_store<kReadoutSlots>(acc, ops, scratch + (int64_t)blockIdx.x * kReadoutSlots);
 }
@@ -407,31 +453,13 @@ __global__ __launch_bounds__(kBlock) void k_scan_moments_partial(const ArtDetect
 }
 
 __global__ __launch_bounds__(kBlock) void k_scan_moments_final(const double* scratch, const int nblocks, double* out) {
-  double acc[kScanSlots];
-  int ops[kScanSlots];
-#pragma unroll
-  for (int k = 0; k < kScanSlots; ++k) { acc[k] = 0.0; ops[k] = RSUM; }
-  for (int blk = threadIdx.x; blk < nblocks; blk += kBlock) {
-#pragma unroll
-    for (int k = 0; k < kScanSlots; ++k) acc[k] += scratch[(int64_t)blk * kScanSlots + k];
-  }
-  block_reduce_store<kScanSlots>(acc, ops, out);
+  fold_slot(scratch, nblocks, kScanSlots, RSUM, out);
 }
 
 __global__ __launch_bounds__(kBlock) void k_readout_final(const double* scratch, const int nblocks, double* out) {
   const int ops[kReadoutSlots] = {RSUM, RSUM, RMIN, RMAX, RMIN, RMAX, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM,
                                   RMIN, RMAX, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM};
-  double acc[kReadoutSlots];
-#pragma unroll
-  for (int k = 0; k < kReadoutSlots; ++k) acc[k] = (ops[k] == RSUM) ? 0.0 : (ops[k] == RMIN ? INFINITY : -INFINITY);
-  for (int blk = threadIdx.x; blk < nblocks; blk += kBlock) {
-#pragma unroll
-    for (int k = 0; k < kReadoutSlots; ++k) {
-      const double v = scratch[(int64_t)blk * kReadoutSlots + k];
-      acc[k] = (ops[k] == RSUM) ? acc[k] + v : (ops[k] == RMIN ? fmin(acc[k], v) : fmax(acc[k], v));
-    }
-  }
-  block_reduce_store<kReadoutSlots>(acc, ops, out);
+  fold_slot(scratch, nblocks, kReadoutSlots, ops[blockIdx.x], out);
 }
 
 __global__ __launch_bounds__(kBlock) void k_moments_partial(const uint8_t* alive, const double* X, const double* Y,
@@ -470,13 +498,7 @@ __global__ __launch_bounds__(kBlock) void k_bundle_sums_partial(const ArtBundleV
 }
 
 __global__ __launch_bounds__(kBlock) void k_sums_final(const double* scratch, const int nblocks, double* out) {
-  const int ops[kSumSlots] = {RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM};
-  double acc[kSumSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int b = threadIdx.x; b < nblocks; b += kBlock) {
-#pragma unroll
-    for (int k = 0; k < kSumSlots; ++k) acc[k] += scratch[(int64_t)b * kSumSlots + k];
-  }
-  block_reduce_store<kSumSlots>(acc, ops, out);
+  fold_slot(scratch, nblocks, kSumSlots, RSUM, out);
 }
 
 // ------------------------------------------------------------------------------------------- source weights
@@ -822,11 +844,22 @@ int art_detector_readout(const ArtDetectorDesc* d, const ArtBundleView* b, const
     return ART_OK;
   }
   if (!view_ok(b)) return fail(ART_ERR_BAD_ARG, "bundle view has a NULL array");
-  // 2048 workgroups of partials: scratch must hold 2048 * 24 doubles (art_reduce_scratch_doubles covers it)
-  const int nb = grid_for(n);
-  hipLaunchKernelGGL(k_detector_readout, dim3(nb), dim3(kBlock), 0, s, *d, *b, w, n, cx, cy, co, p3x, p3y, p3z, X, Y,
-                     opl, scratch);
-  hipLaunchKernelGGL(k_readout_final, dim3(1), dim3(kBlock), 0, s, scratch, nb, out24);
+  // one launch per <= 2^28 rays (32-bit buffer offsets); every launch leaves one partial per workgroup, all of
+  // them folded by the final kernel: scratch holds up to 8 launches x 2048 workgroups x 24 doubles
+  const int64_t chunk = max_rays_per_launch();
+  if ((n + chunk - 1) / chunk > 8) return fail(ART_ERR_UNSUPPORTED, "more than 2^31 rays in one read-out");
+  int nb_total = 0;
+  for (int64_t off = 0; off < n; off += chunk) {
+    const int64_t m = (n - off < chunk) ? n - off : chunk;
+    const int nb = grid_for(m);
+    const ArtBundleView v = view_at(*b, off);
+    hipLaunchKernelGGL(k_detector_readout, dim3(nb), dim3(kBlock), 0, s, *d, v, w ? w + off : nullptr, m, cx, cy, co,
+                       p3x ? p3x + off : nullptr, p3y ? p3y + off : nullptr, p3z ? p3z + off : nullptr,
+                       X ? X + off : nullptr, Y ? Y + off : nullptr, opl ? opl + off : nullptr,
+                       scratch + (int64_t)nb_total * kReadoutSlots);
+    nb_total += nb;
+  }
+  hipLaunchKernelGGL(k_readout_final, dim3(kReadoutSlots), dim3(kBlock), 0, s, scratch, nb_total, out24);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_detector_readout launch");
   return ART_OK;
@@ -846,13 +879,13 @@ int art_detector_scan_moments(const ArtDetectorDesc* d, const ArtBundleView* b, 
   int64_t nbk = (n + kBlock - 1) / kBlock;
   const int nb = (int)(nbk > kRedBlocks ? kRedBlocks : nbk);
   hipLaunchKernelGGL(k_scan_moments_partial, dim3(nb), dim3(kBlock), 0, s, *d, *b, w, n, co, scratch);
-  hipLaunchKernelGGL(k_scan_moments_final, dim3(1), dim3(kBlock), 0, s, scratch, nb, out32);
+  hipLaunchKernelGGL(k_scan_moments_final, dim3(kScanSlots), dim3(kBlock), 0, s, scratch, nb, out32);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_detector_scan_moments launch");
   return ART_OK;
 }
 
-int64_t art_reduce_scratch_doubles(void) { return (int64_t)kMaxBlocks * kReadoutSlots + 64; }
+int64_t art_reduce_scratch_doubles(void) { return (int64_t)8 * kMaxBlocks * kReadoutSlots + 64; }
 
 int art_detector_stats(const uint8_t* alive, const double* X, const double* Y, const double* opl, const double* w,
                        int64_t n, double* scratch, double* out16, void* stream) {
@@ -862,7 +895,7 @@ int art_detector_stats(const uint8_t* alive, const double* X, const double* Y, c
   int64_t b = (n + kBlock - 1) / kBlock;
   const int nb = (int)(b < 1 ? 1 : (b > kRedBlocks ? kRedBlocks : b));
   hipLaunchKernelGGL(k_stats_partial, dim3(nb), dim3(kBlock), 0, s, alive, X, Y, opl, w, n, scratch);
-  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(kBlock), 0, s, scratch, nb, out16);
+  hipLaunchKernelGGL(k_stats_final, dim3(kRedSlots), dim3(kBlock), 0, s, scratch, nb, out16);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_detector_stats launch");
   return ART_OK;
@@ -876,7 +909,7 @@ int art_detector_moments(const uint8_t* alive, const double* X, const double* Y,
   int64_t b = (n + kBlock - 1) / kBlock;
   const int nb = (int)(b < 1 ? 1 : (b > kRedBlocks ? kRedBlocks : b));
   hipLaunchKernelGGL(k_moments_partial, dim3(nb), dim3(kBlock), 0, s, alive, X, Y, opl, w, n, cx, cy, co, scratch);
-  hipLaunchKernelGGL(k_sums_final, dim3(1), dim3(kBlock), 0, s, scratch, nb, out8);
+  hipLaunchKernelGGL(k_sums_final, dim3(kSumSlots), dim3(kBlock), 0, s, scratch, nb, out8);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_detector_moments launch");
   return ART_OK;
@@ -889,7 +922,7 @@ int art_bundle_sums(const ArtBundleView* bv, const double* w, int64_t n, double*
   int64_t b = (n + kBlock - 1) / kBlock;
   const int nb = (int)(b < 1 ? 1 : (b > kRedBlocks ? kRedBlocks : b));
   hipLaunchKernelGGL(k_bundle_sums_partial, dim3(nb), dim3(kBlock), 0, s, *bv, w, n, scratch);
-  hipLaunchKernelGGL(k_sums_final, dim3(1), dim3(kBlock), 0, s, scratch, nb, out8);
+  hipLaunchKernelGGL(k_sums_final, dim3(kSumSlots), dim3(kBlock), 0, s, scratch, nb, out8);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_bundle_sums launch");
   return ART_OK;

@@ -89,3 +89,26 @@ def run_chunking(setenv):
             assert np.array_equal(o.alive.cpu().numpy(), q.alive.cpu().numpy())
             assert np.array_equal(o.points(), q.points()) and np.array_equal(o.paths_total(), q.paths_total())
         assert 0 < len(out[-1]) < 5000
+
+
+def run_readout_chunking(setenv):
+    """The fused detector read-out split over several launches gives the same statistics and per-ray outputs."""
+    import ART.ModuleDetector as mdet
+    oe = _plane_element(4.0)
+    b = _bundle(5000, 4)
+    out = mp.RayTracingCalculation(b, [oe])[0]
+    det = mdet.Detector(np.zeros(3), np.array([0.3, -0.2, 20.0]), np.array([0.05, 0.02, -1.0]))
+    r0 = det.readout(out, points3d=True)
+    setenv("ART_MAX_RAYS_PER_LAUNCH", "1024")
+    r1 = det.readout(out, points3d=True)
+    m = out.alive.cpu().numpy().astype(bool)
+    for k in ("X", "Y", "opl"):
+        assert np.array_equal(r0[k].cpu().numpy()[m], r1[k].cpu().numpy()[m])
+    for p, q in zip(r0["P3"], r1["P3"]):
+        assert np.array_equal(p.cpu().numpy()[m], q.cpu().numpy()[m])
+    s0, s1 = r0["stats"], r1["stats"]
+    assert s0[0] == s1[0] == m.sum()
+    for k in (2, 3, 4, 5, 12, 13):
+        assert s0[k] == s1[k]
+    for k in (1, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 20, 21):
+        assert abs(s0[k] - s1[k]) <= 1e-12 * max(abs(s0[k]), 1e-300)

@@ -266,6 +266,7 @@ def test_gpu_edge_cases(hip):
 def test_gpu_launch_chunking(hip, monkeypatch):
     import edge_cases
     edge_cases.run_chunking(monkeypatch.setenv)
+    edge_cases.run_readout_chunking(monkeypatch.setenv)
 
 
 def test_gpu_source_misalignment_helpers(hip):
