@@ -2,9 +2,9 @@
 
 Point sources and plane-wave disks are generated on the GPU from the ray index (Vogel spiral,
 `art_make_source`) and so are the Gaussian intensity weights (`art_gaussian_intensity`: max-angle reduction +
-weights, nothing returns to the host).  ExtendedSource is (vectorised) host NumPy, then uploaded."""
+weights, nothing returns to the host).  ExtendedSource: `art_make_extended_source`."""
 import numpy as np
-import torch
+
 
 from . import _lib
 from . import ModuleGeometry as mgeo
@@ -39,19 +39,18 @@ def PlaneWaveDisk(Centre, Axis, Radius: float, NbRays: int, Wavelength=None):
 
 
 def ExtendedSource(S, Axis, Diameter: float, Divergence: float, NbRays: int, Wavelength=None):
-    """Disk of point sources (ART/ModuleSource.py:85-131), numbering included."""
+    """Disk of point sources (ART/ModuleSource.py:85-131), numbering included: ray number = point source index *
+    rays per point source + index within the cone, generated on the device from that number."""
     n_src = min(max(30, int(250 * Diameter)), int(NbRays / 300))
-    XY = mgeo.SpiralVogel(n_src, Diameter / 2)
     per = max(300, int(NbRays / n_src))
-    cone = mgeo.SpiralVogel(per, np.tan(Divergence))
-    vec = np.concatenate([cone, np.ones((per, 1))], axis=1)
-    vec /= np.linalg.norm(vec, axis=1)[:, None]
-    pts = np.repeat(np.concatenate([XY, np.zeros((n_src, 1))], axis=1), per, axis=0)
-    vecs = np.tile(vec, (n_src, 1))
-    M = mgeo.rotation_matrix(_EZ, np.asarray(Axis, dtype=float))
-    pts = pts @ M.T + np.asarray(S, dtype=float)
-    vecs = vecs @ M.T
-    return RayBundle.from_arrays(pts, vecs, np.arange(n_src * per), None, Wavelength)
+    be = _lib.get_backend()
+    b = RayBundle.allocate(n_src * per, backend=be)
+    b.wavelength = Wavelength
+    b.number = None
+    rot = mgeo.rotation_matrix(_EZ, np.asarray(Axis, dtype=float))
+    be.make_extended_source(Diameter / 2, Divergence, n_src, per, rot, np.asarray(S, dtype=float), 0, n_src * per,
+                            b.view())
+    return b
 
 
 def ApplyGaussianIntensityToRayList(RayList, IntensityFraction=1 / np.e ** 2):

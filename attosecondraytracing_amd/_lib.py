@@ -220,6 +220,13 @@ class HipBackend:
         self.check(self.fn["art_make_source"](kind, float(size), r, s, first, n, n_total, C.byref(view),
                                               self.stream_ptr()), "art_make_source")
 
+    def make_extended_source(self, radius, divergence, n_points, per, rot, S, first, n, view):
+        r = (C.c_double * 9)(*[float(v) for v in np.asarray(rot).reshape(9)])
+        s = (C.c_double * 3)(*[float(v) for v in np.asarray(S).reshape(3)])
+        self.check(self.fn["art_make_extended_source"](float(radius), float(divergence), int(n_points), int(per), r, s,
+                                                       first, n, C.byref(view), self.stream_ptr()),
+                   "art_make_extended_source")
+
 
 def get_backend():
     """The process-wide backend; created on first use, raises loudly if the HIP path is unavailable."""

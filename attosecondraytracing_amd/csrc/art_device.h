@@ -592,29 +592,48 @@ ART_HD void detector_ray_scan(const ArtDetectorDesc& d, const Ray& r, double& X,
 
 // ---------------------------------------------------------------------------------------------------------
 // Sources (ART/ModuleSource.py:23-81, :135-169; SpiralVogel ART/ModuleGeometry.py:61-76) for ray index k
-ART_HD void source_ray(int kind, double size, const double* rot, const double* S, int64_t k, int64_t n_total,
-                       Ray& r) {
+ART_HD void vogel_point(int64_t k, int64_t n_total, double radius, double& x, double& y) {
   const double golden = 3.14159265358979323846 * (3.0 - sqrt(5.0));
-  const double radius = (kind == 0) ? tan(size) : size;  // _Cone: Height = 1, Radius = tan(Angle)
   const double rr = sqrt((double)k / (double)n_total) * radius;
   const double theta = golden * (double)k;
-  const double x = cos(theta) * rr, y = sin(theta) * rr;
-  double px, py, pz, vx, vy, vz;
-  if (kind == 0) {
-    px = py = pz = 0.0;
-    const double inv = 1.0 / sqrt(fma(x, x, fma(y, y, 1.0)));
-    vx = x * inv; vy = y * inv; vz = inv;
-  } else {
-    px = x; py = y; pz = 0.0;
-    vx = 0.0; vy = 0.0; vz = 1.0;
-  }
+  x = cos(theta) * rr;
+  y = sin(theta) * rr;
+}
+
+// (px,py,0) + direction (vx,vy,vz) in the source frame -> lab frame
+ART_HD void source_place(const double* rot, const double* S, double px, double py, double vx, double vy, double vz,
+                         Ray& r) {
   double ox, oy, oz, dx, dy, dz;
-  mat3_apply(rot, px, py, pz, ox, oy, oz);
+  mat3_apply(rot, px, py, 0.0, ox, oy, oz);
   mat3_apply(rot, vx, vy, vz, dx, dy, dz);
   r.ox = ox + S[0]; r.oy = oy + S[1]; r.oz = oz + S[2];
   r.dx = dx; r.dy = dy; r.dz = dz;
   r.path = 0.0;
   r.inc = NAN;
+}
+
+ART_HD void source_ray(int kind, double size, const double* rot, const double* S, int64_t k, int64_t n_total,
+                       Ray& r) {
+  double x, y;
+  vogel_point(k, n_total, (kind == 0) ? tan(size) : size, x, y);  // _Cone: Height = 1, Radius = tan(Angle)
+  if (kind == 0) {
+    const double inv = 1.0 / sqrt(fma(x, x, fma(y, y, 1.0)));
+    source_place(rot, S, 0.0, 0.0, x * inv, y * inv, inv, r);
+  } else {
+    source_place(rot, S, x, y, 0.0, 0.0, 1.0, r);
+  }
+}
+
+// ExtendedSource (ART/ModuleSource.py:85-131): `n_points` point sources on a Vogel disk of radius `radius`, each
+// emitting the same cone of `per` rays; ray number = point * per + ray-in-cone (:124-127).
+ART_HD void source_ray_extended(double radius, double divergence, int64_t n_points, int64_t per, const double* rot,
+                                const double* S, int64_t k, Ray& r) {
+  const int64_t point = k / per, l = k - point * per;
+  double px, py, x, y;
+  vogel_point(point, n_points, radius, px, py);
+  vogel_point(l, per, tan(divergence), x, y);
+  const double inv = 1.0 / sqrt(fma(x, x, fma(y, y, 1.0)));
+  source_place(rot, S, px, py, x * inv, y * inv, inv, r);
 }
 
 }  // namespace art

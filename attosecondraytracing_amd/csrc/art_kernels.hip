@@ -642,6 +642,19 @@ __global__ __launch_bounds__(kBlock) void k_make_source(const int32_t kind, cons
   }
 }
 
+__global__ __launch_bounds__(kBlock) void k_make_extended_source(const double radius, const double divergence,
+                                                                 const int64_t n_points, const int64_t per,
+                                                                 const ArtDetectorDesc rs, const int64_t first,
+                                                                 const int64_t n, const ArtBundleView out) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    art::Ray r;
+    art::source_ray_extended(radius, divergence, n_points, per, rs.rot, rs.centre, first + i, r);
+    store_ray(out, i, r);
+    out.alive[i] = 1;
+  }
+}
+
 // rays per launch: the hardware limit, or less when ART_MAX_RAYS_PER_LAUNCH is set (lets tests cover the chunking)
 int64_t max_rays_per_launch() {
   const char* v = getenv("ART_MAX_RAYS_PER_LAUNCH");
@@ -1025,6 +1038,24 @@ int art_make_source(int32_t kind, double size, const double rot[9], const double
                      n_total, *out);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_make_source launch");
+  return ART_OK;
+}
+
+int art_make_extended_source(double radius, double divergence, int64_t n_points, int64_t rays_per_point,
+                             const double rot[9], const double S[3], int64_t first, int64_t n,
+                             const ArtBundleView* out, void* stream) {
+  if (!rot || !S || !view_ok(out)) return fail(ART_ERR_BAD_ARG, "NULL argument");
+  if (n_points <= 0 || rays_per_point <= 0) return fail(ART_ERR_BAD_ARG, "n_points and rays_per_point must be > 0");
+  if (n < 0 || first < 0 || first + n > n_points * rays_per_point) return fail(ART_ERR_BAD_ARG, "bad index range");
+  if (n == 0) return ART_OK;
+  ArtDetectorDesc rs;
+  memset(&rs, 0, sizeof(rs));
+  memcpy(rs.rot, rot, 9 * sizeof(double));
+  memcpy(rs.centre, S, 3 * sizeof(double));
+  hipLaunchKernelGGL(k_make_extended_source, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, radius,
+                     divergence, n_points, rays_per_point, rs, first, n, *out);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail_hip(err, "art_make_extended_source launch");
   return ART_OK;
 }
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ART_ABI_VERSION 4
+#define ART_ABI_VERSION 5
 
 /* error codes */
 #define ART_OK 0
@@ -236,6 +236,14 @@ int art_compact(const uint8_t* alive, int64_t n, int32_t* block_counts, int64_t*
  * Writes origin, direction, path = 0, incidence = NaN, alive = 1.                                        */
 int art_make_source(int32_t kind, double size, const double rot[9], const double S[3], int64_t first,
                     int64_t n, int64_t n_total, const ArtBundleView* out, void* stream);
+
+/* ExtendedSource (ART/ModuleSource.py:85-131): n_points point sources on a Vogel disk of radius `radius` (mm), each
+ * emitting the same Vogel cone of rays_per_point rays with half-angle `divergence` (rad).  Global ray index
+ * k = point * rays_per_point + ray-in-cone, the reference's numbering (:124-127); writes indices [first, first+n).
+ * The caller derives n_points and rays_per_point from NbRays as the reference does (:111-119).               */
+int art_make_extended_source(double radius, double divergence, int64_t n_points, int64_t rays_per_point,
+                             const double rot[9], const double S[3], int64_t first, int64_t n,
+                             const ArtBundleView* out, void* stream);
 
 #ifdef __cplusplus
 }

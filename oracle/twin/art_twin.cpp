@@ -127,4 +127,15 @@ int art_cpu_make_source(int32_t kind, double size, const double* rot, const doub
   return 0;
 }
 
+int art_cpu_make_extended_source(double radius, double divergence, int64_t n_points, int64_t per, const double* rot,
+                                 const double* S, int64_t first, int64_t n, const ArtBundleView* out) {
+  for (int64_t i = 0; i < n; ++i) {
+    art::Ray r;
+    art::source_ray_extended(radius, divergence, n_points, per, rot, S, first + i, r);
+    store_ray(*out, i, r);
+    out->alive[i] = 1;
+  }
+  return 0;
+}
+
 }  // extern "C"

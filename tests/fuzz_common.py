@@ -1,0 +1,135 @@
+"""Differential fuzzing: random single-element scenes traced by the product (CPU twin or GPU) and by the pinned CPU
+oracle.  The golden fixtures cover the shipped configurations; this covers the parameter space between them: every
+optic kind, every aperture kind, arbitrary poses, sources inside and outside the optic's body, footprints that
+overfill the aperture.  Tolerances are those of the parity tests (survivors exact, 1e-10 relative).
+
+Scene dictionaries use the schema of the golden fixtures, so both `oracle.elements_from_scene` and
+`parity_common.build_elements` accept them."""
+import numpy as np
+
+from oracle import art_oracle as orc
+import parity_common as pc
+from attosecondraytracing_amd.bundle import RayBundle
+
+KINDS = ["plane", "sphere_cc", "sphere_cx", "cylinder_cc", "cylinder_cx", "parabola", "torus", "torus_steep",
+         "ellipsoid", "mask"]
+TYPE = {"plane": "Plane Mirror", "sphere_cc": "SphericalCC Mirror", "sphere_cx": "SphericalCX Mirror",
+        "cylinder_cc": "CylindricalCC Mirror", "cylinder_cx": "CylindricalCX Mirror", "parabola": "Parabolic Mirror",
+        "torus": "Toroidal Mirror", "torus_steep": "Toroidal Mirror", "ellipsoid": "Ellipsoidal Mirror",
+        "mask": "Mask"}
+
+
+def random_support(rng, size):
+    k = rng.choice(["round", "roundhole", "rect", "recthole", "rectrecthole"])
+    if k == "round":
+        return {"kind": k, "p": [size]}
+    if k == "roundhole":
+        return {"kind": k, "p": [size, size * rng.uniform(0.1, 0.4), size * rng.uniform(-0.3, 0.3),
+                                 size * rng.uniform(-0.3, 0.3)]}
+    X, Y = 2 * size, 2 * size * rng.uniform(0.3, 1.0)
+    if k == "rect":
+        return {"kind": k, "p": [X, Y]}
+    if k == "recthole":
+        return {"kind": k, "p": [X, Y, 0.2 * Y * rng.uniform(0.3, 1.0), X * rng.uniform(-0.2, 0.2),
+                                 Y * rng.uniform(-0.2, 0.2)]}
+    return {"kind": k, "p": [X, Y, X * rng.uniform(0.1, 0.4), Y * rng.uniform(0.1, 0.4), X * rng.uniform(-0.2, 0.2),
+                             Y * rng.uniform(-0.2, 0.2)]}
+
+
+def random_scene(seed, n_rays=1500):
+    """One optic of a random kind in a random pose + a cone of rays aimed at it.  Returns (scene, arrays)."""
+    rng = np.random.default_rng(seed)
+    kind = KINDS[seed % len(KINDS)]
+    size = float(rng.uniform(8.0, 40.0))
+    e = {"kind": kind.split("_")[0], "type": TYPE[kind], "support": random_support(rng, size)}
+    if kind.startswith("sphere") or kind.startswith("cylinder"):
+        e["R"] = float(rng.uniform(4 * size, 3000.0))
+    elif kind == "parabola":
+        e["feff"] = float(rng.uniform(3 * size, 600.0))
+        e["offaxis_rad"] = float(np.deg2rad(rng.uniform(5.0, 120.0)))
+        e["p"] = e["feff"] * (1 + np.cos(e["offaxis_rad"]))
+    elif kind == "torus":
+        e["r"] = float(rng.uniform(3 * size, 500.0))
+        e["R"] = float(rng.uniform(1.2 * e["r"], 9000.0))
+    elif kind == "torus_steep":      # minor radius larger than the major one: the quartic's second factor has roots
+        e["R"] = float(rng.uniform(3 * size, 300.0))
+        e["r"] = float(e["R"] * rng.uniform(1.2, 3.0))
+    elif kind == "ellipsoid":
+        while True:   # some (a, b, angle) have no surface point under that angle: the reference's centre is NaN
+            e["a"] = float(rng.uniform(300.0, 900.0))
+            e["b"] = float(e["a"] * rng.uniform(0.35, 0.9))
+            e["offaxis_rad"] = float(np.deg2rad(rng.uniform(40.0, 130.0)))
+            with np.errstate(invalid="ignore"):
+                if np.isfinite(orc.ellipsoid_centre(e["a"], e["b"], e["offaxis_rad"])).all():
+                    break
+    O = orc.optic_from_desc(e)
+    e["centre"] = [float(v) for v in O.centre()]
+    # pose: arbitrary position and orientation
+    pos = rng.uniform(-500.0, 500.0, 3)
+    normal = rng.normal(size=3)
+    normal /= np.linalg.norm(normal)
+    major = np.cross(normal, rng.normal(size=3))
+    major /= np.linalg.norm(major)
+    e["position"], e["normal"], e["majoraxis"] = pos.tolist(), normal.tolist(), major.tolist()
+    # source: distance d from the element's position, chief ray at `theta` from the normal, cone wide enough to
+    # overfill the aperture in part of the trials
+    theta = np.deg2rad(rng.uniform(0.0, 80.0))
+    phi = rng.uniform(0.0, 2 * np.pi)
+    cross = np.cross(normal, major)
+    w = np.cos(theta) * normal + np.sin(theta) * (np.cos(phi) * major + np.sin(phi) * cross)
+    d = float(rng.uniform(60.0, 1200.0))
+    S = pos + d * w
+    div = float(rng.uniform(0.3, 1.6) * size * max(np.cos(theta), 0.25) / d)
+    B = orc.point_source(S, -w, div, n_rays)
+    # jitter the origins so that they are not all one point (exercises per-ray origins in the transforms)
+    B.point = B.point + rng.normal(scale=0.05 * size, size=B.point.shape)
+    scene = {"elements": [e], "n_source": n_rays, "IgnoreDefects": True}
+    arrays = {"src_point": B.point, "src_vector": B.vector, "src_number": B.number,
+              "src_intensity": np.full(n_rays, np.nan)}
+    return scene, arrays
+
+
+GRAZING = 1.5   # rad (86 deg): beyond it the hit point is ill-conditioned (error amplified by 1/cos(incidence))
+
+
+def run_differential(seeds, modes=("chain", "element"), n_rays=1500):
+    """Trace every seeded scene with the active product backend and with the oracle.  Survivor indices must agree
+    for every ray; positions / directions / paths / incidence within the parity tolerances for every ray whose
+    incidence is below GRAZING (for tangential rays both answers lie on the surface to 1e-15 but apart along the
+    ray: the reference's np.roots and the kernels' solvers are both at the conditioning limit there).
+    Returns the worst errors and how many scenes produced hits."""
+    import ART.ModuleProcessing as mp
+    worst = {"pos": 0.0, "dir": 0.0, "path": 0.0, "inc": 0.0}
+    hits = 0
+    for seed in seeds:
+        scene, a = random_scene(seed, n_rays)
+        e = scene["elements"][0]
+        tag = f"seed {seed} ({e['type']}, {e['support']['kind']})"
+        src_o = orc.make_bundle(a["src_point"], a["src_vector"], a["src_number"], a["src_intensity"], None)
+        ref = orc.ray_tracing_calculation(src_o, orc.elements_from_scene(scene), IgnoreDefects=True)[0]
+        hits += int(len(ref) > 0)
+        scale = pc.scene_scale(a, scene)
+        # a hit-point difference dP (allowed: REL_TOL * scale) turns the normal by dP / rc, the reflected direction by
+        # twice that: on strongly curved optics the direction tolerance follows from the position tolerance
+        rc = {"sphere": e.get("R"), "cylinder": e.get("R"), "torus": e.get("r"), "parabola": e.get("p"),
+              "ellipsoid": (e.get("b", 0) ** 2 / e["a"]) if "a" in e else None}.get(e["kind"])
+        dir_tol = pc.REL_TOL * max(1.0, 2 * scale / rc) if rc else pc.REL_TOL
+        els = pc.build_elements(scene)
+        src = RayBundle.from_arrays(a["src_point"], a["src_vector"], a["src_number"], None, None)
+        for mode in modes:
+            out = mp.RayTracingCalculation(src, els, IgnoreDefects=True, mode=mode)[0]
+            assert np.array_equal(out.numbers(), ref.number), f"{tag}, mode {mode}: survivor indices differ"
+            m = ref.incidence < GRAZING
+            if not m.any():
+                continue
+            mean_path = max(float(np.mean(np.sum(ref.path[m], axis=1))), 1.0)
+            err = {"pos": np.abs(out.points() - ref.point)[m].max() / scale,
+                   "dir": np.abs(out.vectors() - ref.vector)[m].max(),
+                   "path": max(np.abs(out.paths_total() - np.sum(ref.path, axis=1))[m].max(),
+                               np.abs(out.path_segments() - ref.path)[m].max()) / mean_path,
+                   "inc": np.abs(out.incidences() - ref.incidence)[m].max()}
+            for key, v in err.items():
+                tol = {"inc": max(1e-9, dir_tol), "dir": dir_tol}.get(key, pc.REL_TOL)
+                assert v <= tol, f"{tag}, mode {mode}: {key} error {v:.3e} > {tol:.1e}"
+                worst[key] = max(worst[key], float(v))
+    return {"worst": worst, "scenes_with_hits": hits, "scenes": len(list(seeds))}

@@ -1,0 +1,21 @@
+"""CPU (-m "not gpu"): random scenes, product host shell + CPU twin of the kernels against the pinned oracle
+(tests/fuzz_common.py).  The GPU run of the same scenes is tests/test_gpu_parity.py::test_gpu_fuzz_differential."""
+import pytest
+
+import fuzz_common as fz
+
+
+@pytest.fixture(scope="module")
+def twin():
+    from twin_backend import TwinBackend
+    from attosecondraytracing_amd import _lib
+    old = _lib._BACKEND
+    _lib._BACKEND = TwinBackend()
+    yield _lib._BACKEND
+    _lib._BACKEND = old
+
+
+@pytest.mark.parametrize("block", range(6))
+def test_fuzz_twin_vs_oracle(twin, block):
+    res = fz.run_differential(range(block * 20, block * 20 + 20))
+    assert res["scenes_with_hits"] >= 12, res   # the generator must actually exercise the optics

@@ -196,6 +196,25 @@ def test_gpu_sources_match_oracle(hip):
     assert np.abs(b.intensities() - q.intensity).max() <= 1e-10
 
 
+def test_gpu_extended_source_matches_reference(hip):
+    """ExtendedSource on the device (art_make_extended_source) against the reference's list, numbering included."""
+    import ART.ModuleSource as msource
+    _, a = load_golden("geometry_units")
+    b = msource.ExtendedSource(np.array([0.0, 0.0, 0.0]), np.array([1.0, 0.0, 0.0]), 0.1, 0.02, 9000)
+    b = msource.ApplyGaussianIntensityToRayList(b, 1 / np.e ** 2)
+    assert np.array_equal(b.numbers(), a["src_extended_number"])
+    assert np.abs(b.points() - a["src_extended_point"]).max() <= 1e-12
+    assert np.abs(b.vectors() - a["src_extended_vector"]).max() <= 1e-13
+    assert np.abs(b.intensities() - a["src_extended_intensity"]).max() <= 1e-11
+
+
+def test_gpu_fuzz_differential(hip):
+    """300 random scenes (every optic x aperture kind, arbitrary poses) on the GPU against the pinned oracle."""
+    import fuzz_common as fz
+    res = fz.run_differential(range(300))
+    assert res["scenes_with_hits"] >= 250, res
+
+
 def test_gpu_error_paths(hip):
     """Bad arguments come back as error codes with a message, never as a crash."""
     import ctypes as C

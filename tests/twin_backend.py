@@ -43,6 +43,10 @@ class TwinBackend:
         self.lib.art_cpu_make_source.restype = C.c_int
         self.lib.art_cpu_make_source.argtypes = [C.c_int32, C.c_double, _abi.c_double_p, _abi.c_double_p, C.c_int64,
                                                  C.c_int64, C.c_int64, C.POINTER(_abi.ArtBundleView)]
+        self.lib.art_cpu_make_extended_source.restype = C.c_int
+        self.lib.art_cpu_make_extended_source.argtypes = [C.c_double, C.c_double, C.c_int64, C.c_int64,
+                                                          _abi.c_double_p, _abi.c_double_p, C.c_int64, C.c_int64,
+                                                          C.POINTER(_abi.ArtBundleView)]
 
     def synchronize(self):
         pass
@@ -197,3 +201,9 @@ class TwinBackend:
         r = (C.c_double * 9)(*[float(v) for v in np.asarray(rot).reshape(9)])
         s = (C.c_double * 3)(*[float(v) for v in np.asarray(S).reshape(3)])
         assert self.lib.art_cpu_make_source(kind, float(size), r, s, first, n, n_total, C.byref(view)) == 0
+
+    def make_extended_source(self, radius, divergence, n_points, per, rot, S, first, n, view):
+        r = (C.c_double * 9)(*[float(v) for v in np.asarray(rot).reshape(9)])
+        s = (C.c_double * 3)(*[float(v) for v in np.asarray(S).reshape(3)])
+        assert self.lib.art_cpu_make_extended_source(float(radius), float(divergence), int(n_points), int(per), r, s,
+                                                     first, n, C.byref(view)) == 0
