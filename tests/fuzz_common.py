@@ -36,10 +36,8 @@ def random_support(rng, size):
                              Y * rng.uniform(-0.2, 0.2)]}
 
 
-def random_scene(seed, n_rays=1500):
-    """One optic of a random kind in a random pose + a cone of rays aimed at it.  Returns (scene, arrays)."""
-    rng = np.random.default_rng(seed)
-    kind = KINDS[seed % len(KINDS)]
+def random_optic(rng, kind):
+    """Scene-dictionary entry of one optic of the given kind with random parameters and aperture (no pose yet)."""
     size = float(rng.uniform(8.0, 40.0))
     e = {"kind": kind.split("_")[0], "type": TYPE[kind], "support": random_support(rng, size)}
     if kind.startswith("sphere") or kind.startswith("cylinder"):
@@ -64,29 +62,68 @@ def random_scene(seed, n_rays=1500):
                     break
     O = orc.optic_from_desc(e)
     e["centre"] = [float(v) for v in O.centre()]
-    # pose: arbitrary position and orientation
-    pos = rng.uniform(-500.0, 500.0, 3)
-    normal = rng.normal(size=3)
-    normal /= np.linalg.norm(normal)
+    return e, size, O
+
+
+def random_pose(rng, e, pos, towards, theta):
+    """Orient optic `e` at `pos` so that the unit vector `towards` (pointing from the optic to where the light comes
+    from) makes the angle theta with its normal; the roll about the normal is random."""
+    t = rng.normal(size=3)
+    t -= np.dot(t, towards) * towards
+    t /= np.linalg.norm(t)
+    normal = np.cos(theta) * towards + np.sin(theta) * t
     major = np.cross(normal, rng.normal(size=3))
     major /= np.linalg.norm(major)
     e["position"], e["normal"], e["majoraxis"] = pos.tolist(), normal.tolist(), major.tolist()
+
+
+def random_scene(seed, n_rays=1500):
+    """One or two optics of random kinds in random poses + a cone of rays aimed at the first.  The second optic (every
+    other block of seeds) sits on the reflected / transmitted chief ray.  Returns (scene, arrays)."""
+    rng = np.random.default_rng(seed)
+    kind = KINDS[seed % len(KINDS)]
+    e, size, O = random_optic(rng, kind)
+    deformed = (seed // len(KINDS)) % 3 == 0 and e["kind"] != "mask"
+    if deformed:   # DeformedMirror with 1-2 Zernike defects, traced with IgnoreDefects=False
+        e["defects"] = []
+        for _ in range(int(rng.integers(1, 3))):
+            coeffs = []
+            for _ in range(int(rng.integers(1, 6))):
+                n = int(rng.integers(1, 9))
+                coeffs.append([n, int(rng.integers(0, n + 1)), float(rng.uniform(-1.0, 1.0) * 2e-4)])
+            e["defects"].append({"kind": "zernike", "coeffs": coeffs, "R": O.support.circum_circ()})
     # source: distance d from the element's position, chief ray at `theta` from the normal, cone wide enough to
     # overfill the aperture in part of the trials
+    pos = rng.uniform(-500.0, 500.0, 3)
+    w = rng.normal(size=3)
+    w /= np.linalg.norm(w)
     theta = np.deg2rad(rng.uniform(0.0, 80.0))
-    phi = rng.uniform(0.0, 2 * np.pi)
-    cross = np.cross(normal, major)
-    w = np.cos(theta) * normal + np.sin(theta) * (np.cos(phi) * major + np.sin(phi) * cross)
+    random_pose(rng, e, pos, w, theta)
     d = float(rng.uniform(60.0, 1200.0))
     S = pos + d * w
     div = float(rng.uniform(0.3, 1.6) * size * max(np.cos(theta), 0.25) / d)
     B = orc.point_source(S, -w, div, n_rays)
     # jitter the origins so that they are not all one point (exercises per-ray origins in the transforms)
     B.point = B.point + rng.normal(scale=0.05 * size, size=B.point.shape)
-    scene = {"elements": [e], "n_source": n_rays, "IgnoreDefects": True}
+    elements = [e]
+    if (seed // (3 * len(KINDS))) % 2 == 1:
+        # second optic on the chief ray after the first (if the chief ray survives it)
+        chief = orc.make_bundle(S[None, :], -w[None, :], np.array([0]), np.array([np.nan]), None)
+        after = orc.ray_tracing_calculation(chief, orc.elements_from_scene({"elements": [e]}), IgnoreDefects=True)[0]
+        if len(after) == 1:
+            e2, _, _ = random_optic(rng, KINDS[int(rng.integers(0, len(KINDS)))])
+            pos2 = after.point[0] + float(rng.uniform(50.0, 800.0)) * after.vector[0]
+            random_pose(rng, e2, pos2, -after.vector[0], np.deg2rad(rng.uniform(0.0, 75.0)))
+            elements.append(e2)
+    scene = {"elements": elements, "n_source": n_rays, "IgnoreDefects": not deformed}
     arrays = {"src_point": B.point, "src_vector": B.vector, "src_number": B.number,
               "src_intensity": np.full(n_rays, np.nan)}
     return scene, arrays
+
+
+def curvature_radius(e):
+    return {"sphere": e.get("R"), "cylinder": e.get("R"), "torus": e.get("r"), "parabola": e.get("p"),
+            "ellipsoid": (e.get("b", 0) ** 2 / e["a"]) if "a" in e else None}.get(e["kind"])
 
 
 GRAZING = 1.5   # rad (86 deg): beyond it the hit point is ill-conditioned (error amplified by 1/cos(incidence))
@@ -94,42 +131,48 @@ GRAZING = 1.5   # rad (86 deg): beyond it the hit point is ill-conditioned (erro
 
 def run_differential(seeds, modes=("chain", "element"), n_rays=1500):
     """Trace every seeded scene with the active product backend and with the oracle.  Survivor indices must agree
-    for every ray; positions / directions / paths / incidence within the parity tolerances for every ray whose
-    incidence is below GRAZING (for tangential rays both answers lie on the surface to 1e-15 but apart along the
-    ray: the reference's np.roots and the kernels' solvers are both at the conditioning limit there).
-    Returns the worst errors and how many scenes produced hits."""
+    for every ray after every element; positions / directions / paths / incidence within the parity tolerances for
+    every ray that met no optic above GRAZING incidence (for tangential rays both answers lie on the surface to
+    1e-15 but apart along the ray: the reference's np.roots and the kernels' solvers are both at the conditioning
+    limit there).  Returns the worst errors and how many scenes produced hits on their last element."""
     import ART.ModuleProcessing as mp
     worst = {"pos": 0.0, "dir": 0.0, "path": 0.0, "inc": 0.0}
     hits = 0
     for seed in seeds:
         scene, a = random_scene(seed, n_rays)
-        e = scene["elements"][0]
-        tag = f"seed {seed} ({e['type']}, {e['support']['kind']})"
+        tag = f"seed {seed} (" + " -> ".join(
+            f"{e['type']}{' + Zernike' if e.get('defects') else ''} [{e['support']['kind']}]" for e in scene["elements"]) + ")"
         src_o = orc.make_bundle(a["src_point"], a["src_vector"], a["src_number"], a["src_intensity"], None)
-        ref = orc.ray_tracing_calculation(src_o, orc.elements_from_scene(scene), IgnoreDefects=True)[0]
-        hits += int(len(ref) > 0)
+        refs = orc.ray_tracing_calculation(src_o, orc.elements_from_scene(scene), IgnoreDefects=scene["IgnoreDefects"])
+        hits += int(len(refs[-1]) > 0)
         scale = pc.scene_scale(a, scene)
-        # a hit-point difference dP (allowed: REL_TOL * scale) turns the normal by dP / rc, the reflected direction by
-        # twice that: on strongly curved optics the direction tolerance follows from the position tolerance
-        rc = {"sphere": e.get("R"), "cylinder": e.get("R"), "torus": e.get("r"), "parabola": e.get("p"),
-              "ellipsoid": (e.get("b", 0) ** 2 / e["a"]) if "a" in e else None}.get(e["kind"])
-        dir_tol = pc.REL_TOL * max(1.0, 2 * scale / rc) if rc else pc.REL_TOL
         els = pc.build_elements(scene)
         src = RayBundle.from_arrays(a["src_point"], a["src_vector"], a["src_number"], None, None)
         for mode in modes:
-            out = mp.RayTracingCalculation(src, els, IgnoreDefects=True, mode=mode)[0]
-            assert np.array_equal(out.numbers(), ref.number), f"{tag}, mode {mode}: survivor indices differ"
-            m = ref.incidence < GRAZING
-            if not m.any():
-                continue
-            mean_path = max(float(np.mean(np.sum(ref.path[m], axis=1))), 1.0)
-            err = {"pos": np.abs(out.points() - ref.point)[m].max() / scale,
-                   "dir": np.abs(out.vectors() - ref.vector)[m].max(),
-                   "path": max(np.abs(out.paths_total() - np.sum(ref.path, axis=1))[m].max(),
-                               np.abs(out.path_segments() - ref.path)[m].max()) / mean_path,
-                   "inc": np.abs(out.incidences() - ref.incidence)[m].max()}
-            for key, v in err.items():
-                tol = {"inc": max(1e-9, dir_tol), "dir": dir_tol}.get(key, pc.REL_TOL)
-                assert v <= tol, f"{tag}, mode {mode}: {key} error {v:.3e} > {tol:.1e}"
-                worst[key] = max(worst[key], float(v))
+            outs = mp.RayTracingCalculation(src, els, IgnoreDefects=scene["IgnoreDefects"], mode=mode)
+            well = np.ones(n_rays, dtype=bool)      # per source ray: no grazing hit so far
+            dir_tol = pc.REL_TOL
+            for k, (out, ref, e) in enumerate(zip(outs, refs, scene["elements"])):
+                assert np.array_equal(out.numbers(), ref.number), f"{tag}, mode {mode}: survivors differ after {k}"
+                well[ref.number[ref.incidence >= GRAZING]] = False
+                # a hit-point difference dP (allowed: REL_TOL * scale) turns the normal by dP / rc, the reflected
+                # direction by twice that: on strongly curved optics the direction tolerance follows from the
+                # position tolerance (and carries over to the elements downstream)
+                rc = curvature_radius(e)
+                if rc:
+                    dir_tol = max(dir_tol, pc.REL_TOL * 2 * scale / rc)
+                pos_tol = pc.REL_TOL if k == 0 else max(pc.REL_TOL, dir_tol)   # lever arm <= scene scale
+                m = well[ref.number]
+                if not m.any():
+                    continue
+                mean_path = max(float(np.mean(np.sum(ref.path[m], axis=1))), 1.0)
+                err = {"pos": np.abs(out.points() - ref.point)[m].max() / scale,
+                       "dir": np.abs(out.vectors() - ref.vector)[m].max(),
+                       "path": max(np.abs(out.paths_total() - np.sum(ref.path, axis=1))[m].max(),
+                                   np.abs(out.path_segments() - ref.path)[m].max()) / mean_path,
+                       "inc": np.abs(out.incidences() - ref.incidence)[m].max()}
+                tols = {"pos": pos_tol, "dir": dir_tol, "path": pos_tol, "inc": max(1e-9, dir_tol)}
+                for key, v in err.items():
+                    assert v <= tols[key], f"{tag}, mode {mode}, element {k}: {key} error {v:.3e} > {tols[key]:.1e}"
+                    worst[key] = max(worst[key], float(v))
     return {"worst": worst, "scenes_with_hits": hits, "scenes": len(list(seeds))}
