@@ -342,19 +342,35 @@ ART_HD bool torus_newton(double R, double r2, double Ax, double Ay, double Az, d
 }
 
 // Positive-side roots (entry, exit) of the line with one of the two convex bodies; `rb` = radius of a sphere
-// about the origin that contains the body (R + r for K, r - R for L).  Returns the number of roots found.
+// about the origin that contains the body (R + r for K, sqrt(r^2 - R^2) for L).  Returns the number of roots found.
+// SIDE = -1 uses a tighter start than the bounding sphere: the oblate spheroid  rho^2/(R+r)^2 + y^2/(r(R+r)) = 1
+// contains K [squaring  (R+r) sqrt(1 - y^2/(r(R+r))) >= R + sqrt(r^2 - y^2)  leaves (R/r)(r - sqrt(r^2-y^2))^2 >= 0]
+// and osculates the outer half-tube along the equator: the gap is of 4th order in y, so for a mirror (rays a few mm
+// to cm off the equatorial plane, r ~ 100s of mm) Newton starts within ~1e-2 mm of the root and needs 2 steps where
+// the bounding sphere needed 4.  `ia2` = 1/(R+r)^2, `ic2` = 1/(r(R+r)) (prepare_element()).
 template <int SIDE>
-ART_HD int torus_body_roots(double R, double r2, double rb, double Ax, double Ay, double Az, double ux, double uy,
-                            double uz, double& ta, double& tb) {
-  // |u| = 1: t^2 + 2 hb t + c = 0.  Only starting points are needed, so a single-precision sqrt is enough; the
-  // miss test keeps a safety margin for it.
-  const double hb = dot3(Ax, Ay, Az, ux, uy, uz);
-  const double c = dot3(Ax, Ay, Az, Ax, Ay, Az) - rb * rb;
-  const double disc = fma(hb, hb, -c);
-  bool any = disc >= -1e-6 * rb * rb;
+ART_HD int torus_body_roots(double R, double r2, double rb, double ia2, double ic2, double Ax, double Ay, double Az,
+                            double ux, double uy, double uz, double& ta, double& tb) {
+  // bounding quadric  qa t^2 + 2 hb t + c = 0.  Only starting points are needed, so a single-precision sqrt is
+  // enough; the miss test keeps a safety margin for it.
+  double qa, hb, c, iqa;
+  if (SIDE < 0) {
+    qa = fma(fma(ux, ux, uz * uz), ia2, uy * uy * ic2);
+    hb = fma(fma(Ax, ux, Az * uz), ia2, Ay * uy * ic2);
+    c = fma(fma(Ax, Ax, Az * Az), ia2, fma(Ay * Ay, ic2, -1.0));
+    iqa = rcp_seed(qa);
+    iqa = fma(fma(-qa, iqa, 1.0), iqa, iqa);
+  } else {
+    qa = 1.0; iqa = 1.0;   // |u| = 1
+    hb = dot3(Ax, Ay, Az, ux, uy, uz);
+    c = dot3(Ax, Ay, Az, Ax, Ay, Az) - rb * rb;
+  }
+  const double disc = fma(hb, hb, -qa * c);
+  bool any = disc >= -1e-6 * fma(hb, hb, qa * fabs(c) + qa);
   const double sq = (disc > 0.0) ? sqrt_seed(disc) : 0.0;
-  const double pad = 1e-6 * (rb + fabs(hb));
-  const double ts1 = -hb - sq - pad, ts2 = -hb + sq + pad;
+  const double tm = -hb * iqa;                  // closest approach to the centre
+  const double pad = 1e-6 * (rb + fabs(tm));
+  const double ts1 = fma(-sq, iqa, tm) - pad, ts2 = fma(sq, iqa, tm) + pad;
   any = any && (ts2 > 1e-12);
   // Is the ray origin inside the body?  Usual case for a mirror (the previous optic sits inside the tube): decided
   // without a square root by the inscribed box |y| < 0.7 r, rho < R + 0.7 r (0.7^2 + 0.7^2 < 1); only origins
@@ -426,11 +442,13 @@ ART_HD bool intersect(const ArtElementDesc& e, double Ax, double Ay, double Az, 
   if (KIND == ART_TORUS) {
     const double R = e.mp[0], r = e.mp[1], r2 = r * r;
     double ta = 0.0, tb = 0.0;
-    int n = torus_body_roots<-1>(R, r2, R + r, Ax, Ay, Az, ux, uy, uz, ta, tb);
+    int n = torus_body_roots<-1>(R, r2, R + r, e.mp[2], e.mp[3], Ax, Ay, Az, ux, uy, uz, ta, tb);
     consider<KIND>(e, Ax, Ay, Az, ux, uy, uz, ta, n > 0, c);
     consider<KIND>(e, Ax, Ay, Az, ux, uy, uz, tb, n > 1, c);
     if (r > R) {  // self-intersecting torus: the quartic's second factor has real roots too
-      n = torus_body_roots<+1>(R, r2, r - R, Ax, Ay, Az, ux, uy, uz, ta, tb);
+      // bounding sphere of the lemon: (rho + R)^2 + y^2 <= r^2  =>  rho^2 + y^2 <= r^2 - R^2 (its tips sit on the axis
+      // at |y| = sqrt(r^2 - R^2), farther out than its equator rho = r - R)
+      n = torus_body_roots<+1>(R, r2, sqrt(r2 - R * R), 0.0, 0.0, Ax, Ay, Az, ux, uy, uz, ta, tb);
       consider<KIND>(e, Ax, Ay, Az, ux, uy, uz, ta, n > 0, c);
       consider<KIND>(e, Ax, Ay, Az, ux, uy, uz, tb, n > 1, c);
     }
@@ -462,6 +480,16 @@ ART_HD bool intersect(const ArtElementDesc& e, double Ax, double Ay, double Az, 
   }
   t_hit = c.best;
   return c.cnt == 1 || c.cnt == 2;
+}
+
+// Derived constants the library fills into its own copy of a descriptor before a launch (callers leave mp[2..3] of
+// a torus alone): the spheroid of torus_body_roots.
+inline void prepare_element(ArtElementDesc& e) {
+  if (e.kind == ART_TORUS) {
+    const double R = e.mp[0], r = e.mp[1];
+    e.mp[2] = 1.0 / ((R + r) * (R + r));
+    e.mp[3] = 1.0 / (r * (R + r));
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------

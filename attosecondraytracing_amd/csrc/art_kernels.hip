@@ -733,18 +733,20 @@ int art_trace_element(const ArtElementDesc* e, const ArtBundleView* in, const Ar
   if (n == 0) return ART_OK;  // an empty bundle has no arrays to point to
   if (!view_ok(in) || !view_ok(out)) return fail(ART_ERR_BAD_ARG, "bundle view has a NULL array");
   hipStream_t s = (hipStream_t)stream;
+  ArtElementDesc ec = *e;
+  art::prepare_element(ec);
   const int64_t chunk = max_rays_per_launch();
   for (int64_t off = 0; off < n; off += chunk) {
     const int64_t m = (n - off < chunk) ? n - off : chunk;
     const ArtBundleView vi = view_at(*in, off), vo = view_at(*out, off);
-    switch (e->kind) {
-      case ART_PLANE: launch_element<ART_PLANE>(*e, vi, vo, m, s); break;
-      case ART_SPHERE: launch_element<ART_SPHERE>(*e, vi, vo, m, s); break;
-      case ART_PARABOLA: launch_element<ART_PARABOLA>(*e, vi, vo, m, s); break;
-      case ART_TORUS: launch_element<ART_TORUS>(*e, vi, vo, m, s); break;
-      case ART_ELLIPSOID: launch_element<ART_ELLIPSOID>(*e, vi, vo, m, s); break;
-      case ART_CYLINDER: launch_element<ART_CYLINDER>(*e, vi, vo, m, s); break;
-      default: launch_element<ART_MASK>(*e, vi, vo, m, s); break;
+    switch (ec.kind) {
+      case ART_PLANE: launch_element<ART_PLANE>(ec, vi, vo, m, s); break;
+      case ART_SPHERE: launch_element<ART_SPHERE>(ec, vi, vo, m, s); break;
+      case ART_PARABOLA: launch_element<ART_PARABOLA>(ec, vi, vo, m, s); break;
+      case ART_TORUS: launch_element<ART_TORUS>(ec, vi, vo, m, s); break;
+      case ART_ELLIPSOID: launch_element<ART_ELLIPSOID>(ec, vi, vo, m, s); break;
+      case ART_CYLINDER: launch_element<ART_CYLINDER>(ec, vi, vo, m, s); break;
+      default: launch_element<ART_MASK>(ec, vi, vo, m, s); break;
     }
   }
   hipError_t err = hipGetLastError();
@@ -785,6 +787,7 @@ int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundl
       a.n_elems = m;
       for (int k = 0; k < m; ++k) {
         a.e[k] = elems[k0 + k];
+        art::prepare_element(a.e[k]);
         a.out[k] = view_at(outs[k0 + k], off);
         a.zoff[k] = a.zern_doubles;
         a.zern_doubles += a.e[k].n_defects * ART_ZERN_STRIDE;

@@ -5,6 +5,7 @@
 // (closed-form quadrics, convex-Newton torus solver, Zernike recurrences, 3x3 frame maps) can be checked
 // against the oracle and the golden vectors in a container without a GPU.  The product never loads it.
 #define ART_HOST_TWIN 1
+#include <vector>
 #include "../../attosecondraytracing_amd/csrc/art_device.h"
 
 #include <string.h>
@@ -25,7 +26,10 @@ inline void store_ray(const ArtBundleView& v, int64_t i, const art::Ray& r) {
 
 extern "C" {
 
-int art_cpu_trace_element(const ArtElementDesc* e, const ArtBundleView* in, const ArtBundleView* out, int64_t n) {
+int art_cpu_trace_element(const ArtElementDesc* e_in, const ArtBundleView* in, const ArtBundleView* out, int64_t n) {
+  ArtElementDesc ec = *e_in;
+  art::prepare_element(ec);
+  const ArtElementDesc* e = &ec;
   for (int64_t i = 0; i < n; ++i) {
     bool ok = in->alive[i] != 0;
     art::Ray r;
@@ -39,8 +43,10 @@ int art_cpu_trace_element(const ArtElementDesc* e, const ArtBundleView* in, cons
   return 0;
 }
 
-int art_cpu_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundleView* in,
+int art_cpu_trace_chain(const ArtElementDesc* elems_in, int32_t n_elems, const ArtBundleView* in,
                         const ArtBundleView* outs, int64_t n) {
+  std::vector<ArtElementDesc> elems(elems_in, elems_in + n_elems);
+  for (auto& e : elems) art::prepare_element(e);
   for (int64_t i = 0; i < n; ++i) {
     bool ok = in->alive[i] != 0;
     art::Ray r;

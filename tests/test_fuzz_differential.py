@@ -19,3 +19,9 @@ def twin():
 def test_fuzz_twin_vs_oracle(twin, block):
     res = fz.run_differential(range(block * 20, block * 20 + 20))
     assert res["scenes_with_hits"] >= 12, res   # the generator must actually exercise the optics
+
+
+def test_fuzz_regressions(twin):
+    """Seeds that once failed: 20797 / 23917 = self-intersecting torus with the ray origin inside the inner "lemon"
+    next to its tip, outside the sphere of radius r - R that was wrongly used to bound it."""
+    fz.run_differential([20797, 23917])
