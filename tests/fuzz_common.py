@@ -176,3 +176,83 @@ def run_differential(seeds, modes=("chain", "element"), n_rays=1500):
                     assert v <= tols[key], f"{tag}, mode {mode}, element {k}: {key} error {v:.3e} > {tols[key]:.1e}"
                     worst[key] = max(worst[key], float(v))
     return {"worst": worst, "scenes_with_hits": hits, "scenes": len(list(seeds))}
+
+
+def run_detector_fuzz(seeds, n_rays=1200):
+    """Random scene -> autoplaced detector at a random distance (and a second, hand-posed one, tilted and off-centre):
+    3-D hit points, detector-plane coordinates, centred coordinates and delays of the product against the oracle."""
+    import ART.ModuleProcessing as mp
+    import ART.ModuleDetector as mdet
+    checked = 0
+    for seed in seeds:
+        scene, a = random_scene(seed, n_rays)
+        rng = np.random.default_rng(seed + 77_000_000)
+        src_o = orc.make_bundle(a["src_point"], a["src_vector"], a["src_number"], a["src_intensity"], None)
+        last_o = orc.ray_tracing_calculation(src_o, orc.elements_from_scene(scene),
+                                             IgnoreDefects=scene["IgnoreDefects"])[-1]
+        if len(last_o) < 10 or (last_o.incidence >= GRAZING).any():
+            continue          # conditioning of the traced bundle itself is the business of run_differential
+        els = pc.build_elements(scene)
+        src = RayBundle.from_arrays(a["src_point"], a["src_vector"], a["src_number"], None, None)
+        last = mp.RayTracingCalculation(src, els, IgnoreDefects=scene["IgnoreDefects"])[-1]
+        assert np.array_equal(last.numbers(), last_o.number)
+        # the read-out is what is under test here: both sides read out the SAME bundle (the product's)
+        last_o = orc.Bundle(last.points(), last.vectors(), last.numbers(), last.path_segments(), last.incidences(),
+                            np.full(len(last), np.nan), None)
+        dist_ = float(rng.uniform(20.0, 900.0))
+        Do = orc.detector_autoplace(last_o, dist_)
+        D = mdet.Detector(np.array(els[-1].position, float))
+        D.autoplace(last, dist_)
+        scale = max(1.0, np.abs(Do.centre).max(), np.abs(last_o.point).max())
+        tag = f"detector seed {seed}"
+        assert np.abs(D.centre - Do.centre).max() <= 1e-10 * scale, tag
+        assert np.abs(D.normal - Do.normal).max() <= 1e-10, tag
+        assert abs(D.get_distance() - orc.detector_distance(Do)) <= 1e-10 * scale, tag
+        # second pose: tilted by up to 30 degrees and shifted sideways, same for both implementations
+        tilt = rng.normal(size=3)
+        n2 = Do.normal + 0.5 * rng.uniform(0, 1) * (tilt - np.dot(tilt, Do.normal) * Do.normal) / np.linalg.norm(tilt)
+        n2 /= np.linalg.norm(n2)
+        c2 = Do.centre + rng.normal(scale=2.0, size=3)
+        poses = [(Do.refpoint, Do.centre, Do.normal), (Do.refpoint, c2, n2)]
+        if seed % 7 == 0:       # detector normal exactly along -z / +z: RotationPoint's special cases in the read-out
+            poses.append((Do.refpoint, Do.centre, np.array([0.0, 0.0, -1.0 if seed % 2 else 1.0])))
+        for ref_pt, c, nrm in poses:
+            Dq = orc.Detector(np.array(c, float), np.array(nrm, float), np.array(ref_pt, float))
+            den = np.abs(last_o.vector @ Dq.normal)
+            if den.min() < 0.05:
+                continue      # rays nearly parallel to the detector plane: ill-conditioned read-out
+            Dp = mdet.Detector(np.array(ref_pt, float), np.array(c, float), np.array(nrm, float))
+            P3o = orc.detector_points3d(Dq, last_o)
+            sc = max(1.0, np.abs(P3o).max())
+            amp = 1.0 / den.min()
+            assert np.abs(Dp.get_PointList3D(last) - P3o).max() <= 1e-10 * sc * amp, tag
+            assert np.abs(Dp.get_PointList2D(last) - orc.detector_points2d(Dq, last_o)).max() <= 1e-10 * sc * amp, tag
+            assert np.abs(Dp.get_PointList2DCentre(last) - orc.detector_points2dcentre(Dq, last_o)).max() \
+                <= 1e-10 * sc * amp, tag
+            mean_t_fs = np.mean(orc.optical_paths(Dq, last_o)) / orc.LightSpeed * 1e15
+            assert np.abs(Dp.get_Delays(last) - orc.detector_delays(Dq, last_o)).max() <= 1e-10 * mean_t_fs * amp, tag
+            checked += 1
+    return checked
+
+
+def run_source_fuzz(seeds):
+    """Point sources and plane-wave disks with random and special axes (parallel / antiparallel to ez: the
+    RotationPoint special cases) + Gaussian weights, product (device-generated) against the oracle."""
+    import ART.ModuleSource as msource
+    for seed in seeds:
+        rng = np.random.default_rng(seed + 55_000_000)
+        axis = [rng.normal(size=3), np.array([0.0, 0.0, 1.0]), np.array([0.0, 0.0, -1.0]),
+                np.array([0.0, 0.0, -3.0]), np.array([1e-12, 0.0, 1.0])][seed % 5]
+        S = rng.uniform(-300.0, 300.0, 3)
+        n = int(rng.integers(50, 4000))
+        div = float(rng.uniform(1e-4, 0.3))
+        rad = float(rng.uniform(0.1, 60.0))
+        for tag, b, q in (("point", msource.PointSource(S, axis, div, n, 50e-6), orc.point_source(S, axis, div, n)),
+                          ("disk", msource.PlaneWaveDisk(S, axis, rad, n, 50e-6), orc.plane_wave_disk(S, axis, rad, n))):
+            b = msource.ApplyGaussianIntensityToRayList(b)
+            q = orc.apply_gaussian_intensity(q)
+            t = f"source seed {seed} ({tag})"
+            assert len(b) == len(q), t
+            assert np.abs(b.points() - q.point).max() <= 1e-12 * max(1.0, np.abs(q.point).max()), t
+            assert np.abs(b.vectors() - q.vector).max() <= 1e-12, t
+            assert np.abs(b.intensities() - q.intensity).max() <= 1e-10, t

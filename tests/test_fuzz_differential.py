@@ -25,3 +25,11 @@ def test_fuzz_regressions(twin):
     """Seeds that once failed: 20797 / 23917 = self-intersecting torus with the ray origin inside the inner "lemon"
     next to its tip, outside the sphere of radius r - R that was wrongly used to bound it."""
     fz.run_differential([20797, 23917])
+
+
+def test_fuzz_detector_readout(twin):
+    assert fz.run_detector_fuzz(range(60)) >= 80
+
+
+def test_fuzz_sources(twin):
+    fz.run_source_fuzz(range(40))

@@ -213,6 +213,8 @@ def test_gpu_fuzz_differential(hip):
     import fuzz_common as fz
     res = fz.run_differential(list(range(300)) + [20797, 23917])
     assert res["scenes_with_hits"] >= 250, res
+    assert fz.run_detector_fuzz(range(150)) >= 200
+    fz.run_source_fuzz(range(100))
 
 
 def test_gpu_error_paths(hip):
