@@ -63,6 +63,9 @@ def _build_descriptor(oe, IgnoreDefects, backend):
     d.sp[:] = sp + [0.0] * (6 - len(sp))
     mp_ = [float(v) for v in optic._abi_params()]
     d.mp[:] = mp_ + [0.0] * (4 - len(mp_))
+    # e.g. MirrorEllipsoidal parameters without a surface point under the off-axis angle: see RayTracingCalculation
+    d.nonfinite = bool(d.kind not in (_abi.ART_PLANE, _abi.ART_MASK)
+                       and not np.isfinite(list(d.centre) + mp_ + list(d.pos)).all())
     keep = None
     d.n_defects = 0
     d.n_grid = 0
@@ -125,6 +128,20 @@ def RayTracingCalculation(source_rays, optical_elements, IgnoreDefects=True, mod
         descs.append(d)
         keep.append(k)
     mode = mode or DEFAULT_TRACE_MODE
+    bad = next((k for k, d in enumerate(descs) if d.nonfinite), None)
+    if bad is not None:
+        # The reference meets a mirror with NaN/inf parameters in np.roots (ART/ModuleGeometry.py:84, :99), which
+        # raises LinAlgError for the first ray that reaches it -- and stays silent when no ray gets that far.
+        head = RayTracingCalculation(src, optical_elements[:bad], IgnoreDefects, mode, True) if bad else []
+        if len(head[-1] if bad else src) > 0:
+            raise np.linalg.LinAlgError("Array must not contain infs or NaNs")
+        tail = RayBundle.allocate_many(n, m - bad, head[-1] if bad else src, be)
+        prev = head[-1] if bad else src
+        for b in tail:
+            b.alive.zero_()
+            b.parent = prev
+            prev = b
+        return (head + tail) if history else [None] * (m - 1) + [tail[-1]]
     if history:
         outs = RayBundle.allocate_many(n, m, src, be)
     else:
