@@ -119,7 +119,7 @@ class Detector:
                                     (X, Y) if store else None, opl, to_host=sync)
         return {"bundle": B, "X": X, "Y": Y, "opl": opl, "P3": P3, ("stats" if sync else "stats_dev"): stats}
 
-    def _scan_moments(self, RayList):
+    def _scan_moments(self, RayList, span=0.0):
         """Moment sums from which spot size and duration follow at ANY shift of this detector along its normal
         (art_detector_scan_moments).  Two passes over the bundle: the first only finds the mean path used to centre
         the second."""
@@ -128,7 +128,9 @@ class Detector:
         be, n, d = B.backend, B.n_slots, self._desc()
         first = be.detector_scan_moments(d, B.view(), B.intensity, n, 0.0)
         co = first[11] / first[0]
-        return {"m": be.detector_scan_moments(d, B.view(), B.intensity, n, co), "co": co}
+        m = be.detector_scan_moments(d, B.view(), B.intensity, n, co, span)
+        # "kinked": some ray's hit changes side of its origin within the span -> its path |t| is not linear there
+        return {"m": m, "co": co, "kinked": bool(m[32] > 0)}
 
     @staticmethod
     def _spot_duration_from_moments(mom, s, weighted):

@@ -334,10 +334,20 @@ def _scan(detector, Amplitude, Step, RayList, OptFor, IntensityWeighted):
     on the device (Detector._scan_moments: two passes over the bundle, all rays) instead of one pass per position."""
     detector.shiftByDistance(-Amplitude)
     n = int(2 * Amplitude / Step)
-    mom = detector._scan_moments(RayList)
+    mom = detector._scan_moments(RayList, span=(n - 1) * Step)
+    # A scan that carries the detector through the last optic (Amplitude clipped to the detector distance: the scan
+    # starts AT the optic) meets rays whose hit lies behind their origin; the reference's path |I - A| has a kink
+    # there and is no longer linear in the shift.  Those scans are evaluated position by position (still on the
+    # device, still all rays), exactly as the reference's loop does.
+    exact = mom["kinked"] and OptFor in ("intensity", "duration")
     sizes, durations, fitness = [], [], []
     for i in range(n):
-        spot, dur = detector._spot_duration_from_moments(mom, i * Step, IntensityWeighted)
+        if exact:
+            here = detector.copy_detector()
+            here.shiftByDistance(i * Step)
+            spot, dur = here._spot_duration_from_moments(here._scan_moments(RayList), 0.0, IntensityWeighted)
+        else:
+            spot, dur = detector._spot_duration_from_moments(mom, i * Step, IntensityWeighted)
         sizes.append(spot if OptFor in ("intensity", "spotsize") else np.nan)
         durations.append(dur if OptFor in ("intensity", "duration") else np.nan)
         fitness.append(spot ** 2 * dur if OptFor == "intensity" else (dur if OptFor == "duration" else spot))

@@ -1,7 +1,7 @@
 """ctypes mirror of include/art_hip.h (structs, enums, prototypes).  Keep in sync with ART_ABI_VERSION."""
 import ctypes as C
 
-ART_ABI_VERSION = 5
+ART_ABI_VERSION = 6
 
 ART_OK = 0
 ART_ERR_BAD_ARG = -1
@@ -84,7 +84,8 @@ PROTOTYPES = {
     "art_detector_readout": (C.c_int, [C.POINTER(ArtDetectorDesc), C.POINTER(ArtBundleView), C.c_void_p, C.c_int64,
                                        C.c_double, C.c_double, C.c_double] + [C.c_void_p] * 9),
     "art_detector_scan_moments": (C.c_int, [C.POINTER(ArtDetectorDesc), C.POINTER(ArtBundleView), C.c_void_p,
-                                            C.c_int64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                            C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
+                                            C.c_void_p]),
     "art_reduce_scratch_doubles": (C.c_int64, []),
     "art_detector_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),

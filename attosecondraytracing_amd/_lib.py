@@ -138,13 +138,14 @@ class HipBackend:
                                                        self.stream_ptr()), "art_detector_readout")
         return out.cpu().numpy() if to_host else out
 
-    def detector_scan_moments(self, ddesc, view, w, n, co):
-        """32 moment sums for a detector scan along its normal (art_detector_scan_moments); host array."""
+    def detector_scan_moments(self, ddesc, view, w, n, co, span=0.0):
+        """32 moment sums for a detector scan along its normal + [32] the number of rays whose path is not linear
+        over shifts in [0, span] (art_detector_scan_moments); host array."""
         if n == 0:
-            return np.zeros(32)
-        out = self.empty(32)
+            return np.zeros(33)
+        out = self.empty(33)
         self.check(self.fn["art_detector_scan_moments"](C.byref(ddesc), C.byref(view),
-                                                        None if w is None else w.data_ptr(), n, float(co),
+                                                        None if w is None else w.data_ptr(), n, float(co), float(span),
                                                         self._red_scratch().data_ptr(), out.data_ptr(),
                                                         self.stream_ptr()), "art_detector_scan_moments")
         return out.cpu().numpy()

@@ -601,8 +601,10 @@ ART_HD void detector_ray(const ArtDetectorDesc& d, const Ray& r, double& Ix, dou
 
 // Read-out at the current detector position and its derivative with respect to a shift s along -normal
 // (Detector.shiftByDistance(s), ART/ModuleDetector.py:163-177): everything is linear in s.
-ART_HD void detector_ray_scan(const ArtDetectorDesc& d, const Ray& r, double& X, double& Y, double& opl, double& sx,
-                              double& sy, double& so) {
+// `crosses`: does the ray's hit change side of its origin (t changes sign) for some shift in [0, span]?  There
+// opl = |t| |u| + path has a kink and the linear model only describes shift 0.
+ART_HD void detector_ray_scan(const ArtDetectorDesc& d, const Ray& r, double span, double& X, double& Y, double& opl,
+                              double& sx, double& sy, double& so, bool& crosses) {
   double Ix, Iy, Iz;
   detector_ray(d, r, Ix, Iy, Iz, X, Y, opl);
   const double den = dot3(r.dx, r.dy, r.dz, d.normal[0], d.normal[1], d.normal[2]);
@@ -614,8 +616,10 @@ ART_HD void detector_ray_scan(const ArtDetectorDesc& d, const Ray& r, double& X,
   sx = rx; sy = ry;
   const double num = dot3(d.normal[0], d.normal[1], d.normal[2], d.centre[0] - r.ox, d.centre[1] - r.oy,
                           d.centre[2] - r.oz);
-  const double sgn = (num / den >= 0.0) ? 1.0 : -1.0;  // opl = |t| |u| + path
+  const double t0 = num / den;
+  const double sgn = (t0 >= 0.0) ? 1.0 : -1.0;  // opl = |t| |u| + path
   so = sgn * dt * sqrt(dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz));
+  crosses = t0 * fma(span, dt, t0) < 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -424,11 +424,11 @@ __global__ __launch_bounds__(kBlock) void k_detector_readout(const ArtDetectorDe
   block_reduce_store<kReadoutSlots>(acc, ops, scratch + (int64_t)blockIdx.x * kReadoutSlots);
 }
 
-constexpr int kScanSlots = 32;
+constexpr int kScanSlots = 33;
 
 __global__ __launch_bounds__(kBlock) void k_scan_moments_partial(const ArtDetectorDesc d, const ArtBundleView b,
                                                                  const double* w, const int64_t n, const double co,
-                                                                 double* scratch) {
+                                                                 const double span, double* scratch) {
   double acc[kScanSlots];
 #pragma unroll
   for (int k = 0; k < kScanSlots; ++k) acc[k] = 0.0;
@@ -438,7 +438,9 @@ __global__ __launch_bounds__(kBlock) void k_scan_moments_partial(const ArtDetect
     art::Ray r;
     load_ray(b, i, r);
     double q0[3], sq[3];
-    art::detector_ray_scan(d, r, q0[0], q0[1], q0[2], sq[0], sq[1], sq[2]);
+    bool crosses;
+    art::detector_ray_scan(d, r, span, q0[0], q0[1], q0[2], sq[0], sq[1], sq[2], crosses);
+    acc[32] += crosses ? 1.0 : 0.0;
     q0[2] -= co;
     sq[2] -= 1.0;
     const double ww = w ? w[i] : 1.0;
@@ -892,7 +894,7 @@ int art_detector_readout(const ArtDetectorDesc* d, const ArtBundleView* b, const
 }
 
 int art_detector_scan_moments(const ArtDetectorDesc* d, const ArtBundleView* b, const double* w, int64_t n, double co,
-                              double* scratch, double* out32, void* stream) {
+                              double span, double* scratch, double* out32, void* stream) {
   if (!d || !scratch || !out32) return fail(ART_ERR_BAD_ARG, "descriptor/scratch/out32 must not be NULL");
   if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
   hipStream_t s = (hipStream_t)stream;
@@ -904,7 +906,7 @@ int art_detector_scan_moments(const ArtDetectorDesc* d, const ArtBundleView* b, 
   if (!view_ok(b)) return fail(ART_ERR_BAD_ARG, "bundle view has a NULL array");
   int64_t nbk = (n + kBlock - 1) / kBlock;
   const int nb = (int)(nbk > kRedBlocks ? kRedBlocks : nbk);
-  hipLaunchKernelGGL(k_scan_moments_partial, dim3(nb), dim3(kBlock), 0, s, *d, *b, w, n, co, scratch);
+  hipLaunchKernelGGL(k_scan_moments_partial, dim3(nb), dim3(kBlock), 0, s, *d, *b, w, n, co, span, scratch);
   hipLaunchKernelGGL(k_scan_moments_final, dim3(kScanSlots), dim3(kBlock), 0, s, scratch, nb, out32);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_detector_scan_moments launch");

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ART_ABI_VERSION 5
+#define ART_ABI_VERSION 6
 
 /* error codes */
 #define ART_OK 0
@@ -181,11 +181,15 @@ int art_detector_readout(const ArtDetectorDesc* d, const ArtBundleView* b, const
  *     X(s) = X0 + s*sx,  Y(s) = Y0 + s*sy,  opl(s) = opl0 + s*so,   so = -1/(u.normal), (sx, sy) = rot*(so*u + normal)
  * so the spot-size and duration variances at ANY s follow from global sums of per-ray products: one pass over the
  * bundle replaces one pass per scan position.  The path is centred for conditioning: O = opl0 - co, sO = so - 1.
- * out32 (DEVICE, 32 doubles), first block with weight 1, second block (+16) with weight w (= 1 if w is NULL):
+ * out33 (DEVICE, 33 doubles), first block with weight 1, second block (+16) with weight w (= 1 if w is NULL):
  *   [0] sum 1   then for q in (X, Y, O), base = 1 + 5*k:  [base] sum q0  [base+1] sum sq  [base+2] sum q0^2
- *   [base+3] sum q0*sq  [base+4] sum sq^2                                                                        */
+ *   [base+3] sum q0*sq  [base+4] sum sq^2
+ *   [32] number of alive rays whose hit point changes side of the ray origin (t changes sign) for some shift in
+ *        [0, span] (span may be negative): the reference's path |I - A| + sum(path) (ModuleDetector.py:272-275) has a
+ *        kink there, so if [32] > 0 the moments describe shift 0 exactly but not the whole scan -- the caller
+ *        then evaluates the scan positions one by one (a detector scanned through the last optic).            */
 int art_detector_scan_moments(const ArtDetectorDesc* d, const ArtBundleView* b, const double* w, int64_t n, double co,
-                              double* scratch, double* out32, void* stream);
+                              double span, double* scratch, double* out33, void* stream);
 
 /* Masked reductions over alive rays, deterministic (fixed two-level tree, no float atomics).
  * out16 (DEVICE, 16 doubles):

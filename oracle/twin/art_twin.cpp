@@ -77,13 +77,15 @@ int art_cpu_detector(const ArtDetectorDesc* d, const ArtBundleView* b, int64_t n
   return 0;
 }
 
-int art_cpu_detector_scan(const ArtDetectorDesc* d, const ArtBundleView* b, int64_t n, double* X, double* Y,
-                          double* O, double* sx, double* sy, double* so) {
+int art_cpu_detector_scan(const ArtDetectorDesc* d, const ArtBundleView* b, int64_t n, double span, double* X,
+                          double* Y, double* O, double* sx, double* sy, double* so, double* crosses) {
   for (int64_t i = 0; i < n; ++i) {
     if (b->alive[i] == 0) continue;
     art::Ray r;
     load_ray(*b, i, r);
-    art::detector_ray_scan(*d, r, X[i], Y[i], O[i], sx[i], sy[i], so[i]);
+    bool c;
+    art::detector_ray_scan(*d, r, span, X[i], Y[i], O[i], sx[i], sy[i], so[i], c);
+    crosses[i] = c ? 1.0 : 0.0;
   }
   return 0;
 }

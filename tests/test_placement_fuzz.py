@@ -131,3 +131,101 @@ def test_oeplacement_random_chains_match_reference(twin):
             assert np.abs(np.asarray(oe.majoraxis, float) - m).max() <= 1e-10, (seed, oe.majoraxis, m)
         compared += 1
     assert compared >= 40
+
+
+FOCUS_SCRIPT = textwrap.dedent('''
+    import sys, json
+    sys.dont_write_bytecode = True
+    ROOT, REF, lo, hi = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    sys.path[:0] = [REF, ROOT + "/tests/golden/_standin"]
+    import matplotlib; matplotlib.use("Agg")
+    import numpy as np
+    import ART.ModuleProcessing as mp, ART.ModuleMirror as mmirror, ART.ModuleMask as mmask, ART.ModuleSupport as msupp
+    import ART.ModuleDetector as mdet, ART.ModuleAnalysisAndPlots as mplots
+    exec(sys.stdin.read())
+    out = {}
+    for seed in range(lo, hi):
+        SP, optics, dist, inc, plane = make_case(seed, mmirror, mmask, msupp)
+        SP["NumberRays"] = 150
+        try:
+            ch = mp.OEPlacement(SP, optics, dist, inc, plane, "fuzz")
+            last = ch.get_output_rays()[-1]
+        except Exception as e:
+            out[seed] = {"skip": type(e).__name__}
+            continue
+        if len(last) < 30:
+            out[seed] = {"skip": "few rays"}
+            continue
+        rng = np.random.default_rng(seed + 9_000_000)
+        d0 = float(rng.uniform(50, 600))
+        optfor = ["intensity", "duration"][seed % 2]
+        weighted = bool((seed // 2) % 2)
+        D = mdet.Detector(ch.optical_elements[-1].position)
+        D.autoplace(last, d0)
+        try:
+            Dopt, spot, dur = mp.FindOptimalDistance(D, last, optfor, None, 2, weighted)
+            s_sum, d_sum = mplots.GetResultSummary(Dopt, last, False)
+            out[seed] = {"d0": d0, "optfor": optfor, "weighted": weighted, "n": len(last), "distance": Dopt.get_distance(),
+                         "spot": float(spot), "dur": float(dur), "sum_spot": float(s_sum), "sum_dur": float(d_sum),
+                         "et": float(mplots.getETransmission(ch.source_rays, last))}
+        except Exception as e:
+            out[seed] = {"d0": d0, "optfor": optfor, "weighted": weighted, "error": type(e).__name__}
+    print("RESULT" + json.dumps(out))
+''')
+
+
+def test_autofocus_and_summary_random_chains_match_reference(twin):
+    """FindOptimalDistance (both working OptFor values, weighted or not), GetResultSummary and getETransmission on the
+    bundles of random chains: the product's device-side moment scan against the reference's per-position loops."""
+    lo, hi = 0, int(os.environ.get("ART_FUZZ_FOCUS", "24"))
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, "-c", FOCUS_SCRIPT, ROOT, REF, str(lo), str(hi)], input=GENERATOR,
+                       capture_output=True, text=True, timeout=3000, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    ref = json.loads(r.stdout[r.stdout.index("RESULT") + 6:])
+    import ART.ModuleProcessing as mp
+    import ART.ModuleMirror as mmirror
+    import ART.ModuleMask as mmask
+    import ART.ModuleSupport as msupp
+    import ART.ModuleDetector as mdet
+    import ART.ModuleAnalysisAndPlots as mplots
+    ns = {}
+    exec(GENERATOR, ns)
+    compared = 0
+    compared_inside = [0]
+    for seed in range(lo, hi):
+        e = ref[str(seed)]
+        if "skip" in e:
+            continue
+        SP, optics, dist, inc, plane = ns["make_case"](seed, mmirror, mmask, msupp)
+        SP["NumberRays"] = 150
+        ch = mp.OEPlacement(SP, optics, dist, inc, plane, "fuzz")
+        last = ch.get_output_rays()[-1]
+        assert len(last) == e["n"], seed
+        D = mdet.Detector(np.asarray(ch.optical_elements[-1].position, float))
+        D.autoplace(last, e["d0"])
+        if "error" in e:
+            with pytest.raises(Exception) as ei:
+                mp.FindOptimalDistance(D, last, e["optfor"], None, 2, e["weighted"])
+            assert type(ei.value).__name__ == e["error"], (seed, ei.value, e)
+            continue
+        Dopt, spot, dur = mp.FindOptimalDistance(D, last, e["optfor"], None, 2, e["weighted"])
+        # search range of the reference's algorithm (ART/ModuleProcessing.py:430-433)
+        size = 2 * mp.StandardDeviation(D.get_PointList2DCentre(last))
+        A = min(4 * np.ceil(size / np.tan(np.arcsin(mp.ReturnNumericalAperture(last, 1)))), e["d0"])
+        # Each level scans n = int(2 A_k / Step_k) positions; that quotient is 20 or 19.999999999999996 depending on
+        # the last bit of the detector distance, so the two implementations may scan 19 or 20 positions: when the
+        # fitness has no minimum inside the range ("There`s no minimum ... in the searched range") they stop one
+        # coarse step apart.  Inside the range they agree to the final grid (A * 1e-3).
+        at_edge = min(abs(e["distance"] - (e["d0"] - A)), abs(e["distance"] - (e["d0"] + A))) <= 0.25 * A
+        tol_d = 0.125 * A if at_edge else 3e-3 * A + 1e-9
+        assert abs(Dopt.get_distance() - e["distance"]) <= tol_d, (seed, Dopt.get_distance(), A, e)
+        if not at_edge:
+            if not np.isnan(e["spot"]):
+                assert abs(spot - e["spot"]) <= 1e-3 * max(e["spot"], 1e-6), (seed, spot, e)
+            if not np.isnan(e["dur"]):
+                assert abs(dur - e["dur"]) <= 1e-3 * max(e["dur"], 1e-3), (seed, dur, e)
+            compared_inside[0] += 1
+        assert abs(mplots.getETransmission(ch.source_rays, last) - e["et"]) <= 1e-9, seed
+        compared += 1
+    assert compared >= (hi - lo) // 3 and compared_inside[0] >= (hi - lo) // 8, (compared, compared_inside)

@@ -39,7 +39,7 @@ class TwinBackend:
                                               C.c_int64] + [C.c_void_p] * 6
         self.lib.art_cpu_detector_scan.restype = C.c_int
         self.lib.art_cpu_detector_scan.argtypes = [C.POINTER(_abi.ArtDetectorDesc), C.POINTER(_abi.ArtBundleView),
-                                                   C.c_int64] + [C.c_void_p] * 6
+                                                   C.c_int64, C.c_double] + [C.c_void_p] * 7
         self.lib.art_cpu_make_source.restype = C.c_int
         self.lib.art_cpu_make_source.argtypes = [C.c_int32, C.c_double, _abi.c_double_p, _abi.c_double_p, C.c_int64,
                                                  C.c_int64, C.c_int64, C.POINTER(_abi.ArtBundleView)]
@@ -106,15 +106,17 @@ class TwinBackend:
                       (ww * eo ** 2).sum()]
         return out if to_host else torch.from_numpy(out)
 
-    def detector_scan_moments(self, ddesc, view, w, n, co):
-        arrs = [np.zeros(n) for _ in range(6)]
-        assert self.lib.art_cpu_detector_scan(C.byref(ddesc), C.byref(view), n, *[a.ctypes.data for a in arrs]) == 0
+    def detector_scan_moments(self, ddesc, view, w, n, co, span=0.0):
+        arrs = [np.zeros(n) for _ in range(7)]
+        assert self.lib.art_cpu_detector_scan(C.byref(ddesc), C.byref(view), n, float(span),
+                                              *[a.ctypes.data for a in arrs]) == 0
         a = np.ctypeslib.as_array(C.cast(view.alive, C.POINTER(C.c_uint8)), shape=(max(n, 1),))[:n].astype(bool)
-        X, Y, O, sx, sy, so = (v[a] for v in arrs)
+        X, Y, O, sx, sy, so, cr = (v[a] for v in arrs)
         O = O - co
         so = so - 1.0
         ww = w.numpy()[a] if w is not None else np.ones(int(a.sum()))
-        out = np.zeros(32)
+        out = np.zeros(33)
+        out[32] = cr.sum()
         for base, wt in ((0, np.ones_like(ww)), (16, ww)):
             out[base] = wt.sum()
             for k, (q0, sq) in enumerate(((X, sx), (Y, sy), (O, so))):
