@@ -1,7 +1,12 @@
-"""CPU, only where the reference tree is present: `OEPlacement` of the product against `OEPlacement` of the reference
-itself on seeded random chains (1-4 optics of every mirror class + masks, random distances, incidence angles and
-incidence-plane rotations, point and plane-wave sources).  The reference runs in a subprocess (its package is also
-called `ART`) and reports the poses; both sides build their scenes from the same generator text below."""
+"""CPU, only where the reference tree is present: the product's host shell against the reference ITSELF on seeded
+random chains (1-4 optics of every mirror class + masks, random distances, incidence angles and incidence-plane
+rotations, point and plane-wave sources):
+  * `OEPlacement` -> poses and exception types;
+  * `FindOptimalDistance`, `GetResultSummary`, `getETransmission` on the traced bundles;
+  * random sequences of `OpticalChain` operations and the loop-list generators.
+The reference runs in a subprocess (its package is also called `ART`) and reports its results as JSON; both sides
+build their scenes from the same generator text below.  Seeds per test: ART_FUZZ_PLACEMENTS / ART_FUZZ_FOCUS /
+ART_FUZZ_OPS (defaults keep the suite short; 1500 / 160 / 400 were run when the tests were written)."""
 import json
 import os
 import subprocess
@@ -229,3 +234,128 @@ def test_autofocus_and_summary_random_chains_match_reference(twin):
         assert abs(mplots.getETransmission(ch.source_rays, last) - e["et"]) <= 1e-9, seed
         compared += 1
     assert compared >= (hi - lo) // 3 and compared_inside[0] >= (hi - lo) // 8, (compared, compared_inside)
+
+
+OPS_GEN = textwrap.dedent('''
+    def make_ops(seed, n_el):
+        """Seeded random sequence of OpticalChain operations + one loop-list request."""
+        rng = np.random.default_rng(seed + 123456)
+        ops = []
+        for _ in range(int(rng.integers(1, 6))):
+            k = int(rng.integers(0, 4))
+            if k == 0:
+                ax = [("vert",), ("horiz",), (rng.normal(size=3),)][int(rng.integers(0, 3))][0]
+                ops.append(("shift_source", ax, float(rng.uniform(-2, 2))))
+            elif k == 1:
+                ax = [("in_plane",), ("out_plane",), (rng.normal(size=3),)][int(rng.integers(0, 3))][0]
+                ops.append(("tilt_source", ax, float(rng.uniform(-0.2, 0.2))))
+            elif k == 2:
+                ops.append(("rotate_OE", int(rng.integers(-n_el, n_el)), ["pitch", "roll", "yaw"][int(rng.integers(0, 3))],
+                            float(rng.uniform(-0.3, 0.3))))
+            else:
+                ops.append(("shift_OE", int(rng.integers(-n_el, n_el)), ["normal", "major", "cross"][int(rng.integers(0, 3))],
+                            float(rng.uniform(-0.5, 0.5))))
+        if rng.uniform() < 0.5:
+            loop = ("source", ["tilt_in_plane", "tilt_out_plane", "shift_vert", "shift_horiz", "divergence"][int(rng.integers(0, 5))],
+                    [float(v) for v in rng.uniform(0.001, 0.02, 3)])
+        else:
+            loop = ("OE", int(rng.integers(0, n_el)), ["pitch", "roll", "yaw", "shift_normal", "shift_major", "shift_cross"][int(rng.integers(0, 6))],
+                    [float(v) for v in rng.uniform(-0.2, 0.2, 3)])
+        return ops, loop
+
+    def run_ops(ch, ops, loop, points_of):
+        """Apply the operations; returns a JSON-able record of the resulting state (or of the exception)."""
+        rec = {"steps": []}
+        try:
+            for op in ops:
+                getattr(ch, op[0])(*op[1:])
+                rec["steps"].append(op[0])
+            chains = ch.get_source_loop_list(loop[1], loop[2]) if loop[0] == "source" else ch.get_OE_loop_list(loop[1], loop[2], loop[3])
+        except Exception as e:
+            rec["error"] = type(e).__name__
+            return rec
+        rec["chains"] = []
+        for c in [ch] + list(chains):
+            P, V = points_of(c.source_rays)
+            out = c.get_output_rays()
+            Pl, Vl = points_of(out[-1])
+            rec["chains"].append({"name": c.loop_variable_name, "value": None if c.loop_variable_value is None else float(c.loop_variable_value),
+                                  "src_p": P, "src_v": V, "n_out": [len(o) for o in out], "last_p": Pl, "last_v": Vl,
+                                  "poses": [[list(map(float, oe.position)), list(map(float, oe.normal)), list(map(float, oe.majoraxis))]
+                                            for oe in c.optical_elements]})
+        return rec
+''')
+
+OPS_SCRIPT = textwrap.dedent('''
+    import sys, json
+    sys.dont_write_bytecode = True
+    ROOT, REF, lo, hi = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    sys.path[:0] = [REF, ROOT + "/tests/golden/_standin"]
+    import matplotlib; matplotlib.use("Agg")
+    import numpy as np
+    import ART.ModuleProcessing as mp, ART.ModuleMirror as mmirror, ART.ModuleMask as mmask, ART.ModuleSupport as msupp
+    exec(sys.stdin.read())
+    def points_of(rays):
+        return [[float(v) for v in r.point] for r in rays], [[float(v) for v in r.vector] for r in rays]
+    out = {}
+    for seed in range(lo, hi):
+        SP, optics, dist, inc, plane = make_case(seed, mmirror, mmask, msupp)
+        SP["NumberRays"] = 40
+        try:
+            ch = mp.OEPlacement(SP, optics, dist, inc, plane, "fuzz")
+        except Exception as e:
+            out[seed] = {"skip": type(e).__name__}
+            continue
+        ops, loop = make_ops(seed, len(optics))
+        out[seed] = run_ops(ch, ops, loop, points_of)
+    print("RESULT" + json.dumps(out))
+''')
+
+
+def test_chain_operations_random_sequences_match_reference(twin):
+    """shift/tilt of the source, rotate/shift of optical elements and the loop-list generators (ART/ModuleOpticalChain.py:
+    219-615) applied in random sequences to random chains: same resulting sources, poses, loop-variable names, survivor
+    counts, final rays and exception types as the reference."""
+    lo, hi = 0, int(os.environ.get("ART_FUZZ_OPS", "30"))
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, "-c", OPS_SCRIPT, ROOT, REF, str(lo), str(hi)], input=GENERATOR + OPS_GEN,
+                       capture_output=True, text=True, timeout=3000, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    ref = json.loads(r.stdout[r.stdout.index("RESULT") + 6:])
+    import ART.ModuleProcessing as mp
+    import ART.ModuleMirror as mmirror
+    import ART.ModuleMask as mmask
+    import ART.ModuleSupport as msupp
+    ns = {}
+    exec(GENERATOR + OPS_GEN, ns)
+
+    def points_of(rays):
+        return rays.points().tolist(), rays.vectors().tolist()
+
+    compared = 0
+    for seed in range(lo, hi):
+        e = ref[str(seed)]
+        if "skip" in e:
+            continue
+        SP, optics, dist, inc, plane = ns["make_case"](seed, mmirror, mmask, msupp)
+        SP["NumberRays"] = 40
+        ch = mp.OEPlacement(SP, optics, dist, inc, plane, "fuzz")
+        ops, loop = ns["make_ops"](seed, len(optics))
+        mine = ns["run_ops"](ch, ops, loop, points_of)
+        assert mine["steps"] == e["steps"], (seed, mine, e.get("error"))
+        assert mine.get("error") == e.get("error"), (seed, mine.get("error"), e.get("error"), ops, loop)
+        if "error" in e:
+            continue
+        assert len(mine["chains"]) == len(e["chains"])
+        for a, b in zip(mine["chains"], e["chains"]):
+            assert a["name"] == b["name"] and a["value"] == b["value"], (seed, a["name"], b["name"])
+            assert a["n_out"] == b["n_out"], (seed, a["n_out"], b["n_out"])
+            scale = max(1.0, np.abs(np.array(b["src_p"])).max(), *(np.abs(np.array(p[0])).max() for p in b["poses"]))
+            for key, tol in (("src_p", 1e-10 * scale), ("src_v", 1e-10), ("last_p", 1e-9 * scale), ("last_v", 1e-9)):
+                if len(b[key]):
+                    assert np.abs(np.array(a[key]) - np.array(b[key])).max() <= tol, (seed, key, ops, loop)
+            for pa, pb in zip(a["poses"], b["poses"]):
+                assert np.abs(np.array(pa[0]) - np.array(pb[0])).max() <= 1e-10 * scale, (seed, "position", ops)
+                assert np.abs(np.array(pa[1:]) - np.array(pb[1:])).max() <= 1e-10, (seed, "axes", ops)
+        compared += 1
+    assert compared >= (hi - lo) // 3
