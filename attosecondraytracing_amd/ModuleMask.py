@@ -3,6 +3,7 @@ The transmission test and path/incidence update run in the HIP kernel (kind ART_
 import numpy as np
 
 from . import _abi
+from . import ModuleGeometry as mgeo
 
 
 class Mask:
@@ -23,3 +24,28 @@ class Mask:
 
     def __hash__(self):
         return hash(("Mask", hash(self.support)))
+
+    def _get_intersection(self, Ray):
+        """Point where ONE ray (given in the mask's frame) crosses the mask plane if it passes, else None
+        (ART/ModuleMask.py:51-61): a one-ray trace on the device."""
+        hit = TransmitMaskRayList(self, [Ray])
+        return hit[0].point if len(hit) == 1 else None
+
+
+def _TransmitMaskRay(Mask, PointMask, Ray):
+    """ONE ray continued from PointMask with its direction unchanged (ART/ModuleMask.py:93-108), on the host."""
+    out = Ray.copy_ray()
+    out.point = PointMask
+    out.vector = Ray.vector
+    out.incidence = mgeo.AngleBetweenTwoVectors(Ray.vector, Mask.get_normal(PointMask))
+    out.path = Ray.path + (np.linalg.norm(PointMask - Ray.point),)
+    return out
+
+
+def TransmitMaskRayList(Mask, RayList):
+    """The rays that pass the mask, given in the mask's own frame (ART/ModuleMask.py:112-136): one identity-pose
+    element on the device."""
+    from . import ModuleProcessing as mp
+    from .ModuleOpticalElement import OpticalElement
+    oe = OpticalElement(Mask, np.zeros(3), np.array([0.0, 0.0, 1.0]), np.array([1.0, 0.0, 0.0]))
+    return mp.RayTracingCalculation(RayList, [oe])[0]

@@ -12,11 +12,39 @@ from . import _abi
 from . import ModuleGeometry as mgeo
 
 
+def _IntersectionRayMirror(PointMirror, ListPointIntersectionMirror):
+    """Two candidate points -> the one closer to PointMirror, one -> it, otherwise None (ART/ModuleMirror.py:27-38).
+    Host helper kept for API parity; the kernels apply the same rule per ray (art_device.h `consider`)."""
+    if len(ListPointIntersectionMirror) == 2:
+        return mgeo.ClosestPoint(PointMirror, ListPointIntersectionMirror[0], ListPointIntersectionMirror[1])
+    if len(ListPointIntersectionMirror) == 1:
+        return ListPointIntersectionMirror[0]
+    return None
+
+
+def _ReflectionMirrorRay(Mirror, PointMirror, Ray):
+    """Reflect ONE ray at a given surface point (ART/ModuleMirror.py:878-906), on the host; bundles go through
+    ReflectionMirrorRayList / RayTracingCalculation on the device."""
+    NormalMirror = Mirror.get_normal(PointMirror)
+    out = Ray.copy_ray()
+    out.point = PointMirror
+    out.vector = mgeo.SymmetricalVector(-Ray.vector, NormalMirror)
+    out.incidence = mgeo.AngleBetweenTwoVectors(-Ray.vector, NormalMirror)
+    out.path = Ray.path + (np.linalg.norm(PointMirror - Ray.point),)
+    return out
+
+
 class _Mirror:
     _abi_kind = None
 
     def _abi_params(self):
         raise NotImplementedError
+
+    def _get_intersection(self, Ray):
+        """Intersection point of ONE ray, given in the mirror's own frame, with the surface inside its support, or
+        None (the `_get_intersection` of every mirror class of ART/ModuleMirror.py): a one-ray trace on the device."""
+        hit = ReflectionMirrorRayList(self, [Ray], IgnoreDefects=True)
+        return hit[0].point if len(hit) == 1 else None
 
     def __hash__(self):
         return hash((self.type, hash(self.support)) + tuple(float(v) for v in self._abi_params()))

@@ -53,6 +53,24 @@ def ExtendedSource(S, Axis, Diameter: float, Divergence: float, NbRays: int, Wav
     return b
 
 
+def PlaneWaveSquare(Centre, Axis, SideLength: float, NbRays: int, Wavelength=None):
+    """Collimated square beam (ART/ModuleSource.py:171-204).  As shipped, the reference only runs for NbRays < 4
+    (one grid point per side): its test `abs(x) > 1e-4` is applied to the whole coordinate ARRAY, which NumPy refuses
+    for more than one element.  Same here: the same ValueError for larger NbRays, the same rays below."""
+    x = np.linspace(-SideLength / 2, SideLength / 2, int(np.sqrt(NbRays)))
+    y = np.linspace(-SideLength / 2, SideLength / 2, int(np.sqrt(NbRays)))
+    pts = [[0.0, 0.0, 0.0]]
+    for i in x:
+        for j in y:
+            if abs(x) > 1e-4 and abs(y) > 1e-4:   # (sic) raises ValueError for arrays longer than 1
+                pts.append([i, j, 0.0])
+    pts = np.asarray(pts, dtype=float)
+    M = mgeo.rotation_matrix(_EZ, np.asarray(Axis, dtype=float))
+    vec = np.tile(M @ _EZ, (len(pts), 1))
+    b = RayBundle.from_arrays(pts @ M.T + np.asarray(Centre, dtype=float), vec, np.arange(len(pts)), None, Wavelength)
+    return b
+
+
 def ApplyGaussianIntensityToRayList(RayList, IntensityFraction=1 / np.e ** 2):
     """Gaussian intensity profile, 1 on axis and IntensityFraction at the edge (ART/ModuleSource.py:219-261):
     in angle for diverging bundles, in distance from the origin for plane waves."""

@@ -34,6 +34,9 @@ class RayBundle:
         self._count = None
         self.version = 0              # bumped when the arrays are modified in place
         self._serial = next(_SERIAL)
+        # host array [n, k] or None: the path segments rays already carried when a bundle WITHOUT parent was built
+        # from Ray objects whose `path` tuples had k > 1 entries (the device keeps only their sum)
+        self.path_head = None
 
     # ------------------------------------------------------------------ backend / persistence
     @property
@@ -53,13 +56,14 @@ class RayBundle:
         host = lambda t: None if t is None else t.detach().cpu().numpy()
         return {"data": host(self.data), "alive": host(self.alive), "number": host(self.number),
                 "intensity": host(self.intensity), "wavelength": self.wavelength, "parent": self.parent,
-                "version": self.version}
+                "version": self.version, "path_head": self.path_head}
 
     def __setstate__(self, st):
         t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a))
         self.data, self.alive = t(st["data"]), t(st["alive"])
         self.number, self.intensity = t(st["number"]), t(st["intensity"])
         self.wavelength, self.parent, self.version = st["wavelength"], st["parent"], st["version"]
+        self.path_head = st.get("path_head")
         self._backend = None
         self._index = None
         self._count = None
@@ -114,7 +118,11 @@ class RayBundle:
         intensity = None if any(v is None for v in ints) else np.array(ints, dtype=np.float64)
         path0 = np.array([float(np.sum(r.path)) for r in rays])
         wl = rays[0].wavelength if rays else None
-        return cls.from_arrays(pts, vec, number, intensity, wl, path0, backend)
+        b = cls.from_arrays(pts, vec, number, intensity, wl, path0, backend)
+        k = {len(r.path) for r in rays}
+        if len(k) == 1 and k != {1}:
+            b.path_head = np.array([r.path for r in rays], dtype=np.float64)
+        return b
 
     # ------------------------------------------------------------------ raw access
     @property
@@ -186,8 +194,16 @@ class RayBundle:
             cum.append(b.data[ROW_PATH].index_select(0, idx).cpu().numpy())
             b = b.parent
         cum = cum[::-1]
-        segs = [cum[0]] + [cum[j] - cum[j - 1] for j in range(1, len(cum))]
+        head = self._head_segments(idx.cpu().numpy())
+        segs = (list(head.T) if head is not None else [cum[0]]) + [cum[j] - cum[j - 1] for j in range(1, len(cum))]
         return np.stack(segs, axis=1)
+
+    def _head_segments(self, slots):
+        """Rows `slots` of the root bundle's path_head (None if the root carries single-entry paths)."""
+        b = self
+        while b.parent is not None:
+            b = b.parent
+        return None if b.path_head is None else b.path_head[slots]
 
     # ------------------------------------------------------------------ list-of-Ray protocol
     def _ray_at(self, slots):
@@ -202,9 +218,11 @@ class RayBundle:
             cum.append(b.data[ROW_PATH].index_select(0, st).cpu().numpy())
             b = b.parent
         cum = cum[::-1]
+        head = self._head_segments(slots)
         rays = []
         for j in range(len(slots)):
-            path = (float(cum[0][j]),) + tuple(float(cum[k][j] - cum[k - 1][j]) for k in range(1, len(cum)))
+            first = (float(cum[0][j]),) if head is None else tuple(float(v) for v in head[j])
+            path = first + tuple(float(cum[k][j] - cum[k - 1][j]) for k in range(1, len(cum)))
             inc = cols[ROW_INC, j]
             rays.append(Ray(cols[0:3, j].copy(), cols[3:6, j].copy(), path, int(nums[j]), self.wavelength,
                             None if np.isnan(inc) else np.float64(inc),
@@ -236,19 +254,24 @@ class RayBundle:
         pos = torch.as_tensor(np.asarray(positions, dtype=np.int64), device=self.backend.device)
         alive = torch.zeros_like(self.alive)
         alive[idx.index_select(0, pos)] = 1
-        return RayBundle(self.data, alive, self.number, self.intensity, self.wavelength, self.parent, self.backend)
+        out = RayBundle(self.data, alive, self.number, self.intensity, self.wavelength, self.parent, self.backend)
+        out.path_head = self.path_head
+        return out
 
     def transformed(self, M, T, rotate_points=True):
         """Affine map of the whole bundle on the device (art_transform_bundle): point' = M point + T (or
         point + T), vector' = normalize(M vector).  Scene-manipulation helper, not on the tracing path."""
         out = RayBundle.allocate(self.n_slots, like=self, backend=self.backend)
         out.parent = self.parent
+        out.path_head = self.path_head
         self.backend.transform_bundle(M, T, rotate_points, self.view(), out.view(), self.n_slots)
         return out
 
     def copy(self):
-        return RayBundle(self.data.clone(), self.alive.clone(), self.number, self.intensity, self.wavelength,
-                         self.parent, self.backend)
+        out = RayBundle(self.data.clone(), self.alive.clone(), self.number, self.intensity, self.wavelength,
+                        self.parent, self.backend)
+        out.path_head = self.path_head
+        return out
 
     def __deepcopy__(self, memo):
         return self.copy()

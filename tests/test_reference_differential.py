@@ -359,3 +359,127 @@ def test_chain_operations_random_sequences_match_reference(twin):
                 assert np.abs(np.array(pa[1:]) - np.array(pb[1:])).max() <= 1e-10, (seed, "axes", ops)
         compared += 1
     assert compared >= (hi - lo) // 3
+
+
+METHODS_GEN = textwrap.dedent('''
+    def make_mirror_and_rays(seed, mmirror, mmask, msupp, mray):
+        """One optic (any class, any aperture) and 12 rays given in ITS OWN frame, some missing it."""
+        rng = np.random.default_rng(seed + 424242)
+        size = float(rng.uniform(10, 40))
+        sup = [msupp.SupportRound(size), msupp.SupportRoundHole(size, size / 4, size / 5, 0.0),
+               msupp.SupportRectangle(2 * size, size), msupp.SupportRectangleHole(2 * size, size, size / 5, 1.0, -2.0),
+               msupp.SupportRectangleRectHole(2 * size, size, size / 2, size / 4, 2.0, 1.0)][int(rng.integers(0, 5))]
+        k = seed % 8
+        if k == 0: o = mmirror.MirrorPlane(sup)
+        elif k == 1: o = mmirror.MirrorSpherical(float(rng.uniform(100, 2000)), sup)
+        elif k == 2: o = mmirror.MirrorSpherical(-float(rng.uniform(100, 2000)), sup)
+        elif k == 3: o = mmirror.MirrorParabolic(float(rng.uniform(60, 400)), float(rng.uniform(0, 110)), sup)
+        elif k == 4:
+            R, r = mmirror.ReturnOptimalToroidalRadii(float(rng.uniform(200, 800)), float(rng.uniform(50, 82)))
+            o = mmirror.MirrorToroidal(R, r, sup)
+        elif k == 5: o = mmirror.MirrorCylindrical(float(rng.uniform(100, 2000)) * (1 if rng.uniform() < 0.5 else -1), sup)
+        elif k == 6: o = mmirror.MirrorEllipsoidal(sup, f_object=float(rng.uniform(200, 600)), f_image=float(rng.uniform(200, 600)),
+                                                   OffAxisAngle=float(rng.uniform(40, 120)))
+        else: o = mmask.Mask(sup)
+        C = np.asarray(o.get_centre(), dtype=float)
+        rays = []
+        for j in range(12):
+            target = C + np.array([rng.uniform(-1.3, 1.3) * size, rng.uniform(-1.3, 1.3) * size, 0.0])
+            d = rng.normal(size=3); d[2] = abs(d[2]) + 0.3; d /= np.linalg.norm(d)
+            A = target + float(rng.uniform(50, 500)) * d
+            rays.append(mray.Ray(A, -d, (0.0, float(rng.uniform(0, 10))), j, 50e-6, None, float(rng.uniform(0, 1))))
+        return o, rays
+''')
+
+METHODS_SCRIPT = textwrap.dedent('''
+    import sys, json
+    sys.dont_write_bytecode = True
+    ROOT, REF, lo, hi = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    sys.path[:0] = [REF, ROOT + "/tests/golden/_standin"]
+    import matplotlib; matplotlib.use("Agg")
+    import numpy as np
+    import ART.ModuleMirror as mmirror, ART.ModuleMask as mmask, ART.ModuleSupport as msupp, ART.ModuleOpticalRay as mray
+    import ART.ModuleSource as msource
+    exec(sys.stdin.read())
+    out = {}
+    for seed in range(lo, hi):
+        o, rays = make_mirror_and_rays(seed, mmirror, mmask, msupp, mray)
+        pts = [o._get_intersection(r) for r in rays]
+        lst = mmask.TransmitMaskRayList(o, rays) if o.type == "Mask" else mmirror.ReflectionMirrorRayList(o, rays)
+        single = []
+        for r, p in zip(rays, pts):
+            if p is None:
+                single.append(None)
+                continue
+            q = mmask._TransmitMaskRay(o, p, r) if o.type == "Mask" else mmirror._ReflectionMirrorRay(o, p, r)
+            single.append([list(map(float, q.point)), list(map(float, q.vector)), float(q.incidence), [float(v) for v in q.path]])
+        out[seed] = {"type": o.type, "pts": [None if p is None else list(map(float, p)) for p in pts],
+                     "list": [[r.number, list(map(float, r.point)), list(map(float, r.vector)), float(r.incidence),
+                               [float(v) for v in r.path], r.wavelength, r.intensity] for r in lst],
+                     "single": single}
+    sq = {}
+    for n in (0, 1, 2, 3, 4, 9, 50):
+        try:
+            b = msource.PlaneWaveSquare(np.array([1.0, 2.0, 3.0]), np.array([0.2, -0.5, 0.8]), 7.0, n, 800e-6)
+            sq[n] = [[list(map(float, r.point)), list(map(float, r.vector))] for r in b]
+        except Exception as e:
+            sq[n] = type(e).__name__
+    print("RESULT" + json.dumps({"mirrors": out, "square": sq}))
+''')
+
+
+def test_single_ray_methods_and_square_source_match_reference(twin):
+    """`_get_intersection`, `_ReflectionMirrorRay` / `_TransmitMaskRay`, `ReflectionMirrorRayList` /
+    `TransmitMaskRayList` of every optic class on rays given in the optic's own frame, and `PlaneWaveSquare`
+    (which the reference only runs for NbRays < 4)."""
+    lo, hi = 0, int(os.environ.get("ART_FUZZ_METHODS", "48"))
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, "-c", METHODS_SCRIPT, ROOT, REF, str(lo), str(hi)], input=METHODS_GEN,
+                       capture_output=True, text=True, timeout=3000, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    ref = json.loads(r.stdout[r.stdout.index("RESULT") + 6:])
+    import ART.ModuleMirror as mmirror
+    import ART.ModuleMask as mmask
+    import ART.ModuleSupport as msupp
+    import ART.ModuleOpticalRay as mray
+    import ART.ModuleSource as msource
+    ns = {"np": np}
+    exec(METHODS_GEN, ns)
+    n_hits = 0
+    for seed in range(lo, hi):
+        e = ref["mirrors"][str(seed)]
+        o, rays = ns["make_mirror_and_rays"](seed, mmirror, mmask, msupp, mray)
+        assert o.type == e["type"]
+        pts = [o._get_intersection(q) for q in rays]
+        assert [p is None for p in pts] == [p is None for p in e["pts"]], (seed, e["type"])
+        for p, pe in zip(pts, e["pts"]):
+            if pe is not None:
+                assert np.abs(p - np.array(pe)).max() <= 1e-9 * max(1.0, np.abs(pe).max()), (seed, e["type"])
+                n_hits += 1
+        lst = mmask.TransmitMaskRayList(o, rays) if o.type == "Mask" else mmirror.ReflectionMirrorRayList(o, rays)
+        assert [q.number for q in lst] == [x[0] for x in e["list"]]
+        for q, x in zip(lst, e["list"]):
+            assert np.abs(q.point - np.array(x[1])).max() <= 1e-9 * max(1.0, np.abs(x[1]).max())
+            assert np.abs(q.vector - np.array(x[2])).max() <= 1e-9
+            assert abs(q.incidence - x[3]) <= 1e-9
+            assert len(q.path) == len(x[4]) and np.abs(np.array(q.path) - np.array(x[4])).max() <= 1e-9 * max(1.0, max(x[4]))
+            assert q.wavelength == x[5] and abs(q.intensity - x[6]) <= 1e-15
+        for q, p, x in zip(rays, pts, e["single"]):
+            if x is None:
+                continue
+            s = mmask._TransmitMaskRay(o, p, q) if o.type == "Mask" else mmirror._ReflectionMirrorRay(o, p, q)
+            assert np.abs(s.point - np.array(x[0])).max() <= 1e-9 * max(1.0, np.abs(x[0]).max())
+            assert np.abs(s.vector - np.array(x[1])).max() <= 1e-9 and abs(s.incidence - x[2]) <= 1e-9
+            assert np.abs(np.array(s.path) - np.array(x[3])).max() <= 1e-9 * max(1.0, max(x[3]))
+    assert n_hits >= 2 * (hi - lo)
+    for n, expect in ref["square"].items():
+        args = (np.array([1.0, 2.0, 3.0]), np.array([0.2, -0.5, 0.8]), 7.0, int(n), 800e-6)
+        if isinstance(expect, str):
+            with pytest.raises(Exception) as ei:
+                msource.PlaneWaveSquare(*args)
+            assert type(ei.value).__name__ == expect
+        else:
+            b = msource.PlaneWaveSquare(*args)
+            assert len(b) == len(expect)
+            assert np.abs(b.points() - np.array([x[0] for x in expect])).max() <= 1e-12
+            assert np.abs(b.vectors() - np.array([x[1] for x in expect])).max() <= 1e-12
