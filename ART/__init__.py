@@ -5,7 +5,7 @@ import sys
 
 _MODULES = ["ModuleGeometry", "ModuleOpticalRay", "ModuleSupport", "ModuleDefects", "ModuleMask", "ModuleMirror",
             "ModuleOpticalElement", "ModuleSource", "ModuleProcessing", "ModuleDetector", "ModuleOpticalChain",
-            "ModuleAnalysisAndPlots", "DefaultOptions"]
+            "ModuleAnalysisAndPlots", "DefaultOptions", "recursive_zernike_generator"]
 
 for _m in _MODULES:
     _mod = importlib.import_module("attosecondraytracing_amd." + _m)

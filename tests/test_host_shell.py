@@ -229,3 +229,19 @@ def test_save_and_load_results(twin, tmp_path, monkeypatch):
     assert np.array_equal(o2[-1].points(), out[-1].points())
     assert np.array_equal(o2[-1].path_segments(), out[-1].path_segments())
     assert [r.number for r in o2[-1][:3]] == [r.number for r in out[-1][:3]]
+
+
+def test_zernike_gradient_module_matches_reference():
+    """ART.recursive_zernike_generator.zernike_gradient (API parity module) against values produced by the
+    reference's own generator (fixture zernike_tierA: no stand-in module involved)."""
+    from ART.recursive_zernike_generator import zernike_gradient
+    _, a = load_golden("zernike_tierA")
+    N = int(a["nm"][:, 0].max())
+    Z, GX, GY = zernike_gradient(a["x"], a["y"], N)
+    assert [Z[tuple(k)][0][0] for k in a["nm"]] == list(range(len(a["nm"])))      # generation-order index
+    for k, (n, m) in enumerate(a["nm"]):
+        scale = max(1.0, np.abs(a["val"][k]).max(), np.abs(a["gx"][k]).max(), np.abs(a["gy"][k]).max())
+        assert np.abs(Z[(n, m)][0][1] - a["val"][k]).max() <= 1e-13 * scale
+        assert np.abs(GX[(n, m)][0][1] - a["gx"][k]).max() <= 1e-13 * scale
+        assert np.abs(GY[(n, m)][0][1] - a["gy"][k]).max() <= 1e-13 * scale
+    assert (1, 1) in zernike_gradient(a["x"], a["y"], 0)[0] and (2, 2) in zernike_gradient(a["x"], a["y"], 0)[0]
