@@ -286,6 +286,16 @@ class DeformedMirror(_Mirror):
     def _abi_defect_table(self):
         return np.concatenate([d._abi_table() for d in self._zernike_defects()])
 
+    def get_normal(self, PointMirror):
+        """Normal of the deformed surface at ONE point, host side (ART/ModuleMirror.py:952-961): the base normal
+        folded with each defect's normal by slope addition."""
+        normal = np.asarray(self.Mirror.get_normal(PointMirror), dtype=float)
+        C = self.get_centre()
+        for d in self.DeformationList:
+            normal = mgeo.normal_add(normal, d.get_normal(PointMirror - C))
+            normal = normal / np.linalg.norm(normal)
+        return normal
+
     def get_centre(self):
         return self.Mirror.get_centre()
 

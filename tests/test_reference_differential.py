@@ -362,14 +362,14 @@ def test_chain_operations_random_sequences_match_reference(twin):
 
 
 METHODS_GEN = textwrap.dedent('''
-    def make_mirror_and_rays(seed, mmirror, mmask, msupp, mray):
+    def make_mirror_and_rays(seed, mmirror, mmask, msupp, mray, mdef):
         """One optic (any class, any aperture) and 12 rays given in ITS OWN frame, some missing it."""
         rng = np.random.default_rng(seed + 424242)
         size = float(rng.uniform(10, 40))
         sup = [msupp.SupportRound(size), msupp.SupportRoundHole(size, size / 4, size / 5, 0.0),
                msupp.SupportRectangle(2 * size, size), msupp.SupportRectangleHole(2 * size, size, size / 5, 1.0, -2.0),
                msupp.SupportRectangleRectHole(2 * size, size, size / 2, size / 4, 2.0, 1.0)][int(rng.integers(0, 5))]
-        k = seed % 8
+        k = seed % 9
         if k == 0: o = mmirror.MirrorPlane(sup)
         elif k == 1: o = mmirror.MirrorSpherical(float(rng.uniform(100, 2000)), sup)
         elif k == 2: o = mmirror.MirrorSpherical(-float(rng.uniform(100, 2000)), sup)
@@ -380,7 +380,13 @@ METHODS_GEN = textwrap.dedent('''
         elif k == 5: o = mmirror.MirrorCylindrical(float(rng.uniform(100, 2000)) * (1 if rng.uniform() < 0.5 else -1), sup)
         elif k == 6: o = mmirror.MirrorEllipsoidal(sup, f_object=float(rng.uniform(200, 600)), f_image=float(rng.uniform(200, 600)),
                                                    OffAxisAngle=float(rng.uniform(40, 120)))
-        else: o = mmask.Mask(sup)
+        elif k == 7: o = mmask.Mask(sup)
+        else:
+            base = mmirror.MirrorParabolic(float(rng.uniform(60, 400)), float(rng.uniform(0, 90)), sup) if rng.uniform() < 0.5 \
+                else mmirror.MirrorSpherical(float(rng.uniform(200, 2000)), sup)
+            defects = [mdef.Zernike(sup, {(int(n), int(rng.integers(0, n + 1))): float(rng.uniform(-1, 1) * 3e-4)
+                                          for n in rng.integers(1, 8, size=3)}) for _ in range(int(rng.integers(1, 3)))]
+            o = mmirror.DeformedMirror(base, defects)
         C = np.asarray(o.get_centre(), dtype=float)
         rays = []
         for j in range(12):
@@ -399,11 +405,11 @@ METHODS_SCRIPT = textwrap.dedent('''
     import matplotlib; matplotlib.use("Agg")
     import numpy as np
     import ART.ModuleMirror as mmirror, ART.ModuleMask as mmask, ART.ModuleSupport as msupp, ART.ModuleOpticalRay as mray
-    import ART.ModuleSource as msource
+    import ART.ModuleSource as msource, ART.ModuleDefects as mdef
     exec(sys.stdin.read())
     out = {}
     for seed in range(lo, hi):
-        o, rays = make_mirror_and_rays(seed, mmirror, mmask, msupp, mray)
+        o, rays = make_mirror_and_rays(seed, mmirror, mmask, msupp, mray, mdef)
         pts = [o._get_intersection(r) for r in rays]
         lst = mmask.TransmitMaskRayList(o, rays) if o.type == "Mask" else mmirror.ReflectionMirrorRayList(o, rays)
         single = []
@@ -414,6 +420,9 @@ METHODS_SCRIPT = textwrap.dedent('''
             q = mmask._TransmitMaskRay(o, p, r) if o.type == "Mask" else mmirror._ReflectionMirrorRay(o, p, r)
             single.append([list(map(float, q.point)), list(map(float, q.vector)), float(q.incidence), [float(v) for v in q.path]])
         out[seed] = {"type": o.type, "pts": [None if p is None else list(map(float, p)) for p in pts],
+                     "normals": [None if p is None else list(map(float, o.get_normal(p))) for p in pts],
+                     "offsets": [[float(d.get_offset(p - o.get_centre())) for d in getattr(o, "DeformationList", [])]
+                                 for p in pts if p is not None],
                      "list": [[r.number, list(map(float, r.point)), list(map(float, r.vector)), float(r.incidence),
                                [float(v) for v in r.path], r.wavelength, r.intensity] for r in lst],
                      "single": single}
@@ -443,12 +452,13 @@ def test_single_ray_methods_and_square_source_match_reference(twin):
     import ART.ModuleSupport as msupp
     import ART.ModuleOpticalRay as mray
     import ART.ModuleSource as msource
+    import ART.ModuleDefects as mdef
     ns = {"np": np}
     exec(METHODS_GEN, ns)
     n_hits = 0
     for seed in range(lo, hi):
         e = ref["mirrors"][str(seed)]
-        o, rays = ns["make_mirror_and_rays"](seed, mmirror, mmask, msupp, mray)
+        o, rays = ns["make_mirror_and_rays"](seed, mmirror, mmask, msupp, mray, mdef)
         assert o.type == e["type"]
         pts = [o._get_intersection(q) for q in rays]
         assert [p is None for p in pts] == [p is None for p in e["pts"]], (seed, e["type"])
@@ -456,6 +466,12 @@ def test_single_ray_methods_and_square_source_match_reference(twin):
             if pe is not None:
                 assert np.abs(p - np.array(pe)).max() <= 1e-9 * max(1.0, np.abs(pe).max()), (seed, e["type"])
                 n_hits += 1
+        hit_pts = [p for p in pts if p is not None]
+        for p, nrm in zip(hit_pts, [x for x in e["normals"] if x is not None]):
+            assert np.abs(np.asarray(o.get_normal(p), float) - np.array(nrm)).max() <= 1e-9, (seed, e["type"])
+        for p, offs in zip(hit_pts, e["offsets"]):
+            mine = [d.get_offset(p - o.get_centre()) for d in getattr(o, "DeformationList", [])]
+            assert np.allclose(mine, offs, rtol=0, atol=1e-13), (seed, mine, offs)
         lst = mmask.TransmitMaskRayList(o, rays) if o.type == "Mask" else mmirror.ReflectionMirrorRayList(o, rays)
         assert [q.number for q in lst] == [x[0] for x in e["list"]]
         for q, x in zip(lst, e["list"]):
