@@ -1,8 +1,9 @@
-"""Result summaries, API subset of ART/ModuleAnalysisAndPlots.py.
+"""Result summaries and plots, API of ART/ModuleAnalysisAndPlots.py.
 
 `getETransmission` and `GetResultSummary` (the two functions ARTmain needs for its numbers) are built on the
-device reductions.  The interactive matplotlib / PyVista plots of the reference are visualisation and out of
-scope for this package: the plot entry points exist so that ARTmain and CONFIG scripts run, and say so."""
+device reductions.  SpotDiagram, DelayGraph and MirrorProjection are matplotlib adaptors fed from the device
+(_plots.py: statistics over all rays, markers for a down-sampled subset).  RayRenderGraph (PyVista 3-D scene) is not
+built: the entry point exists so that ARTmain and CONFIG scripts run, and says so."""
 import numpy as np
 
 from . import ModuleGeometry as mgeo
@@ -60,16 +61,28 @@ def GetResultSummary(Detector, RayListAnalysed, verbose=False):
     return FocalSpotSizeSD, DurationSD
 
 
-def SpotDiagram(*a, **k):
-    return _not_built("SpotDiagram")
+def _getDetectorPoints(RayListAnalysed, Detector):
+    from . import _plots
+    return _plots._getDetectorPoints(RayListAnalysed, Detector)
 
 
-def DelayGraph(*a, **k):
-    return _not_built("DelayGraph")
+def SpotDiagram(RayListAnalysed, Detector, DrawAiryAndFourier=False, ColorCoded=None):
+    """Spot diagram on the detector, optionally colour-coded by "Intensity", "Incidence" or "Delay"; left/right keys
+    move the detector (ART/ModuleAnalysisAndPlots.py:133-281)."""
+    from . import _plots
+    return _plots.SpotDiagram(RayListAnalysed, Detector, DrawAiryAndFourier, ColorCoded)
 
 
-def MirrorProjection(*a, **k):
-    return _not_built("MirrorProjection")
+def DelayGraph(RayListAnalysed, Detector, DeltaFT, DrawAiryAndFourier=False, ColorCoded=None):
+    """3-D spot diagram with the ray delays on the third axis (ART/ModuleAnalysisAndPlots.py:360-441)."""
+    from . import _plots
+    return _plots.DelayGraph(RayListAnalysed, Detector, DeltaFT, DrawAiryAndFourier, ColorCoded)
+
+
+def MirrorProjection(OpticalChain, ReflectionNumber: int, Detector=None, ColorCoded=None):
+    """Impact points on one optical element in its support frame (ART/ModuleAnalysisAndPlots.py:444-525)."""
+    from . import _plots
+    return _plots.MirrorProjection(OpticalChain, ReflectionNumber, Detector, ColorCoded)
 
 
 def RayRenderGraph(*a, **k):
@@ -77,4 +90,5 @@ def RayRenderGraph(*a, **k):
 
 
 def show():
-    return None
+    from . import _plots
+    return _plots.show()

@@ -28,6 +28,22 @@ class Support(ABC):
     def __hash__(self):
         return hash((type(self).__name__,) + tuple(float(v) for v in self._abi_params()))
 
+    def _ContourSupport(self, Figure):
+        """Outline of the support (and of its hole) on a new equal-aspect axes of `Figure`; used by MirrorProjection
+        (the `_ContourSupport` of every support class of ART/ModuleSupport.py).  Returns the axes."""
+        from matplotlib import patches
+        axe = Figure.add_subplot(111, aspect="equal")
+        if hasattr(self, "radius"):
+            axe.add_patch(patches.Circle((0, 0), self.radius, alpha=0.08))
+        else:
+            axe.add_patch(patches.Rectangle((-self.dimX * 0.5, -self.dimY * 0.5), self.dimX, self.dimY, alpha=0.08))
+        if hasattr(self, "radiushole"):
+            axe.add_patch(patches.Circle((self.centerholeX, self.centerholeY), self.radiushole, color="white", alpha=1))
+        elif hasattr(self, "holeX"):
+            axe.add_patch(patches.Rectangle((-self.holeX * 0.5 + self.centerholeX, -self.holeY * 0.5 + self.centerholeY),
+                                            self.holeX, self.holeY, color="white", alpha=1))
+        return axe
+
 
 class SupportRound(Support):
     """Disk of radius `radius` (ART/ModuleSupport.py:46-105)."""
