@@ -84,6 +84,18 @@ def random_scene(seed, n_rays=1500):
     kind = KINDS[seed % len(KINDS)]
     e, size, O = random_optic(rng, kind)
     deformed = (seed // len(KINDS)) % 3 == 0 and e["kind"] != "mask"
+    gridded = (seed // len(KINDS)) % 9 == 4 and e["kind"] != "mask"
+    arrays_extra = {}
+    if gridded:    # DeformedMirror with a Fourrier height map (+ sometimes a Zernike term), offsets only
+        import ART.ModuleDefects as mdef
+        ctor = {"RMS": float(rng.uniform(1e-5, 5e-4)), "smallest": float(rng.uniform(1.5, 4.0)), "seed": int(seed)}
+        np.random.seed(ctor["seed"])
+        kw = {k: v for k, v in ctor.items() if k != "seed"}
+        arrays_extra["el0_map"] = mdef.Fourrier(pc.build_support(e["support"]), **kw).deformation
+        e["defects"] = [{"kind": "fourrier", "map": "el0_map", "ctor": ctor}]
+        if rng.uniform() < 0.5:
+            e["defects"].append({"kind": "zernike", "coeffs": [[3, 1, float(rng.uniform(-1, 1) * 1e-4)]],
+                                 "R": O.support.circum_circ()})
     if deformed:   # DeformedMirror with 1-2 Zernike defects, traced with IgnoreDefects=False
         e["defects"] = []
         for _ in range(int(rng.integers(1, 3))):
@@ -109,7 +121,7 @@ def random_scene(seed, n_rays=1500):
     if (seed // (3 * len(KINDS))) % 2 == 1:
         # second optic on the chief ray after the first (if the chief ray survives it)
         chief = orc.make_bundle(S[None, :], -w[None, :], np.array([0]), np.array([np.nan]), None)
-        after = orc.ray_tracing_calculation(chief, orc.elements_from_scene({"elements": [e]}), IgnoreDefects=True)[0]
+        after = orc.ray_tracing_calculation(chief, orc.elements_from_scene({"elements": [e]}, arrays_extra), IgnoreDefects=True)[0]
         if len(after) == 1:
             e2, _, _ = random_optic(rng, KINDS[int(rng.integers(0, len(KINDS)))])
             pos2 = after.point[0] + float(rng.uniform(50.0, 800.0)) * after.vector[0]
@@ -117,7 +129,7 @@ def random_scene(seed, n_rays=1500):
             elements.append(e2)
     scene = {"elements": elements, "n_source": n_rays, "IgnoreDefects": not deformed}
     arrays = {"src_point": B.point, "src_vector": B.vector, "src_number": B.number,
-              "src_intensity": np.full(n_rays, np.nan)}
+              "src_intensity": np.full(n_rays, np.nan), **arrays_extra}
     return scene, arrays
 
 
@@ -143,10 +155,10 @@ def run_differential(seeds, modes=("chain", "element"), n_rays=1500):
         tag = f"seed {seed} (" + " -> ".join(
             f"{e['type']}{' + Zernike' if e.get('defects') else ''} [{e['support']['kind']}]" for e in scene["elements"]) + ")"
         src_o = orc.make_bundle(a["src_point"], a["src_vector"], a["src_number"], a["src_intensity"], None)
-        refs = orc.ray_tracing_calculation(src_o, orc.elements_from_scene(scene), IgnoreDefects=scene["IgnoreDefects"])
+        refs = orc.ray_tracing_calculation(src_o, orc.elements_from_scene(scene, a), IgnoreDefects=scene["IgnoreDefects"])
         hits += int(len(refs[-1]) > 0)
         scale = pc.scene_scale(a, scene)
-        els = pc.build_elements(scene)
+        els = pc.build_elements(scene, a)
         src = RayBundle.from_arrays(a["src_point"], a["src_vector"], a["src_number"], None, None)
         for mode in modes:
             outs = mp.RayTracingCalculation(src, els, IgnoreDefects=scene["IgnoreDefects"], mode=mode)
@@ -188,11 +200,11 @@ def run_detector_fuzz(seeds, n_rays=1200):
         scene, a = random_scene(seed, n_rays)
         rng = np.random.default_rng(seed + 77_000_000)
         src_o = orc.make_bundle(a["src_point"], a["src_vector"], a["src_number"], a["src_intensity"], None)
-        last_o = orc.ray_tracing_calculation(src_o, orc.elements_from_scene(scene),
+        last_o = orc.ray_tracing_calculation(src_o, orc.elements_from_scene(scene, a),
                                              IgnoreDefects=scene["IgnoreDefects"])[-1]
         if len(last_o) < 10 or (last_o.incidence >= GRAZING).any():
             continue          # conditioning of the traced bundle itself is the business of run_differential
-        els = pc.build_elements(scene)
+        els = pc.build_elements(scene, a)
         src = RayBundle.from_arrays(a["src_point"], a["src_vector"], a["src_number"], None, None)
         last = mp.RayTracingCalculation(src, els, IgnoreDefects=scene["IgnoreDefects"])[-1]
         assert np.array_equal(last.numbers(), last_o.number)
