@@ -499,3 +499,124 @@ def test_single_ray_methods_and_square_source_match_reference(twin):
             assert len(b) == len(expect)
             assert np.abs(b.points() - np.array([x[0] for x in expect])).max() <= 1e-12
             assert np.abs(b.vectors() - np.array([x[1] for x in expect])).max() <= 1e-12
+
+
+DET_GEN = textwrap.dedent('''
+    def detector_session(seed, mdet, last, refpoint):
+        """Random sequence of Detector operations on the last bundle of a chain; returns a JSON-able log."""
+        rng = np.random.default_rng(seed + 777)
+        log = []
+        def state(D, tag):
+            log.append([tag, None if D.centre is None else [float(v) for v in D.centre],
+                        None if D.normal is None else [float(v) for v in D.normal], [float(v) for v in D.refpoint]])
+        def attempt(tag, fn):
+            try:
+                v = fn()
+                log.append([tag, "ok" if v is None else v])
+            except Exception as e:
+                log.append([tag, "raises " + type(e).__name__])
+        D = mdet.Detector(np.asarray(refpoint, dtype=float))
+        attempt("incomplete.get_distance", lambda: float(D.get_distance()))
+        attempt("incomplete.points", lambda: len(D.get_PointList2D(last)))
+        attempt("bad centre", lambda: setattr(D, "centre", [1.0, 2.0, 3.0]))
+        attempt("bad normal", lambda: setattr(D, "normal", np.zeros(3)))
+        attempt("bad refpoint", lambda: setattr(D, "refpoint", np.zeros(2)))
+        D.autoplace(last, float(rng.uniform(30, 500)))
+        state(D, "autoplace")
+        for _ in range(int(rng.integers(2, 6))):
+            k = int(rng.integers(0, 4))
+            if k == 0:
+                D.shiftByDistance(float(rng.uniform(-20, 40)))
+            elif k == 1:
+                D.shiftToDistance(float(rng.uniform(5, 400)))
+            elif k == 2:
+                D = D.copy_detector()
+            else:
+                n = D.normal + 0.2 * rng.normal(size=3)
+                D.normal = n
+                D.centre = D.centre + rng.normal(size=3)
+            state(D, "op%d" % k)
+            log.append(["distance", float(D.get_distance())])
+        P3 = np.array([np.asarray(p, dtype=float) for p in D.get_PointList3D(last)])
+        P2 = np.array([np.asarray(p, dtype=float) for p in D.get_PointList2D(last)])
+        PC = np.array([np.asarray(p, dtype=float) for p in D.get_PointList2DCentre(last)])
+        dl = np.array([float(v) for v in D.get_Delays(last)])
+        log.append(["readout", P3.tolist(), P2.tolist(), PC.tolist(), dl.tolist()])
+        return log
+''')
+
+DET_SCRIPT = textwrap.dedent('''
+    import sys, json
+    sys.dont_write_bytecode = True
+    ROOT, REF, lo, hi = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    sys.path[:0] = [REF, ROOT + "/tests/golden/_standin"]
+    import matplotlib; matplotlib.use("Agg")
+    import numpy as np
+    import ART.ModuleProcessing as mp, ART.ModuleMirror as mmirror, ART.ModuleMask as mmask, ART.ModuleSupport as msupp
+    import ART.ModuleDetector as mdet
+    exec(sys.stdin.read())
+    out = {}
+    for seed in range(lo, hi):
+        SP, optics, dist, inc, plane = make_case(seed, mmirror, mmask, msupp)
+        SP["NumberRays"] = 60
+        try:
+            ch = mp.OEPlacement(SP, optics, dist, inc, plane, "fuzz")
+            last = ch.get_output_rays()[-1]
+        except Exception as e:
+            out[seed] = {"skip": type(e).__name__}
+            continue
+        if len(last) < 10:
+            out[seed] = {"skip": "few rays"}
+            continue
+        out[seed] = {"log": detector_session(seed, mdet, last, ch.optical_elements[-1].position)}
+    print("RESULT" + json.dumps(out))
+''')
+
+
+def test_detector_sessions_match_reference(twin):
+    """Detector construction errors, autoplace, shiftBy/shiftTo/copy, manual re-posing, and the four read-out
+    methods in random sequences (ART/ModuleDetector.py:47-279)."""
+    lo, hi = 0, int(os.environ.get("ART_FUZZ_DETECTOR", "40"))
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, "-c", DET_SCRIPT, ROOT, REF, str(lo), str(hi)], input=GENERATOR + DET_GEN,
+                       capture_output=True, text=True, timeout=3000, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    ref = json.loads(r.stdout[r.stdout.index("RESULT") + 6:])
+    import ART.ModuleProcessing as mp
+    import ART.ModuleMirror as mmirror
+    import ART.ModuleMask as mmask
+    import ART.ModuleSupport as msupp
+    import ART.ModuleDetector as mdet
+    ns = {}
+    exec(GENERATOR + DET_GEN, ns)
+    compared = 0
+    for seed in range(lo, hi):
+        e = ref[str(seed)]
+        if "skip" in e:
+            continue
+        SP, optics, dist, inc, plane = ns["make_case"](seed, mmirror, mmask, msupp)
+        SP["NumberRays"] = 60
+        ch = mp.OEPlacement(SP, optics, dist, inc, plane, "fuzz")
+        last = ch.get_output_rays()[-1]
+        mine = ns["detector_session"](seed, mdet, last, ch.optical_elements[-1].position)
+        assert len(mine) == len(e["log"]), seed
+        for a, b in zip(mine, e["log"]):
+            assert a[0] == b[0], (seed, a[0], b[0])
+            if a[0] == "readout":
+                scale = max(1.0, np.abs(np.array(b[1])).max())
+                # delays are path differences: tolerance relative to the travel time over the scene scale
+                travel_fs = scale / 299792458000.0 * 1e15
+                for x, y, tol in zip(a[1:4], b[1:4], (1e-9 * scale,) * 3):
+                    assert np.abs(np.array(x) - np.array(y)).max() <= tol, (seed, a[0])
+                assert np.abs(np.array(a[4]) - np.array(b[4])).max() <= 1e-9 * travel_fs, seed
+            elif a[0] == "distance" or isinstance(b[1], float):
+                assert abs(a[1] - b[1]) <= 1e-9 * max(1.0, abs(b[1])), (seed, a, b)
+            elif isinstance(b[1], str) or b[1] is None or isinstance(b[1], int):
+                assert a[1] == b[1], (seed, a, b)
+            else:
+                for x, y in zip(a[1:], b[1:]):
+                    assert (x is None) == (y is None), (seed, a, b)
+                    if x is not None:
+                        assert np.abs(np.array(x) - np.array(y)).max() <= 1e-9 * max(1.0, np.abs(y).max()), (seed, a[0])
+        compared += 1
+    assert compared >= (hi - lo) // 3
