@@ -33,12 +33,12 @@ class Ray:
     __slots__ = ("_point", "_vector", "_path", "_number", "_wavelength", "_incidence", "_intensity")
 
     def __init__(self, Point, Vector, Path=(0.0,), Number=None, Wavelength=None, Incidence=None, Intensity=None):
-        if Number is not None and not isinstance(Number, (int, np.integer)):
+        if Number is not None and type(Number) is not int:      # a NumPy integer is refused too (:60-63)
             raise TypeError("Ray Number must be an integer.")
         self.point, self.vector = Point, Vector
         # the optional attributes bypass their setters at construction, so None is allowed (:57-60)
         self._path, self._wavelength, self._incidence, self._intensity = Path, Wavelength, Incidence, Intensity
-        self._number = None if Number is None else int(Number)
+        self._number = Number
 
     # origin of the ray
     def _get_point(self):

@@ -332,6 +332,10 @@ def _scan(detector, Amplitude, Step, RayList, OptFor, IntensityWeighted):
     """One pass of the detector scan (ART/ModuleProcessing.py:317-366).  The read-out of every ray is linear in the
     detector shift, so the spot size and duration at all scan positions follow from one set of moment sums computed
     on the device (Detector._scan_moments: two passes over the bundle, all rays) instead of one pass per position."""
+    if OptFor not in ("intensity", "duration", "spotsize"):
+        # FindOptimalDistance lets "size" through, but the reference's scan only knows "spotsize": its fitness is
+        # then never assigned (ART/ModuleProcessing.py:342-348)
+        raise UnboundLocalError("local variable 'Fitness' referenced before assignment")
     detector.shiftByDistance(-Amplitude)
     n = int(2 * Amplitude / Step)
     mom = detector._scan_moments(RayList, span=(n - 1) * Step)

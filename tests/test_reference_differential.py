@@ -620,3 +620,160 @@ def test_detector_sessions_match_reference(twin):
                         assert np.abs(np.array(x) - np.array(y)).max() <= 1e-9 * max(1.0, np.abs(y).max()), (seed, a[0])
         compared += 1
     assert compared >= (hi - lo) // 3
+
+
+ERR_CASES = [
+    "mray.Ray([0, 0, 0], np.array([0, 0, 1.0]))",
+    "mray.Ray(np.zeros(3), np.zeros(3))",
+    "mray.Ray(np.zeros(3), np.array([0, 0, 1e-12]))",
+    "mray.Ray(np.zeros(3), np.array([0, 0, 2.0]), Number=1.5)",
+    "mray.Ray(np.zeros(3), np.array([0, 0, 2.0]), Number=np.int64(3)).number",
+    "tuple(mray.Ray(np.zeros(3), np.array([0, 3.0, 4.0])).vector)",
+    "setattr(ray, 'wavelength', 'red')",
+    "setattr(ray, 'wavelength', 5)",
+    "setattr(ray, 'incidence', 1)",
+    "setattr(ray, 'incidence', 0.5)",
+    "setattr(ray, 'intensity', None)",
+    "setattr(ray, 'intensity', np.float64(0.5))",
+    "setattr(ray, 'number', 4)",
+    "setattr(ray, 'point', [1, 2, 3])",
+    "setattr(ray, 'vector', np.zeros(3))",
+    "hash(ray) == hash(ray.copy_ray())",
+    "moe.OpticalElement(plane, [0, 0, 0], np.array([0, 0, 1.0]), np.array([1.0, 0, 0]))",
+    "moe.OpticalElement(plane, np.zeros(3), np.array([0, 0, 0.0]), np.array([1.0, 0, 0]))",
+    "moe.OpticalElement(plane, np.zeros(3), np.array([0, 0, 1.0]), np.array([0, 0, 1.0]))",
+    "tuple(moe.OpticalElement(plane, np.zeros(3), np.array([0, 0, 2.0]), np.array([3.0, 0, 1.0])).majoraxis)",
+    "moe.OpticalElement('mirror', np.zeros(3), np.array([0, 0, 1.0]), np.array([1.0, 0, 0])).type",
+    "moc.OpticalChain([], [])",
+    "moc.OpticalChain('rays', [oe])",
+    "moc.OpticalChain([ray], 'elements')",
+    "moc.OpticalChain([ray], [plane])",
+    "moc.OpticalChain([ray], [oe], 5)",
+    "moc.OpticalChain([ray], [oe], 'x', 7, 1.0)",
+    "len(moc.OpticalChain([ray], [oe]).get_output_rays()[0])",
+    "mmirror.MirrorEllipsoidal(sup)",
+    "mmirror.MirrorEllipsoidal(sup, SemiMajorAxis=300)",
+    "mmirror.MirrorEllipsoidal(sup, f_object=300, f_image=200)",
+    "round(mmirror.MirrorEllipsoidal(sup, f_object=300, f_image=200, OffAxisAngle=60).b, 9)",
+    "round(mmirror.MirrorEllipsoidal(sup, SemiMajorAxis=300, SemiMinorAxis=200)._offaxisangle, 12)",
+    "round(mmirror.MirrorEllipsoidal(sup, SemiMajorAxis=300, SemiMinorAxis=200, f_object=350, f_image=250)._offaxisangle, 12)",
+    "mmirror.MirrorSpherical(-100, sup).type",
+    "mmirror.MirrorCylindrical(-100, sup).type",
+    "[round(v, 9) for v in mmirror.ReturnOptimalToroidalRadii(500, 75)]",
+    "round(mmirror.MirrorParabolic(100, 90, sup)._p, 12)",
+    "mdef.MeasuredMap(sup, {})",
+    "mp.FindOptimalDistance(det, chain.get_output_rays()[-1], 'spotsize')",
+    "mp.FindOptimalDistance(det, chain.get_output_rays()[-1], 'size')",
+    "chain.shift_source('diagonal', 1.0)",
+    "chain.shift_source('vert', '1')",
+    "chain.tilt_source('sideways', 1.0)",
+    "chain.tilt_source('in_plane', [1])",
+    "chain.rotate_OE(7, 'pitch', 1.0)",
+    "chain.rotate_OE(0, 'spin', 1.0)",
+    "chain.rotate_OE(0, 'pitch', '1')",
+    "chain.shift_OE(0, 'sideways', 1.0)",
+    "chain.shift_OE(-9, 'normal', 1.0)",
+    "chain.get_OE_loop_list(0, 'bad', [1.0])",
+    "chain.get_OE_loop_list(0, 'pitch', 1.0)",
+    "chain.get_source_loop_list('tilt_in_plane', 5)",
+    "chain.get_source_loop_list('zoom', [1.0])",
+    "[c.loop_variable_name for c in chain.get_source_loop_list('shift_vert', [0.1, 0.2])]",
+    "[c.loop_variable_name for c in chain.get_OE_loop_list(-1, 'shift_major', [0.1])]",
+    "planechain.shift_source('vert', 1.0)",
+    "mp.OEPlacement(dict(SP), [tor, tor], [[100, 200], 300], [[80, 70], -80])",
+    "len(mp.OEPlacement(dict(SP), [tor, tor], [[100, 200], 300], [80, -80]))",
+    "mp.OEPlacement(dict(SP), [tor, tor], [100, 300], [80, [-80, -70]])[1].loop_variable_name",
+    "mp.OEPlacement(dict(SP), [tor, 'lens'], [100, 300], [80, -80])",
+    "mp.RayTracingCalculation([ray], [moe.OpticalElement(Odd(), np.zeros(3), np.array([0, 0, 1.0]), np.array([1.0, 0, 0]))])",
+    "mp.ReturnNumericalAperture(chain.get_output_rays()[-1], 1) > 0",
+    "round(mp.ReturnAiryRadius(50e-6, 0.01), 12)",
+    "mp.ReturnAiryRadius(50e-6, 1e-4)",
+    "round(mp.StandardDeviation([np.array([0.0, 1.0]), np.array([2.0, 5.0])]), 12)",
+    "round(mp.WeightedStandardDeviation([1.0, 2.0, 4.0], [1.0, 1.0, 2.0]), 12)",
+    "mdet.Detector([0, 0, 0])",
+    "mdet.Detector(np.zeros(3), np.zeros(3), np.zeros(3))",
+    "mdet.Detector(np.zeros(3)).get_distance()",
+    "msupp.SupportRoundHole(10, 2, 1, 1)._IncludeSupport(np.array([1.0, 1.0, 0]))",
+    "msupp.SupportRectangleRectHole(10, 8, 2, 2, 1, 1)._IncludeSupport(np.array([4.9, -4.0, 0]))",
+    "[round(v, 12) for v in msupp.SupportRectangle(6, 8)._CircumRect()] + [round(msupp.SupportRectangle(6, 8)._CircumCirc(), 12)]",
+    "mgeo.SolverQuadratic(0, 2, -4)",
+    "mgeo.SolverQuadratic(1, 0, 1)",
+    "[round(v, 10) for v in mgeo.SolverQuartic(1, 0, -5, 0, 4)]",
+    "mgeo.KeepPositiveSolution([-1, 0, 1e-13, 2])",
+    "mgeo.IncludeRectangle(-4, 2, np.array([2.0, -1.0, 0]))",
+    "[round(v, 12) for v in mgeo.RotationPoint(np.array([1.0, 2, 3]), np.array([0, 0, 1.0]), np.array([0, 0, -1.0]))]",
+    "[round(v, 12) for v in mgeo.VectorPerpendicular(np.array([0.0, 0, 2]))]",
+    "[round(v, 12) for v in mgeo.VectorPerpendicular(np.array([1.0, 2, 0]))]",
+    "round(mgeo.AngleBetweenTwoVectors(np.array([1.0, 0, 0]), np.array([-1.0, 1e-9, 0])), 12)",
+    "mgeo.DiameterPointList([])",
+    "round(mgeo.DiameterPointList([np.array([0.0, 0]), np.array([3.0, 4])]), 12)",
+]
+
+ERR_PRELUDE = textwrap.dedent('''
+    import numpy as np
+    import ART.ModuleOpticalRay as mray, ART.ModuleOpticalElement as moe, ART.ModuleOpticalChain as moc
+    import ART.ModuleMirror as mmirror, ART.ModuleMask as mmask, ART.ModuleSupport as msupp, ART.ModuleDefects as mdef
+    import ART.ModuleProcessing as mp, ART.ModuleDetector as mdet, ART.ModuleGeometry as mgeo
+    class Odd:
+        type = "Lens"
+        support = msupp.SupportRound(5)
+        def get_centre(self): return np.zeros(3)
+    def run_cases(cases):
+        out = []
+        for c in cases:
+            sup = msupp.SupportRound(20.0)
+            plane = mmirror.MirrorPlane(sup)
+            ray = mray.Ray(np.zeros(3), np.array([0.0, 0.0, 1.0]), (0.0,), 1, 50e-6, 0.1, 1.0)
+            oe = moe.OpticalElement(plane, np.array([0.0, 0.0, 10.0]), np.array([0.0, 0.6, -0.8]), np.array([1.0, 0.0, 0.0]))
+            R, r = mmirror.ReturnOptimalToroidalRadii(300, 80)
+            tor = mmirror.MirrorToroidal(R, r, msupp.SupportRectangle(150, 30))
+            SP = {"Divergence": 0.01, "SourceSize": 0, "Wavelength": 50e-6, "DeltaFT": 0.5, "NumberRays": 30}
+            chain = mp.OEPlacement(dict(SP), [tor, tor], [300, 600], [80, -80])
+            planechain = mp.OEPlacement(dict(SP), [mmirror.MirrorPlane(msupp.SupportRound(50))], [100], [0])
+            det = mdet.Detector(chain.optical_elements[-1].position)
+            det.autoplace(chain.get_output_rays()[-1], 300)
+            try:
+                v = eval(c)
+                if isinstance(v, (np.bool_, bool)): v = bool(v)
+                elif isinstance(v, (np.integer,)): v = int(v)
+                elif isinstance(v, (np.floating,)): v = float(v)
+                elif isinstance(v, tuple): v = [float(x) for x in v]
+                elif isinstance(v, list): v = [x if isinstance(x, str) else float(x) for x in v]
+                elif not isinstance(v, (int, float, str, type(None))): v = type(v).__name__
+                out.append(["value", v])
+            except Exception as e:
+                out.append(["raises", type(e).__name__])
+        return out
+''')
+
+ERR_SCRIPT = textwrap.dedent('''
+    import sys, json
+    sys.dont_write_bytecode = True
+    ROOT, REF = sys.argv[1], sys.argv[2]
+    sys.path[:0] = [REF, ROOT + "/tests/golden/_standin"]
+    import matplotlib; matplotlib.use("Agg")
+    src = sys.stdin.read()
+    prelude, cases = src.split("#CASES#")
+    exec(prelude)
+    print("RESULT" + json.dumps(run_cases(json.loads(cases))))
+''')
+
+
+def test_values_and_exception_types_of_the_host_api_match_reference(twin, capsys):
+    """A table of small API calls -- constructors with bad arguments, validating setters, helper functions, chain
+    operations with wrong axis names or indices -- evaluated by the reference and by the product: same values, same
+    exception TYPES (SURVEY 8b: "same names, argument meaning and error behaviour")."""
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, "-c", ERR_SCRIPT, ROOT, REF], input=ERR_PRELUDE + "#CASES#" + json.dumps(ERR_CASES),
+                       capture_output=True, text=True, timeout=3000, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    ref = json.loads(r.stdout[r.stdout.index("RESULT") + 6:])
+    ns = {}
+    exec(ERR_PRELUDE, ns)
+    mine = ns["run_cases"](ERR_CASES)
+    bad = []
+    for c, a, b in zip(ERR_CASES, mine, ref):
+        same = a[0] == b[0] and (a[1] == b[1] or (isinstance(b[1], (float, list)) and np.allclose(a[1], b[1], rtol=0, atol=1e-9)))
+        if not same:
+            bad.append((c, a, b))
+    assert not bad, "\\n".join(f"{c}\\n    product:   {a}\\n    reference: {b}" for c, a, b in bad)
