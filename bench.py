@@ -84,6 +84,50 @@ def cpu_baseline(chain, Rr, n_sample):
     return inter / dt, inter, dt
 
 
+def cpu_twin_allcores(chain, n_sample):
+    """Second CPU figure, for scale: the kernels' own per-ray code compiled by g++ (oracle/twin, the test suite's CPU
+    twin) with OpenMP over rays on all host cores, on a sample of the same workload.  Not the reference's algorithm
+    (that is cpu_baseline, the oracle): it shows what the same arithmetic does on the host CPU."""
+    import ctypes as C
+    import subprocess
+    from attosecondraytracing_amd import _abi
+    import ART.ModuleProcessing as mp
+    from oracle import art_oracle as orc
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    # threads: the cores this process may use, at most 16 (a one-GPU box's share of its host)
+    threads = min(len(os.sched_getaffinity(0)), 16)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_twin", "libart_twin.so"))
+    lib.art_cpu_trace_chain.restype = C.c_int
+    lib.art_cpu_trace_chain.argtypes = [C.POINTER(_abi.ArtElementDesc), C.c_int32, C.POINTER(_abi.ArtBundleView),
+                                        C.POINTER(_abi.ArtBundleView), C.c_int64]
+    B = orc.point_source([0.0, 0.0, 0.0], [1.0, 0.0, 0.0], 0.02, n_sample, 50e-6)
+    m = len(chain.optical_elements)
+
+    def block():
+        d = np.zeros((8, n_sample))
+        a = np.ones(n_sample, dtype=np.uint8)
+        v = _abi.ArtBundleView()
+        p = d.ctypes.data
+        v.ox, v.oy, v.oz, v.dx, v.dy, v.dz, v.path, v.incidence = (p + k * n_sample * 8 for k in range(8))
+        v.alive = a.ctypes.data
+        return d, a, v
+    sd, sa, sv = block()
+    sd[0:3], sd[3:6] = B.point.T, B.vector.T
+    outs = [block() for _ in range(m)]
+    descs = (_abi.ArtElementDesc * m)(*[mp.element_descriptor(oe)[0] for oe in chain.optical_elements])
+    views = (_abi.ArtBundleView * m)(*[o[2] for o in outs])
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        rc = lib.art_cpu_trace_chain(descs, m, C.byref(sv), views, n_sample)
+        dt = time.perf_counter() - t0
+        assert rc == 0
+        best = dt if best is None else min(best, dt)
+    inter = n_sample + sum(int(o[1].sum()) for o in outs[:-1])
+    return inter / best, inter, best, threads
+
+
 def profiled_traffic(kernel, n, mirrors, mode):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same workload
     (profiles/rNN_relay<M>_<mode>.json, written by tools/summarize_profile.py from separate --pmc FETCH_SIZE /
@@ -292,6 +336,13 @@ def main():
                                    "sample": f"oracle/art_oracle.py (NumPy, batched LAPACK eigvals; single thread) on "
                                              f"{args.cpu_sample} rays x {args.mirrors} mirrors + detector = {inter} "
                                              f"intersections in {secs:.1f} s; host has {os.cpu_count()} cores"}
+            try:
+                v2, inter2, secs2, thr = cpu_twin_allcores(chain, min(args.cpu_sample, 4_000_000))
+                res["cpu_twin_allcores"] = {"value": v2, "unit": "intersections/s", "cores": thr,
+                                            "note": f"oracle/twin: the kernels' per-ray code built by g++ -O2 -fopenmp, "
+                                                    f"{inter2} intersections in {secs2:.2f} s (best of 3); for scale only"}
+            except Exception as e:    # noqa: BLE001 -- an optional extra must never cost the result line
+                log(f"[bench] cpu_twin_allcores skipped: {e!r}")
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(res), flush=True)

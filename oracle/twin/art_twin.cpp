@@ -47,6 +47,8 @@ int art_cpu_trace_chain(const ArtElementDesc* elems_in, int32_t n_elems, const A
                         const ArtBundleView* outs, int64_t n) {
   std::vector<ArtElementDesc> elems(elems_in, elems_in + n_elems);
   for (auto& e : elems) art::prepare_element(e);
+  // rays are independent: all host cores (used by bench.py's all-cores CPU figure; the tests do not care)
+#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; ++i) {
     bool ok = in->alive[i] != 0;
     art::Ray r;
