@@ -98,6 +98,10 @@ def cpu_twin_allcores(chain, n_sample):
     threads = min(len(os.sched_getaffinity(0)), 16)
     os.environ["OMP_NUM_THREADS"] = str(threads)
     lib = C.CDLL(os.path.join(ROOT, "oracle", "_twin", "libart_twin.so"))
+    try:        # libgomp is usually initialised already (torch links it): set the team size through its API as well
+        C.CDLL("libgomp.so.1").omp_set_num_threads(threads)
+    except OSError:
+        pass
     lib.art_cpu_trace_chain.restype = C.c_int
     lib.art_cpu_trace_chain.argtypes = [C.POINTER(_abi.ArtElementDesc), C.c_int32, C.POINTER(_abi.ArtBundleView),
                                         C.POINTER(_abi.ArtBundleView), C.c_int64]
