@@ -109,7 +109,10 @@ typedef struct ArtElementDesc {
 /* SoA view of one ray bundle (all DEVICE pointers, length n).  `path` is the running optical path
  * (sum of the reference's Ray.path tuple); `incidence` the incidence angle on the element the ray
  * comes from (Ray.incidence).  Ray.number / intensity / wavelength never change along a chain and are
- * therefore not part of the per-element state (slot i of every bundle is source ray i).               */
+ * therefore not part of the per-element state (slot i of every bundle is source ray i).
+ * Alignment: 8 bytes are enough for correctness; for full throughput every array should start on a cache-line
+ * boundary (the package pitches its rows to 512 bytes): rows that start 8 bytes off a line cost about a third of
+ * the bandwidth.  mp[2..3] of a torus descriptor are scratch the library fills in its own copy.              */
 typedef struct ArtBundleView {
   double* ox; double* oy; double* oz;   /* Ray.point  */
   double* dx; double* dy; double* dz;   /* Ray.vector */
