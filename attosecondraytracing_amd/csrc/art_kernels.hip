@@ -1,9 +1,9 @@
 // art_kernels.hip -- gfx950 kernels + the C ABI of libart_hip.so (include/art_hip.h).
 //
-// One ray per lane, SoA fp64 streams read and written with coalesced 8-byte accesses (64 lanes x 8 B =
-// 512 B per wave instruction and per array), element descriptors in kernel arguments (scalar loads ->
-// SGPRs, broadcast for free), Zernike coefficient tables staged once per workgroup in LDS, wavefront
-// ballot on the torus Newton loop.  No MFMA: the path is streaming fp64 VALU work against HBM.
+// One ray per lane, SoA fp64 streams read and written with coalesced, non-temporal 8-byte accesses (64 lanes x
+// 8 B = 512 B per wave instruction and per array; 16 B per lane in the read-out), element descriptors in kernel
+// arguments (scalar loads -> SGPRs, broadcast for free), Zernike coefficient tables staged once per workgroup in
+// LDS, wavefront ballot on the torus Newton loop.  No MFMA: the path is streaming fp64 VALU work against HBM.
 #include <hip/hip_runtime.h>
 
 #include <math.h>
@@ -283,7 +283,8 @@ __global__ __launch_bounds__(kBlock) void k_detector(const ArtDetectorDesc d, co
 
 // ------------------------------------------------------------------------------------------- reductions
 // Deterministic: fixed grid, each lane accumulates its grid-stride slice, wave shuffle tree, LDS across the
-// 4 waves, one partial per workgroup into `scratch`, then a single workgroup folds the partials in order.
+// 4 waves, one partial per workgroup into `scratch`, then fold_slot(): one workgroup per statistic folds the
+// partials in a fixed order.
 constexpr int kRedBlocks = 1024;
 constexpr int kRedSlots = 16;
 
