@@ -1,7 +1,7 @@
 """ctypes mirror of include/art_hip.h (structs, enums, prototypes).  Keep in sync with ART_ABI_VERSION."""
 import ctypes as C
 
-ART_ABI_VERSION = 6
+ART_ABI_VERSION = 7
 
 ART_OK = 0
 ART_ERR_BAD_ARG = -1
@@ -101,6 +101,8 @@ PROTOTYPES = {
     "art_compact": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "art_make_source": (C.c_int, [C.c_int32, C.c_double, c_double_p, c_double_p, C.c_int64, C.c_int64, C.c_int64,
                                   C.POINTER(ArtBundleView), C.c_void_p]),
+    "art_exchange_pack": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_void_p, C.c_void_p]),
+    "art_exchange_fold": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "art_make_extended_source": (C.c_int, [C.c_double, C.c_double, C.c_int64, C.c_int64, c_double_p, c_double_p,
                                            C.c_int64, C.c_int64, C.POINTER(ArtBundleView), C.c_void_p]),
 }

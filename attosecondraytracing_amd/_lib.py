@@ -221,6 +221,18 @@ class HipBackend:
         self.check(self.fn["art_make_source"](kind, float(size), r, s, first, n, n_total, C.byref(view),
                                               self.stream_ptr()), "art_make_source")
 
+    def exchange_pack(self, stats, X, Y, opl, alive, slots, send):
+        """stats[24] + (X, Y, opl, alive) of the sampled slots -> send[24 + 4k] (art_exchange_pack)."""
+        k = int(slots.numel())
+        self.check(self.fn["art_exchange_pack"](stats.data_ptr(), X.data_ptr(), Y.data_ptr(), opl.data_ptr(),
+                                                alive.data_ptr(), slots.data_ptr(), k, send.data_ptr(),
+                                                self.stream_ptr()), "art_exchange_pack")
+
+    def exchange_fold(self, recv, world, stride, out):
+        """Fold `world` gathered statistics vectors into the global 24 (art_exchange_fold)."""
+        self.check(self.fn["art_exchange_fold"](recv.data_ptr(), int(world), int(stride), out.data_ptr(),
+                                                self.stream_ptr()), "art_exchange_fold")
+
     def make_extended_source(self, radius, divergence, n_points, per, rot, S, first, n, view):
         r = (C.c_double * 9)(*[float(v) for v in np.asarray(rot).reshape(9)])
         s = (C.c_double * 3)(*[float(v) for v in np.asarray(S).reshape(3)])

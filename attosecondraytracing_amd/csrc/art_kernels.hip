@@ -658,6 +658,31 @@ __global__ __launch_bounds__(kBlock) void k_make_extended_source(const double ra
   }
 }
 
+// multi-GPU exchange (include/art_hip.h): pack statistics + a sample of the read-out; fold the gathered statistics
+__global__ __launch_bounds__(kBlock) void k_exchange_pack(const double* stats, const double* X, const double* Y,
+                                                          const double* opl, const uint8_t* alive, const int64_t* slots,
+                                                          const int64_t k, double* send) {
+  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j < kReadoutSlots) send[j] = stats[j];
+  if (j < k) {
+    const int64_t s = slots[j];
+    double* o = send + kReadoutSlots + 4 * j;
+    o[0] = X[s]; o[1] = Y[s]; o[2] = opl[s]; o[3] = alive[s] ? 1.0 : 0.0;
+  }
+}
+
+__global__ void k_exchange_fold(const double* recv, const int world, const int64_t stride, double* out) {
+  const int s = threadIdx.x;
+  if (s >= kReadoutSlots) return;
+  const bool is_min = (s == 2 || s == 4 || s == 12), is_max = (s == 3 || s == 5 || s == 13);
+  double v = recv[s];
+  for (int r = 1; r < world; ++r) {       // rank order: deterministic
+    const double w = recv[(int64_t)r * stride + s];
+    v = is_min ? fmin(v, w) : (is_max ? fmax(v, w) : v + w);
+  }
+  out[s] = v;
+}
+
 // rays per launch: the hardware limit, or less when ART_MAX_RAYS_PER_LAUNCH is set (lets tests cover the chunking)
 int64_t max_rays_per_launch() {
   const char* v = getenv("ART_MAX_RAYS_PER_LAUNCH");
@@ -1044,6 +1069,27 @@ int art_make_source(int32_t kind, double size, const double rot[9], const double
                      n_total, *out);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_make_source launch");
+  return ART_OK;
+}
+
+int art_exchange_pack(const double* stats24, const double* X, const double* Y, const double* opl, const uint8_t* alive,
+                      const int64_t* slots, int64_t k, double* send, void* stream) {
+  if (!stats24 || !send) return fail(ART_ERR_BAD_ARG, "stats24/send must not be NULL");
+  if (k < 0 || (k > 0 && (!X || !Y || !opl || !alive || !slots))) return fail(ART_ERR_BAD_ARG, "bad sample arguments");
+  const int64_t work = k > kReadoutSlots ? k : kReadoutSlots;
+  hipLaunchKernelGGL(k_exchange_pack, dim3((unsigned)((work + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                     stats24, X, Y, opl, alive, slots, k, send);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail_hip(err, "art_exchange_pack launch");
+  return ART_OK;
+}
+
+int art_exchange_fold(const double* recv, int32_t world, int64_t stride_doubles, double* stats_out24, void* stream) {
+  if (!recv || !stats_out24) return fail(ART_ERR_BAD_ARG, "recv/stats_out24 must not be NULL");
+  if (world < 1 || stride_doubles < kReadoutSlots) return fail(ART_ERR_BAD_ARG, "bad world size or stride");
+  hipLaunchKernelGGL(k_exchange_fold, dim3(1), dim3(64), 0, (hipStream_t)stream, recv, world, stride_doubles, stats_out24);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail_hip(err, "art_exchange_fold launch");
   return ART_OK;
 }
 

@@ -94,3 +94,58 @@ def gather_readout(X, Y, opl, alive, dst=0, pack=None, sizes=None, async_op=Fals
     dist.gather(send, None, dst=dst)
     dist.gather(asend, None, dst=dst)
     return None, None
+
+
+def sample_slots(n, k, device):
+    """`k` evenly spaced slot indices of a shard of n slots (all of them if n <= k), as an int64 tensor on `device`."""
+    if n <= k:
+        return torch.arange(n, dtype=torch.int64, device=device)
+    return torch.unique(torch.linspace(0, n - 1, k, device=device).to(torch.int64))
+
+
+def gather_sample(X, Y, opl, alive, slots, dst=0, pack=None):
+    """Gather an evenly spaced SAMPLE of every shard's read-out to rank `dst`: what a spot diagram or delay graph
+    consumes (the plots draw at most ~2e4 markers; the statistics they print are reduced over all rays by
+    allreduce_stats).  A few hundred kB instead of 25 B x every ray, so it fits inside every step.
+    `slots` = sample_slots(...) of this shard (every rank must use the same count); `pack` may hold preallocated
+    {'recv': [world x [4, k]]} on dst.  Returns ([4, world*k] float64: X, Y, opl, alive-as-0/1) on dst, None elsewhere."""
+    send = torch.stack([X.index_select(0, slots), Y.index_select(0, slots), opl.index_select(0, slots),
+                        alive.index_select(0, slots).to(torch.float64)])
+    if not (dist.is_available() and dist.is_initialized()):
+        return send
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if rank == dst:
+        recv = pack["recv"] if pack else [torch.empty_like(send) for _ in range(world)]
+        dist.gather(send, recv, dst=dst)
+        return torch.cat(recv, dim=1)
+    dist.gather(send, None, dst=dst)
+    return None
+
+
+class Exchange:
+    """The per-step exchange of a sharded run in ONE collective: statistics of every shard + an evenly spaced sample
+    of every shard's read-out, all-gathered (every rank gets the global statistics; any rank can draw the sample).
+    Buffers are allocated once; per step it costs two tiny kernels (art_exchange_pack / art_exchange_fold) and the
+    all-gather -- the host work of a step stays far below its GPU time."""
+
+    def __init__(self, backend, n_slots, sample=20000):
+        self.be = backend
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        per_rank = 0 if sample <= 0 else max(1, sample // self.world)      # sample = 0: statistics only
+        self.slots = (sample_slots(n_slots, per_rank, backend.device) if per_rank
+                      else torch.empty(0, dtype=torch.int64, device=backend.device))
+        self.k = int(self.slots.numel())
+        self.stride = 24 + 4 * self.k
+        self.send = torch.empty(self.stride, dtype=torch.float64, device=backend.device)
+        self.recv = torch.empty(self.world * self.stride, dtype=torch.float64, device=backend.device)
+        self.stats = torch.empty(24, dtype=torch.float64, device=backend.device)
+
+    def __call__(self, stats_dev, X, Y, opl, alive):
+        """Returns (global statistics [24], sample [world, k, 4] = X, Y, opl, alive) -- views of reused buffers."""
+        self.be.exchange_pack(stats_dev, X, Y, opl, alive, self.slots, self.send)
+        if self.world > 1 or (dist.is_available() and dist.is_initialized()):
+            dist.all_gather_into_tensor(self.recv, self.send)
+        else:
+            self.recv.copy_(self.send)
+        self.be.exchange_fold(self.recv, self.world, self.stride, self.stats)
+        return self.stats, self.recv.view(self.world, self.stride)[:, 24:].reshape(self.world, self.k, 4)

@@ -158,9 +158,12 @@ def main():
     ap.add_argument("--rays", type=int, default=10_000_000, help="rays per GPU")
     ap.add_argument("--mirrors", type=int, default=4)
     ap.add_argument("--mode", default=None, choices=[None, "chain", "element"])
-    ap.add_argument("--gather", default="ondemand", choices=["ondemand", "full"],
-                    help="N > 1: gather the per-ray read-out to rank 0 on demand (after the timed steps; default) "
-                         "or inside every step")
+    ap.add_argument("--gather", default="sample", choices=["sample", "ondemand", "full"],
+                    help="N > 1, what is exchanged inside every step: 'sample' (default) = the 24 statistics + an evenly "
+                         "spaced 20000-ray sample of the read-out (what the plots consume) in ONE all-gather; "
+                         "'ondemand' = the statistics only; 'full' = statistics + every ray's read-out gathered to "
+                         "rank 0, double-buffered behind the next step.  The full gather is always executed and timed "
+                         "once after the steps (gather_to_rank0_ms).")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="rays of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -215,6 +218,10 @@ def main():
 
     packs, works = [], [None, None]
     gather_each_step = use_dist and args.gather == "full"
+    sample_each_step = use_dist and args.gather == "sample"
+    exchange = sharding.Exchange(be, n, sample=20000 if sample_each_step else 0) if use_dist else None
+    sample_k = exchange.k if exchange else 0
+    last_sample = [None]
     if use_dist:
         import torch.distributed as dist
         # double-buffered gather buffers: the gather of step i (RCCL, its own stream) overlaps the tracing of
@@ -227,21 +234,15 @@ def main():
                 pk["arecv"] = [torch.empty(n, dtype=torch.uint8, device=be.device) for _ in range(world)]
             packs.append(pk)
     step_no = [0]
-    pending, last_stats = [], [None]
+    last_stats = [None]
 
     def step():
         # nothing in a step blocks the host: launches queue up like the steps of a training loop
         o = mp.RayTracingCalculation(src, els, mode=mode)
         r = det.readout(o[-1], sync=False)
         if use_dist:
-            # global statistics: exchanged on RCCL's stream while this stream goes on with the next step; folded
-            # two steps later (and for the last steps in drain()), so no stream ever idles on the collective
-            if os.environ.get("ART_STATS_ASYNC", "0") == "1":
-                pending.append(sharding.allreduce_stats(r["stats_dev"], be.device, async_op=True))
-                if len(pending) > 2:
-                    r["stats_global_prev"] = pending.pop(0).result()
-            else:
-                last_stats[0] = sharding.allreduce_stats(r["stats_dev"], be.device)
+            # ONE collective per step: statistics of every shard (+ a sample of every shard's read-out)
+            last_stats[0], last_sample[0] = exchange(r["stats_dev"], r["X"], r["Y"], r["opl"], o[-1].alive)
         if gather_each_step:
             b = step_no[0] % 2
             step_no[0] += 1
@@ -253,8 +254,6 @@ def main():
         return o, r
 
     def drain():
-        while pending:
-            last_stats[0] = pending.pop(0).result()
         for b in range(2):
             if works[b] is not None:
                 for w in works[b]:
@@ -294,6 +293,11 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
             gather_ms = (time.perf_counter() - tg) * 1e3
+        if rank == 0 and sample_each_step:
+            S = last_sample[0]
+            assert S.shape == (world, sample_k, 4)
+            own = torch.stack([r["X"], r["Y"], r["opl"]]).index_select(1, exchange.slots).T
+            assert torch.equal(S[0][:, 0:3], own)                        # rank 0's own part of the last step's sample
         if rank == 0:
             assert XYO.shape == (3, n * world) and int(alv.sum().item()) > 0
             assert torch.equal(XYO[:, :n], torch.stack([r["X"], r["Y"], r["opl"]]))   # rank 0's own shard, in place
@@ -319,7 +323,9 @@ def main():
                                    f"= {inter_per_step_rank} intersections/GPU/step; full per-element history",
                        "rays_per_gpu": n, "mirrors": args.mirrors, "trace_mode": mode,
                        "step": "RayTracingCalculation + Detector.readout"
-                               + (" + RCCL all-reduce of the 24 statistics" if use_dist else "")
+                               + (" + ONE RCCL all-gather of the 24 statistics of every shard, folded on the device"
+                                  if use_dist else "")
+                               + (f" (it also carries a {sample_k * world}-ray sample of the read-out)" if sample_each_step else "")
                                + (" + RCCL gather of the per-ray read-out to rank 0 (overlapped)" if gather_each_step else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None if tr is None else tr[0],
@@ -332,7 +338,9 @@ def main():
             "gather_to_rank0_ms": gather_ms,
             "gather_note": None if gather_ms is None else
             f"one gather of the {n * world}-ray read-out (25 B/ray) to rank 0, run after the timed steps; "
-            f"{'inside' if gather_each_step else 'not inside'} the timed step",
+            f"{'inside' if gather_each_step else 'not inside'} the timed step"
+            + (f"; every timed step all-gathers the statistics and a {sample_k * world}-ray sample (32 B/ray) in one "
+               f"collective" if sample_each_step else ""),
         }
         if world == 1 and args.cpu_sample > 0:
             v, inter, secs = cpu_baseline(chain, Rr, args.cpu_sample)

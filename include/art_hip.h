@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ART_ABI_VERSION 6
+#define ART_ABI_VERSION 7
 
 /* error codes */
 #define ART_OK 0
@@ -251,6 +251,16 @@ int art_make_source(int32_t kind, double size, const double rot[9], const double
 int art_make_extended_source(double radius, double divergence, int64_t n_points, int64_t rays_per_point,
                              const double rot[9], const double S[3], int64_t first, int64_t n,
                              const ArtBundleView* out, void* stream);
+
+/* Multi-GPU exchange at the detector, two tiny kernels around ONE all-gather (sharding.py): every rank packs
+ *   send[0..23]            its 24 read-out statistics (art_detector_readout)
+ *   send[24 + 4*j + 0..3]  X, Y, opl, alive (0/1) of its sampled slot slots[j], j < k
+ * all ranks all-gather their (24 + 4k)-vectors (rank-major `recv`), and art_exchange_fold folds the `world` statistics
+ * vectors into the global ones (slots 2,4,12: min; 3,5,13: max; others: sum -- the slot layout of
+ * art_detector_readout).  The sample parts stay where the collective put them.  All pointers DEVICE.       */
+int art_exchange_pack(const double* stats24, const double* X, const double* Y, const double* opl,
+                      const uint8_t* alive, const int64_t* slots, int64_t k, double* send, void* stream);
+int art_exchange_fold(const double* recv, int32_t world, int64_t stride_doubles, double* stats_out24, void* stream);
 
 #ifdef __cplusplus
 }

@@ -70,6 +70,29 @@ def _worker(rank, world, port, n_total, q):
         if rank == 0:
             again = torch.cat([t[:, :sz] for t, sz in zip(pack["recv"], sizes)], dim=1)
             assert torch.equal(again, XYO)
+        # sampled gather (what bench.py does inside every step at N > 1): equal counts on every rank
+        k = 100
+        slots = sharding.sample_slots(min(sizes), k, torch.device("cpu"))
+        S = sharding.gather_sample(r["X"], r["Y"], r["opl"], last.alive, slots, 0)
+        if rank == 0:
+            assert S.shape == (4, world * len(slots))
+            off = 0
+            for kk in range(world):
+                part = S[:, kk * len(slots):(kk + 1) * len(slots)]
+                assert torch.equal(part[0:3], XYO[:, off + slots]) and torch.equal(part[3], alive[off + slots].to(torch.float64))
+                off += sizes[kk]
+        else:
+            assert S is None
+        # the one-collective form bench.py uses in every step at N > 1: statistics + sample in ONE all-gather
+        ex = sharding.Exchange(_lib.get_backend(), min(sizes), sample=200)
+        st2, smp = ex(r["stats_dev"], r["X"], r["Y"], r["opl"], last.alive)
+        assert torch.equal(st2, stats)                       # same fold as allreduce_stats, bit for bit
+        assert smp.shape == (world, ex.k, 4)
+        mine = torch.stack([r["X"][ex.slots], r["Y"][ex.slots], r["opl"][ex.slots], last.alive[ex.slots].to(torch.float64)], dim=1)
+        assert torch.equal(smp[rank], mine)
+        if rank == 0:
+            off = sizes[0]
+            assert torch.equal(smp[1][:, 0:3], XYO[:, off + ex.slots].T)    # the other rank's sample, global order
         if rank == 0:
             q.put((stats.numpy(), XYO.numpy(), alive.numpy()))
         else:

@@ -204,6 +204,21 @@ class TwinBackend:
         s = (C.c_double * 3)(*[float(v) for v in np.asarray(S).reshape(3)])
         assert self.lib.art_cpu_make_source(kind, float(size), r, s, first, n, n_total, C.byref(view)) == 0
 
+    def exchange_pack(self, stats, X, Y, opl, alive, slots, send):
+        k = int(slots.numel())
+        send[:24] = stats
+        if k:
+            send[24:24 + 4 * k] = torch.stack([X[slots], Y[slots], opl[slots], alive[slots].to(torch.float64)], dim=1).reshape(-1)
+
+    def exchange_fold(self, recv, world, stride, out):
+        allv = recv.view(world, stride)[:, :24]
+        res = allv.sum(dim=0)
+        for s in (2, 4, 12):
+            res[s] = allv[:, s].min()
+        for s in (3, 5, 13):
+            res[s] = allv[:, s].max()
+        out.copy_(res)
+
     def make_extended_source(self, radius, divergence, n_points, per, rot, S, first, n, view):
         r = (C.c_double * 9)(*[float(v) for v in np.asarray(rot).reshape(9)])
         s = (C.c_double * 3)(*[float(v) for v in np.asarray(S).reshape(3)])
