@@ -217,6 +217,43 @@ def test_gpu_fuzz_differential(hip):
     fz.run_source_fuzz(range(100))
 
 
+def test_gpu_exchange_kernels(hip):
+    """art_exchange_pack / art_exchange_fold (the per-step multi-GPU exchange) against torch, incl. a fold over
+    several fake ranks."""
+    import torch
+    from attosecondraytracing_amd import sharding, _lib
+    be = _lib.get_backend()
+    n = 100_003
+    g = torch.Generator(device="cpu").manual_seed(5)
+    X, Y, O = (torch.randn(n, generator=g, dtype=torch.float64).to(be.device) for _ in range(3))
+    alive = (torch.rand(n, generator=g) > 0.3).to(torch.uint8).to(be.device)
+    stats = torch.randn(24, generator=g, dtype=torch.float64).to(be.device)
+    ex = sharding.Exchange(be, n, sample=1000)
+    st, smp = ex(stats, X, Y, O, alive)
+    assert torch.equal(st, stats) and smp.shape == (1, ex.k, 4) and ex.k == 1000
+    ref = torch.stack([X[ex.slots], Y[ex.slots], O[ex.slots], alive[ex.slots].to(torch.float64)], dim=1)
+    assert torch.equal(smp[0], ref)
+    ex0 = sharding.Exchange(be, n, sample=0)            # statistics only
+    st0, smp0 = ex0(stats, X, Y, O, alive)
+    assert torch.equal(st0, stats) and smp0.shape == (1, 0, 4)
+    # fold over 5 fake ranks
+    world, stride = 5, 24 + 8
+    recv = torch.randn(world * stride, generator=g, dtype=torch.float64).to(be.device)
+    out = torch.empty(24, dtype=torch.float64, device=be.device)
+    be.exchange_fold(recv, world, stride, out)
+    allv = recv.view(world, stride)[:, :24].cpu()
+    want = allv[0].clone()
+    for r in range(1, world):
+        want = want + allv[r]
+    for sl in (2, 4, 12):
+        want[sl] = allv[:, sl].min()
+    for sl in (3, 5, 13):
+        want[sl] = allv[:, sl].max()
+    assert torch.equal(out.cpu(), want)
+    with pytest.raises(RuntimeError):
+        be.exchange_fold(recv, 0, stride, out)
+
+
 def test_gpu_error_paths(hip):
     """Bad arguments come back as error codes with a message, never as a crash."""
     import ctypes as C
