@@ -122,3 +122,79 @@ def test_ellipsoid_images_focus_to_focus(twin, f_o, offaxis_deg):
     opl = det.get_OpticalPaths(out)
     assert (opl.max() - opl.min()) <= 1e-10 * opl.mean()
     assert abs(opl.mean() - 2 * ell.a) <= 1e-9 * ell.a         # string construction: f_o + f_i = 2a
+
+
+@settings(max_examples=20, deadline=None)
+@given(st.floats(50, 800), st.floats(0, 75), st.floats(20, 400), st.integers(0, 2 ** 31 - 1))
+def test_plane_mirror_images_a_point_source(twin, dist_, inc_deg, after, seed):
+    """Plane mirror: every reflected ray, traced backwards, passes through the mirror image of the source point, and
+    its optical path to any point equals the straight distance from that image point."""
+    import ART.ModuleMirror as mmirror
+    import ART.ModuleSupport as msupp
+    rng = np.random.default_rng(seed)
+    S = np.array([0.0, 0.0, 0.0])
+    th = np.deg2rad(inc_deg)
+    pos = np.array([dist_, 0.0, 0.0])
+    normal = np.array([-np.cos(th), np.sin(th), 0.0])            # faces the source under the incidence angle
+    major = np.array([np.sin(th), np.cos(th), 0.0])
+    n = 200
+    d = np.stack([np.ones(n), rng.uniform(-0.02, 0.02, n), rng.uniform(-0.02, 0.02, n)], axis=1)
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    src, out, oe, _ = _trace(mmirror.MirrorPlane(msupp.SupportRound(1e4)), pos, normal, major, np.tile(S, (n, 1)), d)
+    assert len(out) == n
+    image = S - 2 * np.dot(S - pos, normal) * normal             # mirror image of the source
+    P, V, path = out.points(), out.vectors(), out.paths_total()
+    # the reflected rays diverge from the image point: (P - image) is parallel to V, |P - image| is the path so far
+    back = P - image
+    assert np.abs(np.cross(back, V)).max() <= 1e-10 * dist_
+    assert np.abs(np.linalg.norm(back, axis=1) - path).max() <= 1e-10 * dist_
+    Q = P + after * V
+    assert np.abs(np.linalg.norm(Q - image, axis=1) - (path + after)).max() <= 1e-10 * (dist_ + after)
+
+
+@settings(max_examples=15, deadline=None)
+@given(st.floats(200, 4000), st.floats(1e-4, 2e-3))
+def test_sphere_at_normal_incidence_focuses_paraxial_rays_at_half_the_radius(twin, R, h_rel):
+    """Concave sphere, rays parallel to its axis at height h: they cross the axis at R/2 minus the spherical
+    aberration R/2 (1/cos(asin(h/R)) - 1) -- the exact closed form, hence a known answer for any h."""
+    import ART.ModuleMirror as mmirror
+    import ART.ModuleSupport as msupp
+    h = h_rel * R * np.array([1.0, 3.0, 10.0])
+    pts = np.stack([np.full(3, 0.0), h, np.zeros(3)], axis=1)   # rays along +x at heights h above the axis
+    d = np.tile(np.array([1.0, 0.0, 0.0]), (3, 1))
+    pos = np.array([R, 0.0, 0.0])                               # vertex; centre of curvature at the origin
+    src, out, oe, _ = _trace(mmirror.MirrorSpherical(R, msupp.SupportRound(R / 2)), pos, np.array([-1.0, 0.0, 0.0]),
+                             np.array([0.0, 1.0, 0.0]), pts, d)
+    assert len(out) == 3
+    P, V = out.points(), out.vectors()
+    t = -P[:, 1] / V[:, 1]                                       # where the reflected ray meets the axis y = 0
+    x_cross = P[:, 0] + t * V[:, 0]
+    theta = np.arcsin(h / R)
+    expect = R / (2 * np.cos(theta))                             # distance of the crossing point from the centre
+    assert np.abs(x_cross - expect).max() <= 1e-9 * R
+    assert abs(x_cross[0] - R / 2) <= 1e-5 * R                   # paraxial limit
+
+
+def test_toroid_2f_2f_images_the_source(twin):
+    """A toroid from ReturnOptimalToroidalRadii(f, angle) used 2f-2f: the chief ray reaches the mirror after exactly
+    2f (OEPlacement puts the mirror there), and a detector 2f behind the mirror sees an image far smaller than the
+    footprint of the bundle on the mirror, with the chief ray's total path at 4f to within the cone's asymmetry."""
+    import ART.ModuleMirror as mmirror
+    import ART.ModuleSupport as msupp
+    import ART.ModuleProcessing as mp
+    import ART.ModuleDetector as mdet
+    f, ang = 300.0, 80.0
+    R, r = mmirror.ReturnOptimalToroidalRadii(f, ang)
+    SP = {"Divergence": 2e-3, "SourceSize": 0, "Wavelength": 50e-6, "DeltaFT": 0.5, "NumberRays": 400}
+    ch = mp.OEPlacement(SP, [mmirror.MirrorToroidal(R, r, msupp.SupportRectangle(150, 30))], [2 * f], [ang])
+    out = ch.get_output_rays()[-1]
+    assert len(out) == 400
+    assert abs(out.paths_total()[0] - 2 * f) <= 1e-10 * f        # ray 0 of the Vogel cone is the chief ray
+    assert np.abs(out.points()[0] - np.asarray(ch.optical_elements[0].position, float)).max() <= 1e-9 * f
+    D = mdet.Detector(np.asarray(ch.optical_elements[-1].position, float))
+    D.autoplace(out, 2 * f)
+    opl = np.asarray(D.get_OpticalPaths(out))
+    assert abs(opl[0] - 4 * f) <= 1e-4 * f                       # the detector is placed on the MEAN ray, not the chief ray
+    spot = mp.StandardDeviation(D.get_PointList2DCentre(out))
+    footprint = np.std(out.points(), axis=0).max()
+    assert spot < 1e-2 * footprint
