@@ -15,6 +15,9 @@ TWIN = os.path.join(ROOT, "oracle", "_twin", "libart_twin.so")
 
 
 def build_twin():
+    # ART_TWIN_LIB: use another build of the twin, e.g. one made with -fsanitize=address,undefined (CPU only)
+    if os.environ.get("ART_TWIN_LIB"):
+        return os.environ["ART_TWIN_LIB"]
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL,
                           stderr=subprocess.DEVNULL)
     return TWIN
@@ -24,8 +27,7 @@ class TwinBackend:
     name = "twin"
 
     def __init__(self):
-        build_twin()
-        self.lib = C.CDLL(TWIN)
+        self.lib = C.CDLL(build_twin())
         self.device = torch.device("cpu")
         self.lib.art_cpu_trace_element.restype = C.c_int
         self.lib.art_cpu_trace_element.argtypes = [C.POINTER(_abi.ArtElementDesc), C.POINTER(_abi.ArtBundleView),
