@@ -198,44 +198,97 @@ ART_HD int quadratic_roots(double a, double b, double c, double& t1, double& t2)
 
 // ---------------------------------------------------------------------------------------------------------
 // Zernike defects (ART/ModuleDefects.py:149-174; polynomials of ART/recursive_zernike_generator.py:35-254).
-// The host expands the summed surface into monomials (exact: the recurrences have integer coefficients) and stores
-// the polynomial and its two partial derivatives (table layout: art_hip.h).  Per ray this is a bivariate Horner
-// scheme whose coefficients every lane reads from the same LDS address (broadcast, conflict-free): no per-lane
-// arrays, ~20 live registers, cost (N+1)(N+2)/2 fused multiply-adds per polynomial.
-ART_HD double poly2_horner(const double* A, int N, double x, double y) {
-  double acc = 0.0;
-  for (int p = N; p >= 0; --p) {
-    const double* row = A + p * ART_ZERN_DIM;
-    double in = row[N - p];
-    for (int q = N - p - 1; q >= 0; --q) in = fma(in, y, row[q]);
-    acc = fma(acc, x, in);
+// The host expands the summed surface into monomials (exact: the recurrences have integer coefficients) and hands
+// over the polynomial and its two partial derivatives as dense [p][q] tables (layout: art_hip.h).  Per ray this is a
+// bivariate Horner scheme whose coefficients every lane reads from the same LDS address (broadcast, conflict-free).
+// A Horner chain is one dependent LDS read + FMA per coefficient, i.e. latency-bound; so the kernels re-pack the
+// tables, once per workgroup while staging them in LDS, into the order the scheme consumes them -- row m (p = deg - m)
+// as A[p][m], .., A[p][0] -- with every row padded IN FRONT with zeros to a multiple of 4 (a leading zero leaves a
+// Horner chain unchanged): the inner loop then fetches 4 coefficients with two 16-byte reads and runs 4 FMAs per
+// LDS round trip, without any per-coefficient control flow.
+//
+// Packed table of one defect (ART_ZPACK_STRIDE doubles, 16-byte aligned parts): [0] R, [1] N, then h (ART_ZPACK_T0
+// slots), dh/dx and dh/dy (ART_ZPACK_T1 slots each).
+ART_HD constexpr int zpack_rows_size(int deg) {      // sum over rows m = 0..deg of (m + 1) rounded up to 4
+  int t = 0;
+  for (int m = 0; m <= deg; ++m) t += ((m + 1 + 3) / 4) * 4;
+  return t;
+}
+#define ART_ZPACK_T0 (art::zpack_rows_size(ART_ZERN_MAX_ORDER))          /* 180 */
+#define ART_ZPACK_T1 (art::zpack_rows_size(ART_ZERN_MAX_ORDER - 1))      /* 160 */
+#define ART_ZPACK_STRIDE (2 + ART_ZPACK_T0 + 2 * ART_ZPACK_T1)           /* 502, even */
+
+// dense entry j (0 .. 3*DIM^2-1) of a defect table -> slot in the packed table, or -1 if its degree exceeds N
+ART_HD int zern_pack_slot(int N, int j) {
+  const int poly = j / (ART_ZERN_DIM * ART_ZERN_DIM), rem = j - poly * ART_ZERN_DIM * ART_ZERN_DIM;
+  const int p = rem / ART_ZERN_DIM, q = rem - p * ART_ZERN_DIM;
+  const int deg = (poly == 0) ? N : N - 1;
+  if (p + q > deg) return -1;
+  const int m = deg - p;
+  int off = 0;
+  for (int r = 0; r < m; ++r) off += ((r + 1 + 3) / 4) * 4;
+  const int lead = ((m + 1 + 3) / 4) * 4 - (m + 1);              // zeros in front of row m
+  const int base = 2 + (poly == 0 ? 0 : ART_ZPACK_T0 + (poly - 1) * ART_ZPACK_T1);
+  return base + off + lead + (m - q);
+}
+
+// stage one defect: dense table `src` (ART_ZERN_STRIDE doubles) -> packed table `dst` (ART_ZPACK_STRIDE doubles,
+// zero-filled first); called by every thread of the workgroup with its index (host twin: tid = 0, nthreads = 1).
+// The caller synchronises the workgroup between zern_pack_clear and zern_pack.
+ART_HD void zern_pack_clear(double* dst, int tid, int nthreads) {
+  for (int j = tid; j < ART_ZPACK_STRIDE; j += nthreads) dst[j] = 0.0;
+}
+ART_HD void zern_pack(const double* src, double* dst, int tid, int nthreads) {
+  const int N = (int)src[1];
+  if (tid == 0) { dst[0] = src[0]; dst[1] = src[1]; }
+  for (int j = tid; j < 3 * ART_ZERN_DIM * ART_ZERN_DIM; j += nthreads) {
+    const int slot = zern_pack_slot(N, j);
+    if (slot >= 0) dst[slot] = src[2 + j];
   }
-  return acc;
+}
+
+struct Coef4 { double a, b, c, d; };
+ART_HD Coef4 ld_coef4(const double* P) {      // P is 16-byte aligned: two 128-bit LDS reads on the device
+  Coef4 v;
+  v.a = P[0]; v.b = P[1]; v.c = P[2]; v.d = P[3];
+  return v;
 }
 
 // h = get_offset (:168-174)
 ART_HD double zernike_offset(const double* tab, double px, double py) {
   const double iR = rcp_full(tab[0]);
-  return poly2_horner(tab + 2, (int)tab[1], px * iR, py * iR);
+  const int N = (int)tab[1];
+  const double x = px * iR, y = py * iR;
+  const double* P = tab + 2;
+  double acc = 0.0;
+  for (int m = 0; m <= N; ++m) {
+    double in = 0.0;
+    for (int g = 0; g < m + 1; g += 4) {
+      const Coef4 c = ld_coef4(P);
+      P += 4;
+      in = fma(fma(fma(fma(in, y, c.a), y, c.b), y, c.c), y, c.d);
+    }
+    acc = fma(acc, x, in);
+  }
+  return acc;
 }
 
 // (gX, gY): get_normal (:159-166) returns (-gX, -gY, 1)
 ART_HD void zernike_slopes(const double* tab, double px, double py, double& gX, double& gY) {
   const double iR = rcp_full(tab[0]);
-  const int N = (int)tab[1];
+  const int M = (int)tab[1] - 1;
   const double x = px * iR, y = py * iR;
   // both derivative polynomials in one pass (two independent Horner chains), degree N-1
-  const double* GX = tab + 2 + ART_ZERN_DIM * ART_ZERN_DIM;
-  const double* GY = GX + ART_ZERN_DIM * ART_ZERN_DIM;
+  const double* PX = tab + 2 + ART_ZPACK_T0;
+  const double* PY = PX + ART_ZPACK_T1;
   double ax = 0.0, ay = 0.0;
-  const int M = N - 1;
-  for (int p = M; p >= 0; --p) {
-    const double* rx = GX + p * ART_ZERN_DIM;
-    const double* ry = GY + p * ART_ZERN_DIM;
-    double ix = rx[M - p], iy = ry[M - p];
-    for (int q = M - p - 1; q >= 0; --q) {
-      ix = fma(ix, y, rx[q]);
-      iy = fma(iy, y, ry[q]);
+  for (int m = 0; m <= M; ++m) {
+    double ix = 0.0, iy = 0.0;
+    for (int g = 0; g < m + 1; g += 4) {
+      const Coef4 cx = ld_coef4(PX), cy = ld_coef4(PY);
+      PX += 4; PY += 4;
+      ix = fma(fma(fma(fma(ix, y, cx.a), y, cx.b), y, cx.c), y, cx.d);
+      iy = fma(fma(fma(fma(iy, y, cy.a), y, cy.b), y, cy.c), y, cy.d);
     }
     ax = fma(ax, x, ix);
     ay = fma(ay, x, iy);
@@ -524,7 +577,7 @@ ART_HD bool trace_ray(const ArtElementDesc& e, const double* zern, Ray& r) {
       // h / cos(alpha), h = summed defect offsets at (P - centre), alpha = angle(-u, base normal)
       double h = 0.0;
       for (int d = 0; d < e.n_defects; ++d)
-        h += zernike_offset(zern + d * ART_ZERN_STRIDE, Px - e.centre[0], Py - e.centre[1]);
+        h += zernike_offset(zern + d * ART_ZPACK_STRIDE, Px - e.centre[0], Py - e.centre[1]);
       for (int d = 0; d < e.n_grid; ++d) h += grid_offset(e.grid[d], Px - e.centre[0], Py - e.centre[1]);
       const double cosa = -dot3(ux, uy, uz, nx, ny, nz);
       const double s = div_full(h, cosa);
@@ -538,7 +591,7 @@ ART_HD bool trace_ray(const ArtElementDesc& e, const double* zern, Ray& r) {
         double gXs = -nx * inz, gYs = -ny * inz;
         for (int d = 0; d < e.n_defects; ++d) {
           double gX, gY;
-          zernike_slopes(zern + d * ART_ZERN_STRIDE, Px - e.centre[0], Py - e.centre[1], gX, gY);
+          zernike_slopes(zern + d * ART_ZPACK_STRIDE, Px - e.centre[0], Py - e.centre[1], gX, gY);
           gXs += gX; gYs += gY;
         }
         const double inv = rsqrt_full(fma(gXs, gXs, fma(gYs, gYs, 1.0)));

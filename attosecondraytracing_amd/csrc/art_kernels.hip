@@ -139,11 +139,13 @@ __device__ __forceinline__ void store_ray(const ArtBundleView& v, int64_t i, con
 template <int KIND, bool DEFECT>
 __global__ __launch_bounds__(kBlock) void k_trace_element(const ArtElementDesc e, const ArtBundleView in,
                                                           const ArtBundleView out, const int64_t n) {
-  __shared__ double s_zern[DEFECT ? ART_MAX_DEFECTS * ART_ZERN_STRIDE : 1];
+  __shared__ __attribute__((aligned(16))) double s_zern[DEFECT ? ART_MAX_DEFECTS * ART_ZPACK_STRIDE : 2];
   const double* zern = nullptr;
-  if (DEFECT) {
-    const int cnt = e.n_defects * ART_ZERN_STRIDE;
-    for (int j = threadIdx.x; j < cnt; j += kBlock) s_zern[j] = e.zern[j];
+  if (DEFECT) {   // dense caller tables -> packed, row-padded Horner-order tables in LDS (art_device.h)
+    for (int d = 0; d < e.n_defects; ++d) art::zern_pack_clear(s_zern + d * ART_ZPACK_STRIDE, threadIdx.x, kBlock);
+    __syncthreads();
+    for (int d = 0; d < e.n_defects; ++d)
+      art::zern_pack(e.zern + d * ART_ZERN_STRIDE, s_zern + d * ART_ZPACK_STRIDE, threadIdx.x, kBlock);
     __syncthreads();
     zern = s_zern;
   }
@@ -188,12 +190,13 @@ struct ChainArgs {
 // whole chain, ray resident in registers; history written for every element whose view is non-null
 template <bool DEFECT, int WAVES>
 __global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain(const ChainArgs a, const ArtBundleView in, const int64_t n) {
-  extern __shared__ double s_zern[];  // Zernike tables of all elements, staged once per workgroup
+  extern __shared__ __attribute__((aligned(16))) double s_zern[];  // packed Zernike tables of all elements, staged once per workgroup
   if (DEFECT) {
-    for (int k = 0; k < a.n_elems; ++k) {
-      const int cnt = a.e[k].n_defects * ART_ZERN_STRIDE;
-      for (int j = threadIdx.x; j < cnt; j += kBlock) s_zern[a.zoff[k] + j] = a.e[k].zern[j];
-    }
+    for (int j = threadIdx.x; j < a.zern_doubles; j += kBlock) s_zern[j] = 0.0;
+    __syncthreads();
+    for (int k = 0; k < a.n_elems; ++k)
+      for (int d = 0; d < a.e[k].n_defects; ++d)
+        art::zern_pack(a.e[k].zern + d * ART_ZERN_STRIDE, s_zern + a.zoff[k] + d * ART_ZPACK_STRIDE, threadIdx.x, kBlock);
     __syncthreads();
   }
   const BundleRsrc bi = make_rsrc(in, n);
@@ -818,7 +821,7 @@ int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundl
         art::prepare_element(a.e[k]);
         a.out[k] = view_at(outs[k0 + k], off);
         a.zoff[k] = a.zern_doubles;
-        a.zern_doubles += a.e[k].n_defects * ART_ZERN_STRIDE;
+        a.zern_doubles += a.e[k].n_defects * ART_ZPACK_STRIDE;
         if (a.e[k].n_defects > 0 || a.e[k].n_grid > 0) any_defect = true;
       }
       if ((size_t)a.zern_doubles * sizeof(double) > 64 * 1024)

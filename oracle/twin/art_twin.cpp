@@ -24,11 +24,24 @@ inline void store_ray(const ArtBundleView& v, int64_t i, const art::Ray& r) {
 }
 }  // namespace
 
+// the kernels stage the caller's dense Zernike tables in LDS in packed, row-padded Horner order (art_device.h
+// zern_pack); the twin packs them into a host buffer the same way
+static std::vector<double> pack_tables(const ArtElementDesc& e) {
+  std::vector<double> out;
+  if (e.n_defects > 0 && e.zern) {
+    out.assign((size_t)e.n_defects * ART_ZPACK_STRIDE, 0.0);
+    for (int d = 0; d < e.n_defects; ++d) art::zern_pack(e.zern + d * ART_ZERN_STRIDE, out.data() + d * ART_ZPACK_STRIDE, 0, 1);
+  }
+  return out;
+}
+
 extern "C" {
 
 int art_cpu_trace_element(const ArtElementDesc* e_in, const ArtBundleView* in, const ArtBundleView* out, int64_t n) {
   ArtElementDesc ec = *e_in;
   art::prepare_element(ec);
+  const std::vector<double> packed = pack_tables(ec);
+  ec.zern = packed.empty() ? nullptr : packed.data();
   const ArtElementDesc* e = &ec;
   for (int64_t i = 0; i < n; ++i) {
     bool ok = in->alive[i] != 0;
@@ -46,7 +59,12 @@ int art_cpu_trace_element(const ArtElementDesc* e_in, const ArtBundleView* in, c
 int art_cpu_trace_chain(const ArtElementDesc* elems_in, int32_t n_elems, const ArtBundleView* in,
                         const ArtBundleView* outs, int64_t n) {
   std::vector<ArtElementDesc> elems(elems_in, elems_in + n_elems);
-  for (auto& e : elems) art::prepare_element(e);
+  std::vector<std::vector<double>> packed(n_elems);
+  for (int k = 0; k < n_elems; ++k) {
+    art::prepare_element(elems[k]);
+    packed[k] = pack_tables(elems[k]);
+    elems[k].zern = packed[k].empty() ? nullptr : packed[k].data();
+  }
   // rays are independent: all host cores (used by bench.py's all-cores CPU figure; the tests do not care)
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; ++i) {
