@@ -136,9 +136,18 @@ __device__ __forceinline__ void store_ray(const ArtBundleView& v, int64_t i, con
 }
 
 // ------------------------------------------------------------------------------------------- trace kernels
+// The descriptor travels in a one-element array and is indexed with blockIdx.y (always 0): a dynamic index makes the
+// compiler fetch descriptor fields with scalar loads where they are used instead of keeping all ~60 of them (plus
+// 72 SGPRs of buffer descriptors) live across the ray loop, which overflowed the SGPR file into VGPR lanes (200
+// v_readlane/v_writelane in the torus kernel).  The fused chain kernel indexes its descriptors by element anyway.
+struct ElemArg {
+  ArtElementDesc e[1];
+};
+
 template <int KIND, bool DEFECT>
-__global__ __launch_bounds__(kBlock) void k_trace_element(const ArtElementDesc e, const ArtBundleView in,
+__global__ __launch_bounds__(kBlock) void k_trace_element(const ElemArg ea, const ArtBundleView in,
                                                           const ArtBundleView out, const int64_t n) {
+  const ArtElementDesc& e = ea.e[blockIdx.y];
   __shared__ __attribute__((aligned(16))) double s_zern[DEFECT ? ART_MAX_DEFECTS * ART_ZPACK_STRIDE : 2];
   const double* zern = nullptr;
   if (DEFECT) {   // dense caller tables -> packed, row-padded Horner-order tables in LDS (art_device.h)
@@ -726,10 +735,12 @@ template <int KIND>
 void launch_element(const ArtElementDesc& e, const ArtBundleView& in, const ArtBundleView& out, int64_t n,
                     hipStream_t s) {
   const int grid = grid_for(n);
+  ElemArg ea;
+  ea.e[0] = e;
   if (e.n_defects > 0 || e.n_grid > 0)
-    hipLaunchKernelGGL((k_trace_element<KIND, true>), dim3(grid), dim3(kBlock), 0, s, e, in, out, n);
+    hipLaunchKernelGGL((k_trace_element<KIND, true>), dim3(grid), dim3(kBlock), 0, s, ea, in, out, n);
   else
-    hipLaunchKernelGGL((k_trace_element<KIND, false>), dim3(grid), dim3(kBlock), 0, s, e, in, out, n);
+    hipLaunchKernelGGL((k_trace_element<KIND, false>), dim3(grid), dim3(kBlock), 0, s, ea, in, out, n);
 }
 
 }  // namespace
