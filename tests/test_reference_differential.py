@@ -777,3 +777,81 @@ def test_values_and_exception_types_of_the_host_api_match_reference(twin, capsys
         if not same:
             bad.append((c, a, b))
     assert not bad, "\\n".join(f"{c}\\n    product:   {a}\\n    reference: {b}" for c, a, b in bad)
+
+
+GEO_GEN = textwrap.dedent('''
+    def geometry_session(seed, mgeo, mray):
+        """Every helper of ModuleGeometry on seeded random inputs (incl. the RotationPoint special cases); a flat list
+        of numbers."""
+        rng = np.random.default_rng(seed + 31337)
+        v = lambda: rng.normal(size=3)
+        out = []
+        def put(x):
+            out.extend(np.asarray(x, dtype=float).ravel().tolist())
+        a, b, c, p = v(), v(), v(), v() * 50
+        put(mgeo.Normalize(a)); put(mgeo.VectorPerpendicular(a)); put([mgeo.AngleBetweenTwoVectors(a, b)])
+        n = mgeo.Normalize(c)
+        if abs(np.dot(a, n)) > 0.05:
+            put(mgeo.IntersectionLinePlane(p, a, b * 10, n))
+        put(mgeo.SpiralVogel(int(rng.integers(1, 40)), float(rng.uniform(0.1, 9))))
+        put(sorted(mgeo.SolverQuadratic(1.0, float(rng.uniform(-9, 9)), float(rng.uniform(-9, 2)))))
+        r = np.sort(rng.uniform(-5, 5, 4))
+        co = np.poly(r)
+        put(sorted(np.round(mgeo.SolverQuartic(*co), 7)))
+        vals = list(rng.uniform(-1, 1, 6))
+        put(mgeo.KeepPositiveSolution(vals)); put(mgeo.KeepNegativeSolution(vals))
+        put(mgeo.ClosestPoint(p, p + a, p + 2 * b)); put(mgeo.FarestPoint(p, p + a, p + 2 * b))
+        pts2 = [rng.uniform(-5, 5, 2) for _ in range(7)]
+        put([mgeo.DiameterPointList(pts2)]); put(mgeo.CentrePointList(pts2))
+        pts3 = [v() for _ in range(5)]
+        put([mgeo.DiameterPointList(pts3)])
+        put([float(mgeo.IncludeRectangle(4.0, 3.0, v() * 2)), float(mgeo.IncludeDisk(2.0, v() * 2))])
+        put(mgeo.SymmetricalVector(a, b))
+        put(mgeo.TranslationPoint(p, a)); put(mgeo.TranslationPointList(pts3, a))
+        ang = float(rng.uniform(-3.5, 3.5))
+        put(mgeo.RotationAroundAxis(a, ang, b)); put(mgeo.RotationAroundAxis(a, 0.0, b)); put(mgeo.RotationAroundAxis(a, np.pi, b))
+        for ax1, ax2 in ((a, b), (a, a * 2.5), (a, -a), (np.array([0.0, 0, 1]), np.array([0.0, 0, -1]))):
+            put(mgeo.RotationPoint(p, ax1, ax2))
+        put(mgeo.RotationPointList(pts3, a, b))
+        ray = mray.Ray(p.copy(), mgeo.Normalize(c), (0.0, 1.5), 3, 50e-6, 0.2, 0.7)
+        for q in (mgeo.TranslationRay(ray, a), mgeo.RotationRay(ray, a, b), mgeo.RotationRay(ray, a, -a)):
+            put(q.point); put(q.vector); put(q.path); put([q.number, q.incidence, q.intensity])
+        rl = [mray.Ray(v() * 10, mgeo.Normalize(v()), (0.0,), k) for k in range(4)]
+        for lst in (mgeo.TranslationRayList(rl, a), mgeo.RotationRayList(rl, a, b), mgeo.RotationAroundAxisRayList(rl, a, ang)):
+            for q in lst:
+                put(q.point); put(q.vector)
+        put(mgeo.normal_add(np.array([0.1, -0.2, 1.0]), np.array([-0.05, 0.3, 0.9])))
+        return out
+''')
+
+GEO_SCRIPT = textwrap.dedent('''
+    import sys, json
+    sys.dont_write_bytecode = True
+    ROOT, REF, lo, hi = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    sys.path[:0] = [REF, ROOT + "/tests/golden/_standin"]
+    import numpy as np
+    import ART.ModuleGeometry as mgeo, ART.ModuleOpticalRay as mray
+    exec(sys.stdin.read())
+    print("RESULT" + json.dumps({s: geometry_session(s, mgeo, mray) for s in range(lo, hi)}))
+''')
+
+
+def test_geometry_helpers_match_reference(twin):
+    """All 27 functions of ModuleGeometry on random inputs (rotations incl. the identity / point-inversion special
+    cases, ray and ray-list transforms, solvers, point-list statistics)."""
+    lo, hi = 0, int(os.environ.get("ART_FUZZ_GEOMETRY", "60"))
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, "-c", GEO_SCRIPT, ROOT, REF, str(lo), str(hi)], input=GEO_GEN,
+                       capture_output=True, text=True, timeout=3000, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    ref = json.loads(r.stdout[r.stdout.index("RESULT") + 6:])
+    import ART.ModuleGeometry as mgeo
+    import ART.ModuleOpticalRay as mray
+    ns = {"np": np}
+    exec(GEO_GEN, ns)
+    for seed in range(lo, hi):
+        mine = np.array(ns["geometry_session"](seed, mgeo, mray))
+        want = np.array(ref[str(seed)])
+        assert mine.shape == want.shape, (seed, mine.shape, want.shape)
+        err = np.abs(mine - want) / np.maximum(1.0, np.abs(want))
+        assert err.max() <= 1e-9, (seed, int(err.argmax()), mine[err.argmax()], want[err.argmax()])
