@@ -707,6 +707,25 @@ ERR_CASES = [
     "round(mgeo.AngleBetweenTwoVectors(np.array([1.0, 0, 0]), np.array([-1.0, 1e-9, 0])), 12)",
     "mgeo.DiameterPointList([])",
     "round(mgeo.DiameterPointList([np.array([0.0, 0]), np.array([3.0, 4])]), 12)",
+    # seeded random operations: the same NumPy draws in the same order on both sides
+    "(np.random.seed(3), chain.shift_source('random', 1.5), [float(x) for x in chain.source_rays[5].point])[-1]",
+    "(np.random.seed(4), chain.tilt_source('random', 0.2), [float(x) for x in chain.source_rays[5].vector])[-1]",
+    "(np.random.seed(5), oe.rotate_random_by(2.0), [float(x) for x in oe.normal] + [float(x) for x in oe.majoraxis])[-1]",
+    "(np.random.seed(6), oe.shift_along_random(0.7), [float(x) for x in oe.position])[-1]",
+    "(np.random.seed(7), chain.rotate_OE(1, 'random', 0.3), [float(x) for x in chain.optical_elements[1].normal])[-1]",
+    "(np.random.seed(8), chain.shift_OE(0, 'random', 0.3), [float(x) for x in chain.optical_elements[0].position])[-1]",
+    "(np.random.seed(9), [[float(x) for x in c.optical_elements[1].normal] + [float(x) for x in c.optical_elements[0].position] "
+    "for c in chain.get_OE_random_loop_list(0.1, 0.05, 3)])[-1][2]",
+    "(np.random.seed(9), [c.loop_variable_name for c in chain.get_OE_random_loop_list(0.1, 0.05, 2)])[-1]",
+    "(np.random.seed(10), [[float(x) for x in c.source_rays[3].vector] for c in chain.get_source_loop_list('tilt_random', [0.1, 0.2])])[-1][1]",
+    "(np.random.seed(11), [[float(x) for x in c.source_rays[3].point] for c in chain.get_source_loop_list('shift_random', [0.1, 0.2])])[-1][0]",
+    "[round(float(x), 12) for x in chain.get_source_loop_list('divergence', [0.005, 0.02])[1].source_rays[7].vector]",
+    "[round(float(c.source_rays[7].intensity), 12) for c in chain.get_source_loop_list('divergence', [0.005, 0.02])]",
+    "oe.rotate_pitch_by('1')",
+    "oe.shift_along_normal([1])",
+    "(oe.rotate_pitch_by(1.0), oe.rotate_roll_by(-2.0), oe.rotate_yaw_by(3.0), oe.shift_along_major(0.5), oe.shift_along_cross(-0.5), "
+    "[float(x) for x in oe.position] + [float(x) for x in oe.normal] + [float(x) for x in oe.majoraxis])[-1]",
+    "hash(oe) == hash(moe.OpticalElement(plane, np.array([0.0, 0.0, 10.0]), np.array([0.0, 0.6, -0.8]), np.array([1.0, 0.0, 0.0])))",
 ]
 
 ERR_PRELUDE = textwrap.dedent('''
