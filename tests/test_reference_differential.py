@@ -874,3 +874,118 @@ def test_geometry_helpers_match_reference(twin):
         assert mine.shape == want.shape, (seed, mine.shape, want.shape)
         err = np.abs(mine - want) / np.maximum(1.0, np.abs(want))
         assert err.max() <= 1e-9, (seed, int(err.argmax()), mine[err.argmax()], want[err.argmax()])
+
+
+MAIN_GEN = textwrap.dedent('''
+    def main_options(seed, ch):
+        """Random DetectorOptions / AnalysisOptions for ARTmain.main (auto or manual detector, autofocus on or off)."""
+        rng = np.random.default_rng(seed + 2024)
+        det = {"ReflectionNumber": -1, "AutoDetectorDistance": bool(rng.uniform() < 0.5),
+               "OptFor": ["intensity", "duration"][int(rng.integers(0, 2))]}
+        if rng.uniform() < 0.3:
+            last = ch.optical_elements[-1]
+            det.update(ManualDetector=True, DetectorCentre=np.asarray(last.position, dtype=float) + np.array([30.0, -20.0, 10.0]),
+                       DetectorNormal=np.array([-0.3, 0.2, -0.9]))
+        else:
+            det.update(ManualDetector=False, DistanceDetector=float(rng.uniform(40, 500)))
+        if rng.uniform() < 0.1:
+            det.pop("DistanceDetector", None)
+            det["ManualDetector"] = False
+            det["DistanceDetector"] = None           # -> RuntimeError in setup_detector
+        ana = {"verbose": False, "save_results": False}
+        return det, ana
+''')
+
+MAIN_SCRIPT = textwrap.dedent('''
+    import sys, json, copy
+    sys.dont_write_bytecode = True
+    ROOT, REF, lo, hi = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    sys.path[:0] = [REF, ROOT + "/tests/golden/_standin"]
+    import matplotlib; matplotlib.use("Agg")
+    import numpy as np
+    import ART.ModuleProcessing as mp, ART.ModuleMirror as mmirror, ART.ModuleMask as mmask, ART.ModuleSupport as msupp
+    import ART.DefaultOptions as DO
+    import ARTmain
+    assert ARTmain.__file__.startswith(REF)
+    exec(sys.stdin.read())
+    defaults = {k: dict(getattr(DO, k)) for k in ("DefaultSourceProperties", "DefaultDetectorOptions", "DefaultAnalysisOptions")}
+    out = {}
+    for seed in range(lo, hi):
+        for k, v in defaults.items():            # complete_defaults mutates the module-level dicts
+            getattr(DO, k).clear(); getattr(DO, k).update(v)
+        SP, optics, dist, inc, plane = make_case(seed, mmirror, mmask, msupp)
+        SP["NumberRays"] = 120
+        try:
+            ch = mp.OEPlacement(SP, optics, dist, inc, plane, "fuzz")
+        except Exception as e:
+            out[seed] = {"skip": type(e).__name__}
+            continue
+        det, ana = main_options(seed, ch)
+        try:
+            kept = ARTmain.main(ch, SP, det, ana)
+            D = kept["Detector"][0]
+            out[seed] = {"et": float(kept["ETransmission"][0]), "spot": float(kept["SpotSizeSD"][0]), "dur": float(kept["DurationSD"][0]),
+                         "distance": float(D.get_distance()), "auto": det["AutoDetectorDistance"], "optfor": det["OptFor"],
+                         "n": len(kept["OpticalChain"][0].get_output_rays()[-1])}
+        except Exception as e:
+            out[seed] = {"error": type(e).__name__}
+    print("RESULT" + json.dumps(out))
+''')
+
+
+def test_artmain_main_matches_reference(twin):
+    """`ARTmain.main` end to end (trace, transmission, detector set-up -- automatic, manual or invalid --, autofocus or
+    summary) on random chains with <= 1000 rays, where the reference's autofocus also uses every ray."""
+    lo, hi = 0, int(os.environ.get("ART_FUZZ_MAIN", "24"))
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, "-c", MAIN_SCRIPT, ROOT, REF, str(lo), str(hi)], input=GENERATOR + MAIN_GEN,
+                       capture_output=True, text=True, timeout=3000, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    ref = json.loads(r.stdout[r.stdout.index("RESULT") + 6:])
+    import ART.ModuleProcessing as mp
+    import ART.ModuleMirror as mmirror
+    import ART.ModuleMask as mmask
+    import ART.ModuleSupport as msupp
+    import ARTmain
+    from attosecondraytracing_amd import DefaultOptions as DO
+    defaults = {k: dict(getattr(DO, k)) for k in ("DefaultSourceProperties", "DefaultDetectorOptions", "DefaultAnalysisOptions")}
+    ns = {}
+    exec(GENERATOR + MAIN_GEN, ns)
+    compared = 0
+    try:
+        for seed in range(lo, hi):
+            e = ref[str(seed)]
+            if "skip" in e:
+                continue
+            for k, v in defaults.items():
+                getattr(DO, k).clear()
+                getattr(DO, k).update(v)
+            SP, optics, dist, inc, plane = ns["make_case"](seed, mmirror, mmask, msupp)
+            SP["NumberRays"] = 120
+            ch = mp.OEPlacement(SP, optics, dist, inc, plane, "fuzz")
+            det, ana = ns["main_options"](seed, ch)
+            if "error" in e:
+                with pytest.raises(Exception) as ei:
+                    ARTmain.main(ch, SP, det, ana)
+                assert type(ei.value).__name__ == e["error"], (seed, ei.value, e)
+                continue
+            kept = ARTmain.main(ch, SP, det, ana)
+            assert len(kept["OpticalChain"][0].get_output_rays()[-1]) == e["n"], seed
+            assert abs(kept["ETransmission"][0] - e["et"]) <= 1e-9, (seed, kept["ETransmission"][0], e)
+            D = kept["Detector"][0]
+            if e["auto"] and e["n"] < 30:
+                compared += 1          # a handful of rays: the fitness is flat (ties decide), nothing to compare
+                continue
+            if not e["auto"]:
+                assert abs(D.get_distance() - e["distance"]) <= 1e-9 * max(1.0, e["distance"]), seed
+                assert abs(kept["SpotSizeSD"][0] - e["spot"]) <= 1e-9 * max(1.0, e["spot"]), (seed, kept["SpotSizeSD"][0], e)
+                assert abs(kept["DurationSD"][0] - e["dur"]) <= 1e-7 * max(1.0, e["dur"]), (seed, kept["DurationSD"][0], e)
+            else:
+                # autofocus: same caveat as in the FindOptimalDistance test (19 or 20 scan positions per level)
+                assert abs(D.get_distance() - e["distance"]) <= 0.13 * max(1.0, abs(e["distance"])) + 1.0, (seed, D.get_distance(), e)
+            compared += 1
+    finally:
+        for k, v in defaults.items():
+            getattr(DO, k).clear()
+            getattr(DO, k).update(v)
+    assert compared >= (hi - lo) // 3
