@@ -254,6 +254,25 @@ def test_gpu_exchange_kernels(hip):
         be.exchange_fold(recv, 0, stride, out)
 
 
+def test_gpu_plain_c_consumer_of_the_abi(hip, tmp_path):
+    """examples/c_abi_demo.c: gcc (C, not C++), the HIP runtime for memory, include/art_hip.h for everything else --
+    no Python and no PyTorch between the caller and libart_hip.so."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rocm = "/opt/rocm"
+    if not (shutil.which("gcc") and os.path.isdir(rocm + "/include/hip")):
+        pytest.skip("gcc or the HIP headers are not available")
+    exe = str(tmp_path / "c_abi_demo")
+    lib = os.path.join(root, "attosecondraytracing_amd", "libart_hip.so")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I" + rocm + "/include",
+                           "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "c_abi_demo.c"),
+                           "-L" + rocm + "/lib", "-lamdhip64", lib, "-lm", "-Wl,-rpath," + rocm + "/lib", "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "C_ABI_DEMO_OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_gpu_error_paths(hip):
     """Bad arguments come back as error codes with a message, never as a crash."""
     import ctypes as C
