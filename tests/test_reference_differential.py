@@ -222,6 +222,9 @@ def test_autofocus_and_summary_random_chains_match_reference(twin):
         # the last bit of the detector distance, so the two implementations may scan 19 or 20 positions: when the
         # fitness has no minimum inside the range ("There`s no minimum ... in the searched range") they stop one
         # coarse step apart.  Inside the range they agree to the final grid (A * 1e-3).
+        if not np.isnan(e["dur"]) and e["dur"] < 1e-6:
+            compared += 1      # all optical paths equal (e.g. a plane wave on plane mirrors): the duration is rounding
+            continue           # noise (1e-10 fs) and so is the position of its "minimum"
         at_edge = min(abs(e["distance"] - (e["d0"] - A)), abs(e["distance"] - (e["d0"] + A))) <= 0.25 * A
         tol_d = 0.125 * A if at_edge else 3e-3 * A + 1e-9
         assert abs(Dopt.get_distance() - e["distance"]) <= tol_d, (seed, Dopt.get_distance(), A, e)
