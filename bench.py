@@ -78,10 +78,32 @@ def cpu_baseline(chain, Rr, n_sample):
     t0 = time.perf_counter()
     out = orc.ray_tracing_calculation(B, els)
     D = orc.detector_autoplace(out[-1], 600.0)
-    orc.detector_delays(D, out[-1])
+    delays = orc.detector_delays(D, out[-1])
     dt = time.perf_counter() - t0
     inter = n_sample + sum(len(o) for o in out[:-1])
-    return inter / dt, inter, dt
+    return inter / dt, inter, dt, {"last": out[-1], "detector": D, "delays": delays}
+
+
+def parity_against(oracle_result, chain, n_sample, be, mode):
+    """The second half of BASELINE.json's metric ("fp64 delay max-rel-err"): the same n_sample-ray workload traced on
+    the GPU and compared with what the oracle just computed for the CPU baseline."""
+    import ART.ModuleProcessing as mp
+    import ART.ModuleDetector as mdet
+    from oracle import art_oracle as orc
+    ref, Do = oracle_result["last"], oracle_result["detector"]
+    src = device_source(n_sample, 0, n_sample, be)
+    last = mp.RayTracingCalculation(src, chain.optical_elements, mode=mode)[-1]
+    same = bool(np.array_equal(last.numbers(), ref.number))
+    det = mdet.Detector(np.asarray(Do.refpoint, float), np.asarray(Do.centre, float), np.asarray(Do.normal, float))
+    res = {"rays": n_sample, "survivor_indices_equal": same}
+    if same and len(ref) > 0:
+        mean_path = float(np.mean(orc.optical_paths(Do, ref)))
+        d = np.asarray(det.get_Delays(last))
+        res["delay_max_rel_err"] = float(np.abs(d - oracle_result["delays"]).max() / (mean_path / orc.LightSpeed * 1e15))
+        res["position_max_rel_err"] = float(np.abs(last.points() - ref.point).max() / max(1.0, np.abs(ref.point).max()))
+        res["path_max_rel_err"] = float(np.abs(last.paths_total() - ref.path.sum(axis=1)).max() / mean_path)
+        res["note"] = "GPU vs oracle on the cpu_baseline sample; delays and paths relative to the mean optical path"
+    return res
 
 
 def cpu_twin_allcores(chain, n_sample):
@@ -343,7 +365,8 @@ def main():
                f"collective" if sample_each_step else ""),
         }
         if world == 1 and args.cpu_sample > 0:
-            v, inter, secs = cpu_baseline(chain, Rr, args.cpu_sample)
+            v, inter, secs, oracle_result = cpu_baseline(chain, Rr, args.cpu_sample)
+            res["parity"] = parity_against(oracle_result, chain, args.cpu_sample, be, mode)
             res["cpu_baseline"] = {"value": v, "unit": "intersections/s", "cores": 1, "kind": "port",
                                    "sample": f"oracle/art_oracle.py (NumPy, batched LAPACK eigvals; single thread) on "
                                              f"{args.cpu_sample} rays x {args.mirrors} mirrors + detector = {inter} "
