@@ -4,7 +4,6 @@
 device reductions.  SpotDiagram, DelayGraph and MirrorProjection are matplotlib adaptors fed from the device
 (_plots.py: statistics over all rays, markers for a down-sampled subset).  RayRenderGraph (PyVista 3-D scene) is not
 built: the entry point exists so that ARTmain and CONFIG scripts run, and says so."""
-import numpy as np
 
 from . import ModuleGeometry as mgeo
 from . import ModuleProcessing as mp

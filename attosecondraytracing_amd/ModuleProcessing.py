@@ -73,7 +73,6 @@ def _build_descriptor(oe, IgnoreDefects, backend):
     d.zern = None
     d.grid = None
     if hasattr(optic, "DeformationList") and len(optic.DeformationList) > 0:
-        import ctypes as C
         be = backend or _lib.get_backend()
         keep = []
         zern, grids = optic._zernike_defects(), optic._grid_defects()

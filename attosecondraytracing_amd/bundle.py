@@ -6,7 +6,6 @@ row is a unit-stride stream for the kernels) plus `alive[n]` (uint8).  n is the 
 stays fixed along a chain: slot i of every bundle is source ray i, so `number`, `intensity` and
 `wavelength` are shared, not copied.  The list-of-survivors view the reference API exposes
 (`len()`, indexing, iteration in source order) is produced lazily by a stable device compaction."""
-import ctypes as C
 
 import numpy as np
 import torch
