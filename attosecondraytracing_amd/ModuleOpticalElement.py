@@ -5,86 +5,101 @@ import numpy as np
 
 from . import ModuleGeometry as mgeo
 
+_EPS_ORTHO = 1e-12
+
+
+def _is_vec3(v, nonzero=False):
+    return isinstance(v, np.ndarray) and len(v) == 3 and (not nonzero or np.linalg.norm(v) > 0)
+
 
 class OpticalElement:
+    """Pose = position of the optic's centre point, unit normal, unit major axis (perpendicular to the normal).
+    Assigning a new normal carries the major axis along so that the two stay perpendicular; assigning a major axis
+    that is not perpendicular to the normal is an error (ART/ModuleOpticalElement.py:107-160)."""
+
     def __init__(self, Type, Position, Normal, MajorAxis):
         self._type = Type
         self.position = Position
         self.normal = mgeo.Normalize(Normal)
         self.majoraxis = mgeo.Normalize(MajorAxis)
 
-    @property
-    def position(self):
+    type = property(lambda self: self._type)
+
+    def _get_position(self):
         return self._position
 
-    @position.setter
-    def position(self, NewPosition):
-        if not (isinstance(NewPosition, np.ndarray) and len(NewPosition) == 3):
+    def _set_position(self, value):
+        if not _is_vec3(value):
             raise TypeError("Position must be a 3D numpy.ndarray.")
-        self._position = NewPosition
+        self._position = value
 
-    @property
-    def normal(self):
+    position = property(_get_position, _set_position)
+
+    def _get_normal(self):
         return self._normal
 
-    @normal.setter
-    def normal(self, NewNormal):
-        if not (isinstance(NewNormal, np.ndarray) and len(NewNormal) == 3 and np.linalg.norm(NewNormal) > 0):
+    def _set_normal(self, value):
+        if not _is_vec3(value, nonzero=True):
             raise TypeError("Normal must be a 3D numpy.ndarray with finite length.")
-        new = mgeo.Normalize(NewNormal)
-        # keep the major axis perpendicular: carry it along with the rotation old normal -> new normal
-        # (ART/ModuleOpticalElement.py:126-141; skipped during construction, when no major axis exists yet)
-        if hasattr(self, "_majoraxis") and abs(np.dot(new, self._majoraxis)) > 1e-12:
-            self._majoraxis = mgeo.RotationAroundAxis(np.cross(self._normal, NewNormal),
-                                                      mgeo.AngleBetweenTwoVectors(self._normal, NewNormal),
-                                                      self._majoraxis)
-        self._normal = new
+        unit = mgeo.Normalize(value)
+        # (during construction there is no major axis yet)
+        if hasattr(self, "_majoraxis") and abs(np.dot(unit, self._majoraxis)) > _EPS_ORTHO:
+            turn_axis = np.cross(self._normal, value)
+            turn_angle = mgeo.AngleBetweenTwoVectors(self._normal, value)
+            self._majoraxis = mgeo.RotationAroundAxis(turn_axis, turn_angle, self._majoraxis)
+        self._normal = unit
 
-    @property
-    def majoraxis(self):
+    normal = property(_get_normal, _set_normal)
+
+    def _get_majoraxis(self):
         return self._majoraxis
 
-    @majoraxis.setter
-    def majoraxis(self, NewMajorAxis):
-        if not (isinstance(NewMajorAxis, np.ndarray) and len(NewMajorAxis) == 3 and np.linalg.norm(NewMajorAxis) > 0):
+    def _set_majoraxis(self, value):
+        if not _is_vec3(value, nonzero=True):
             raise TypeError("MajorAxis must be a 3D numpy.ndarray with finite length.")
-        if abs(np.dot(self.normal, mgeo.Normalize(NewMajorAxis))) > 1e-12:
+        unit = mgeo.Normalize(value)
+        if abs(np.dot(self.normal, unit)) > _EPS_ORTHO:
             raise ValueError("The normal and major axis of optical elements need to be orthogonal!")
-        self._majoraxis = mgeo.Normalize(NewMajorAxis)
+        self._majoraxis = unit
 
-    @property
-    def type(self):
-        return self._type
+    majoraxis = property(_get_majoraxis, _set_majoraxis)
 
     def __hash__(self):
-        return hash(tuple(self.position) + tuple(self.normal) + tuple(self.majoraxis)) + hash(self.type)
+        pose = tuple(self.position) + tuple(self.normal) + tuple(self.majoraxis)
+        return hash(pose) + hash(self.type)
 
     # ------------------------------------------------------------------ (mis-)alignment, angles in degrees
+    def _turn(self, which, axis, angle_deg):
+        setattr(self, which, mgeo.RotationAroundAxis(axis, np.deg2rad(angle_deg), getattr(self, which)))
+
     def rotate_pitch_by(self, angle):
-        """About normal x majoraxis (ART/ModuleOpticalElement.py:169-185)."""
-        axis = np.cross(self.normal, self.majoraxis)
-        self.normal = mgeo.RotationAroundAxis(axis, np.deg2rad(angle), self.normal)
+        """Normal turned about normal x majoraxis (:169-185)."""
+        self._turn("normal", np.cross(self.normal, self.majoraxis), angle)
 
     def rotate_roll_by(self, angle):
-        """About the major axis (:187-198)."""
-        self.normal = mgeo.RotationAroundAxis(self.majoraxis, np.deg2rad(angle), self.normal)
+        """Normal turned about the major axis (:187-198)."""
+        self._turn("normal", self.majoraxis, angle)
 
     def rotate_yaw_by(self, angle):
-        """About the normal (:200-209)."""
-        self.majoraxis = mgeo.RotationAroundAxis(self.normal, np.deg2rad(angle), self.majoraxis)
+        """Major axis turned about the normal (:200-209)."""
+        self._turn("majoraxis", self.normal, angle)
 
     def rotate_random_by(self, angle):
-        """About a random axis (:211-221)."""
-        self.normal = mgeo.RotationAroundAxis(np.random.random(3), np.deg2rad(angle), self.normal)
+        """Normal turned about a random axis, one np.random.random(3) draw (:211-221)."""
+        self._turn("normal", np.random.random(3), angle)
+
+    def _shift(self, direction, distance):
+        self.position = self.position + distance * direction
 
     def shift_along_normal(self, distance):
-        self.position = self.position + distance * self.normal
+        self._shift(self.normal, distance)
 
     def shift_along_major(self, distance):
-        self.position = self.position + distance * self.majoraxis
+        self._shift(self.majoraxis, distance)
 
     def shift_along_cross(self, distance):
-        self.position = self.position + distance * mgeo.Normalize(np.cross(self.normal, self.majoraxis))
+        self._shift(mgeo.Normalize(np.cross(self.normal, self.majoraxis)), distance)
 
     def shift_along_random(self, distance):
-        self.position = self.position + distance * mgeo.Normalize(np.random.random(3))
+        """Along a random direction, one np.random.random(3) draw (:252-265)."""
+        self._shift(mgeo.Normalize(np.random.random(3)), distance)
