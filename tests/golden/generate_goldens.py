@@ -27,6 +27,7 @@ import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = os.environ.get("ART_REFERENCE", "/root/reference")
+OUT = os.environ.get("ART_GOLDEN_OUT", HERE)      # set it to regenerate elsewhere and compare with the committed files
 sys.dont_write_bytecode = True
 sys.path.insert(0, REF)
 sys.path.insert(0, os.path.join(HERE, "_standin"))
@@ -184,7 +185,7 @@ def dump_chain(name, chain, detector_distance=None, ignore_defects=None, extra=N
     if getattr(chain, "_placement", None) is not None and not getattr(chain, "_modified_after_placement", False):
         scene["placement"] = chain._placement
     arrays["scene_json"] = np.array(json.dumps(scene))
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **arrays)
     print(f"{name}: src {scene['n_source']} -> {scene['n_out']}  ({scene['reference_trace_seconds']:.2f}s)  "
           f"{os.path.getsize(path)/1024:.0f} kB", flush=True)
@@ -418,7 +419,7 @@ def scene_zernike_tierA():
     arrays["defect_offset"] = np.array([Z.get_offset(p) for p in pts])
     arrays["defect_R"] = np.array(Z.R)
     arrays["defect_coeffs"] = np.array([[k[0], k[1], c] for k, c in coeffs.items()])
-    np.savez_compressed(os.path.join(HERE, "zernike_tierA.npz"), **arrays)
+    np.savez_compressed(os.path.join(OUT, "zernike_tierA.npz"), **arrays)
     print("zernike_tierA: %d polys x %d points" % (len(nm), len(x)))
 
 
@@ -484,7 +485,7 @@ def scene_geometry_units():
     arrays["stat_pts"], arrays["stat_w"], arrays["stat_delays"] = np.array(pts), np.array(w), np.array(dl)
     arrays["stat_out"] = np.array([mp.StandardDeviation(pts), mp.WeightedStandardDeviation(pts, w),
                                    mp.StandardDeviation(dl), mp.WeightedStandardDeviation(dl, w)])
-    np.savez_compressed(os.path.join(HERE, "geometry_units.npz"), **arrays)
+    np.savez_compressed(os.path.join(OUT, "geometry_units.npz"), **arrays)
     print("geometry_units done")
 
 
