@@ -16,7 +16,9 @@
 namespace {
 
 constexpr int kBlock = 256;          // 4 waves per workgroup
-constexpr int kMaxBlocks = 256 * 8;  // 256 CUs x 8 workgroups: grid-stride beyond that
+constexpr int kMaxBlocks = 256 * 8;  // reductions: 256 CUs x 8 workgroups, grid-stride beyond that (one partial each)
+constexpr int kReadoutBlocks = kMaxBlocks;  // fused read-out: persistent workgroups -- every workgroup ends with a 24-slot
+                                           // reduction, so MORE workgroups cost more (16384: 244 us instead of 176 us)
 constexpr int kChainMax = 8;         // elements per fused launch (kernel-argument budget)
 
 thread_local char g_err[512] = "";
@@ -28,6 +30,18 @@ int fail(int code, const char* msg) {
 int fail_hip(hipError_t e, const char* what) {
   snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
   return ART_ERR_HIP;
+}
+
+// Streaming kernels (trace, sources, transforms, read-out) get one workgroup per 256 rays, NOT a persistent grid with a
+// grid-stride loop: measured on relay4, 1e7 rays, the fused kernel takes 0.686 ms with 2048 workgroups and 0.653 ms
+// with 39063 (per-element kernel 0.243 -> 0.222 ms; at 1e8 rays 7.33 -> 6.35 ms).  Consecutive workgroups then sweep
+// every stream linearly (DRAM pages, TLB), and the hardware's workgroup dispatch hides latency at least as well as
+// the software prefetch of the grid-stride loop, which stays in the kernels for launches cut short by the cap.
+inline int grid_stream(int64_t n) {
+  int64_t b = (n + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  if (b > (int64_t)1 << 22) b = (int64_t)1 << 22;   // 2^28 rays per launch at most: never reached
+  return (int)b;
 }
 
 inline int grid_for(int64_t n) {
@@ -158,34 +172,22 @@ __global__ __launch_bounds__(kBlock) void k_trace_element(const ElemArg ea, cons
     __syncthreads();
     zern = s_zern;
   }
-  // Software-pipelined grid-stride loop: the 7 input streams + alive of the NEXT slot are requested (one round
-  // trip, speculatively for dead slots too) before the current ray is traced, so HBM latency hides under the
-  // ~450 fp64 instructions of an intersection; loads and stores are branch-free (see above), so the only waits
-  // the compiler inserts are counted ones on the prefetched registers.
+  // one ray per thread (grid_stream): no loop.  Slots beyond n fall outside every descriptor: their loads return 0
+  // (alive = 0) and their stores are dropped, so the tail needs no branch; loads and stores are branch-free (see
+  // above), so dead rays cost no divergent store sequence either.
   const BundleRsrc bi = make_rsrc(in, n), bo = make_rsrc(out, n);
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   art::Ray r;
   r.inc = 0.0;
   uint8_t a;
   load_slot(bi, i, r, a);
-  while (i < n) {
-    const int64_t inext = i + stride;
-    art::Ray rn;
-    rn.inc = 0.0;
-    uint8_t an;
-    load_slot(bi, inext, rn, an);
-    bool ok = a != 0;
+  bool ok = a != 0;
 #ifdef ART_DIAG_NOCOMPUTE   // timing-only build: memory traffic without the intersection math (results are wrong)
-    r.path += e.mp[0];
+  r.path += e.mp[0];
 #else
-    if (ok) ok = art::trace_ray<KIND, DEFECT>(e, zern, r);
+  if (ok) ok = art::trace_ray<KIND, DEFECT>(e, zern, r);
 #endif
-    store_slot(bo, i, r, ok);
-    r = rn;
-    a = an;
-    i = inext;
-  }
+  store_slot(bo, i, r, ok);
 }
 
 struct ChainArgs {
@@ -208,32 +210,23 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain(const ChainArgs a
         art::zern_pack(a.e[k].zern + d * ART_ZERN_STRIDE, s_zern + a.zoff[k] + d * ART_ZPACK_STRIDE, threadIdx.x, kBlock);
     __syncthreads();
   }
+  // one ray per thread (grid_stream): no loop.  Slots beyond n fall outside every descriptor: their loads return 0
+  // (alive = 0) and their stores are dropped, so the tail needs no branch.
   const BundleRsrc bi = make_rsrc(in, n);
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   art::Ray r;
   r.inc = 0.0;
   uint8_t al;
   load_slot(bi, i, r, al);
-  while (i < n) {  // software-pipelined like k_trace_element: next slot's inputs in flight while this ray is traced
-    const int64_t inext = i + stride;
-    art::Ray rn;
-    rn.inc = 0.0;
-    uint8_t an;
-    load_slot(bi, inext, rn, an);
-    bool ok = al != 0;
-    for (int k = 0; k < a.n_elems; ++k) {
+  bool ok = al != 0;
+  for (int k = 0; k < a.n_elems; ++k) {
 #ifdef ART_DIAG_NOCOMPUTE
-      r.path += a.e[k].mp[0];
+    r.path += a.e[k].mp[0];
 #else
-      if (ok) ok = art::trace_ray_dyn<DEFECT>(a.e[k], s_zern + a.zoff[k], r);
+    if (ok) ok = art::trace_ray_dyn<DEFECT>(a.e[k], s_zern + a.zoff[k], r);
 #endif
-      // no history view for this element -> zero-length descriptors: every store is dropped by the range check
-      store_slot(make_rsrc(a.out[k], a.out[k].alive != nullptr ? n : 0), i, r, ok);
-    }
-    r = rn;
-    al = an;
-    i = inext;
+    // no history view for this element -> zero-length descriptors: every store is dropped by the range check
+    store_slot(make_rsrc(a.out[k], a.out[k].alive != nullptr ? n : 0), i, r, ok);
   }
 }
 
@@ -734,7 +727,7 @@ int check_elem(const ArtElementDesc* e) {
 template <int KIND>
 void launch_element(const ArtElementDesc& e, const ArtBundleView& in, const ArtBundleView& out, int64_t n,
                     hipStream_t s) {
-  const int grid = grid_for(n);
+  const int grid = grid_stream(n);
   ElemArg ea;
   ea.e[0] = e;
   if (e.n_defects > 0 || e.n_grid > 0)
@@ -815,8 +808,11 @@ int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundl
     // the chunk's last bundle is the next chunk's input: it must exist
     if (!view_ok(&outs[k0 + m - 1])) return fail(ART_ERR_BAD_ARG, "chains longer than 8 need a view every 8th element");
   }
-  const char* wv = getenv("ART_CHAIN_WAVES");   // tuning knob: register budget of the fused kernel (waves per SIMD)
-  const int waves = wv ? atoi(wv) : 4;
+  // register budget of the fused kernel in waves per SIMD: 5 (96 VGPRs, no spills) measures 2.5 % faster than 4
+  // (98 VGPRs, which the allocation granule rounds to 104 = 4 waves); 6 needs 12 spilled registers and is 20 % slower.
+  // ART_CHAIN_WAVES=4 selects the other build for comparison.
+  const char* wv = getenv("ART_CHAIN_WAVES");
+  const int waves = wv ? atoi(wv) : 5;
   const int64_t chunk = max_rays_per_launch();
   for (int64_t off = 0; off < n; off += chunk) {
     const int64_t cnt = (n - off < chunk) ? n - off : chunk;
@@ -838,13 +834,13 @@ int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundl
       if ((size_t)a.zern_doubles * sizeof(double) > 64 * 1024)
         return fail(ART_ERR_UNSUPPORTED, "Zernike tables of one fused launch exceed 64 KiB of LDS: trace this chain "
                                          "element by element (art_trace_element)");
-      const dim3 g(grid_for(cnt)), b(kBlock);
+      const dim3 g(grid_stream(cnt)), b(kBlock);
       if (any_defect)
         hipLaunchKernelGGL((k_trace_chain<true, 4>), g, b, (size_t)a.zern_doubles * sizeof(double), s, a, cur, cnt);
-      else if (waves == 3)
-        hipLaunchKernelGGL((k_trace_chain<false, 3>), g, b, 0, s, a, cur, cnt);
-      else
+      else if (waves == 4)
         hipLaunchKernelGGL((k_trace_chain<false, 4>), g, b, 0, s, a, cur, cnt);
+      else
+        hipLaunchKernelGGL((k_trace_chain<false, 5>), g, b, 0, s, a, cur, cnt);
       cur = a.out[m - 1];
     }
   }
@@ -858,7 +854,7 @@ int art_pack_rays(const double* points, const double* vectors, const double* pat
   if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
   if (n == 0) return ART_OK;
   if (!points || !vectors || !view_ok(out)) return fail(ART_ERR_BAD_ARG, "NULL argument");
-  hipLaunchKernelGGL(k_pack_rays, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, points, vectors, path0, n,
+  hipLaunchKernelGGL(k_pack_rays, dim3(grid_stream(n)), dim3(kBlock), 0, (hipStream_t)stream, points, vectors, path0, n,
                      *out);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_pack_rays launch");
@@ -875,7 +871,7 @@ int art_transform_bundle(const double M[9], const double T[3], int32_t rotate_po
   memset(&mt, 0, sizeof(mt));
   memcpy(mt.rot, M, 9 * sizeof(double));
   memcpy(mt.centre, T, 3 * sizeof(double));
-  hipLaunchKernelGGL(k_transform, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, mt, (int)rotate_points, *in,
+  hipLaunchKernelGGL(k_transform, dim3(grid_stream(n)), dim3(kBlock), 0, (hipStream_t)stream, mt, (int)rotate_points, *in,
                      *out, n);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_transform_bundle launch");
@@ -891,7 +887,7 @@ int art_detector(const ArtDetectorDesc* d, const ArtBundleView* b, int64_t n, do
   if ((X || Y) && !(X && Y)) return fail(ART_ERR_BAD_ARG, "X/Y must be both set or both NULL");
   if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
   if (n == 0) return ART_OK;
-  hipLaunchKernelGGL(k_detector, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, *d, *b, n, p3x, p3y, p3z, X,
+  hipLaunchKernelGGL(k_detector, dim3(grid_stream(n)), dim3(kBlock), 0, (hipStream_t)stream, *d, *b, n, p3x, p3y, p3z, X,
                      Y, opl);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_detector launch");
@@ -913,13 +909,14 @@ int art_detector_readout(const ArtDetectorDesc* d, const ArtBundleView* b, const
   }
   if (!view_ok(b)) return fail(ART_ERR_BAD_ARG, "bundle view has a NULL array");
   // one launch per <= 2^28 rays (32-bit buffer offsets); every launch leaves one partial per workgroup, all of
-  // them folded by the final kernel: scratch holds up to 8 launches x 2048 workgroups x 24 doubles
+  // them folded by the final kernel: scratch holds up to 8 launches x kReadoutBlocks workgroups x 24 doubles
   const int64_t chunk = max_rays_per_launch();
   if ((n + chunk - 1) / chunk > 8) return fail(ART_ERR_UNSUPPORTED, "more than 2^31 rays in one read-out");
   int nb_total = 0;
   for (int64_t off = 0; off < n; off += chunk) {
     const int64_t m = (n - off < chunk) ? n - off : chunk;
-    const int nb = grid_for(m);
+    const int64_t want = ((m + 1) / 2 + kBlock - 1) / kBlock;      // two slots per thread
+    const int nb = (int)(want < 1 ? 1 : (want > kReadoutBlocks ? kReadoutBlocks : want));
     const ArtBundleView v = view_at(*b, off);
     hipLaunchKernelGGL(k_detector_readout, dim3(nb), dim3(kBlock), 0, s, *d, v, w ? w + off : nullptr, m, cx, cy, co,
                        p3x ? p3x + off : nullptr, p3y ? p3y + off : nullptr, p3z ? p3z + off : nullptr,
@@ -953,7 +950,7 @@ int art_detector_scan_moments(const ArtDetectorDesc* d, const ArtBundleView* b, 
   return ART_OK;
 }
 
-int64_t art_reduce_scratch_doubles(void) { return (int64_t)8 * kMaxBlocks * kReadoutSlots + 64; }
+int64_t art_reduce_scratch_doubles(void) { return (int64_t)8 * kReadoutBlocks * kReadoutSlots + 64; }
 
 int art_detector_stats(const uint8_t* alive, const double* X, const double* Y, const double* opl, const double* w,
                        int64_t n, double* scratch, double* out16, void* stream) {
@@ -1010,7 +1007,7 @@ int art_gaussian_intensity(const ArtBundleView* bv, const double axis[3], double
   double* maxima = scratch + (int64_t)kRedBlocks * kSumSlots;
   hipLaunchKernelGGL(k_gauss_max_partial, dim3(nb), dim3(kBlock), 0, s, *bv, ax, n, scratch);
   hipLaunchKernelGGL(k_gauss_max_final, dim3(1), dim3(kBlock), 0, s, scratch, nb, maxima);
-  hipLaunchKernelGGL(k_gauss_weights, dim3(grid_for(n)), dim3(kBlock), 0, s, *bv, ax, -0.5 * log(fraction), maxima, n,
+  hipLaunchKernelGGL(k_gauss_weights, dim3(grid_stream(n)), dim3(kBlock), 0, s, *bv, ax, -0.5 * log(fraction), maxima, n,
                      w_out);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_gaussian_intensity launch");
@@ -1079,7 +1076,7 @@ int art_make_source(int32_t kind, double size, const double rot[9], const double
   memset(&rs, 0, sizeof(rs));
   memcpy(rs.rot, rot, 9 * sizeof(double));
   memcpy(rs.centre, S, 3 * sizeof(double));
-  hipLaunchKernelGGL(k_make_source, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, kind, size, rs, first, n,
+  hipLaunchKernelGGL(k_make_source, dim3(grid_stream(n)), dim3(kBlock), 0, (hipStream_t)stream, kind, size, rs, first, n,
                      n_total, *out);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_make_source launch");
@@ -1118,7 +1115,7 @@ int art_make_extended_source(double radius, double divergence, int64_t n_points,
   memset(&rs, 0, sizeof(rs));
   memcpy(rs.rot, rot, 9 * sizeof(double));
   memcpy(rs.centre, S, 3 * sizeof(double));
-  hipLaunchKernelGGL(k_make_extended_source, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, radius,
+  hipLaunchKernelGGL(k_make_extended_source, dim3(grid_stream(n)), dim3(kBlock), 0, (hipStream_t)stream, radius,
                      divergence, n_points, rays_per_point, rs, first, n, *out);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_make_extended_source launch");

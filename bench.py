@@ -333,7 +333,7 @@ def main():
     achieved = ALGO_BYTES_PER_INTERSECTION * inter_per_launch / (kernel_ms * 1e-3) / 1e9
 
     if rank == 0:
-        kname = "k_trace_chain<false, 4>" if mode == "chain" else "k_trace_element<ART_TORUS, false>"
+        kname = "k_trace_chain<false, 5>" if mode == "chain" else "k_trace_element<ART_TORUS, false>"
         tr = profiled_traffic(kname, n, args.mirrors, mode)
         value = inter_per_step_rank * world * args.steps / dt
         res = {
