@@ -32,11 +32,13 @@ int fail_hip(hipError_t e, const char* what) {
   return ART_ERR_HIP;
 }
 
-// Streaming kernels (trace, sources, transforms, read-out) get one workgroup per 256 rays, NOT a persistent grid with a
-// grid-stride loop: measured on relay4, 1e7 rays, the fused kernel takes 0.686 ms with 2048 workgroups and 0.653 ms
-// with 39063 (per-element kernel 0.243 -> 0.222 ms; at 1e8 rays 7.33 -> 6.35 ms).  Consecutive workgroups then sweep
-// every stream linearly (DRAM pages, TLB), and the hardware's workgroup dispatch hides latency at least as well as
-// the software prefetch of the grid-stride loop, which stays in the kernels for launches cut short by the cap.
+// The two trace kernels get one workgroup per 256 rays, NOT a persistent grid with a grid-stride loop: measured on
+// relay4, 1e7 rays, the fused kernel takes 0.686 ms with 2048 workgroups and 0.653 ms with 39063 (per-element kernel
+// 0.243 -> 0.222 ms; at 1e8 rays 7.33 -> 6.35 ms).  Consecutive workgroups then sweep every stream linearly (DRAM
+// pages, TLB), and the hardware's workgroup dispatch hides latency at least as well as a software prefetch did.
+// It is not a general rule (all per 1e7 rays, launches back to back): the bundle transform also gains (263 -> 226 us),
+// the source generator (plain stores behind heavy trigonometry) loses (138 -> 158 us) and the fused read-out loses
+// (every workgroup ends in a 24-slot reduction), so those keep the persistent grid_for().
 inline int grid_stream(int64_t n) {
   int64_t b = (n + kBlock - 1) / kBlock;
   if (b < 1) b = 1;
@@ -854,7 +856,7 @@ int art_pack_rays(const double* points, const double* vectors, const double* pat
   if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
   if (n == 0) return ART_OK;
   if (!points || !vectors || !view_ok(out)) return fail(ART_ERR_BAD_ARG, "NULL argument");
-  hipLaunchKernelGGL(k_pack_rays, dim3(grid_stream(n)), dim3(kBlock), 0, (hipStream_t)stream, points, vectors, path0, n,
+  hipLaunchKernelGGL(k_pack_rays, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, points, vectors, path0, n,
                      *out);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_pack_rays launch");
@@ -887,7 +889,7 @@ int art_detector(const ArtDetectorDesc* d, const ArtBundleView* b, int64_t n, do
   if ((X || Y) && !(X && Y)) return fail(ART_ERR_BAD_ARG, "X/Y must be both set or both NULL");
   if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
   if (n == 0) return ART_OK;
-  hipLaunchKernelGGL(k_detector, dim3(grid_stream(n)), dim3(kBlock), 0, (hipStream_t)stream, *d, *b, n, p3x, p3y, p3z, X,
+  hipLaunchKernelGGL(k_detector, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, *d, *b, n, p3x, p3y, p3z, X,
                      Y, opl);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_detector launch");
@@ -1007,7 +1009,7 @@ int art_gaussian_intensity(const ArtBundleView* bv, const double axis[3], double
   double* maxima = scratch + (int64_t)kRedBlocks * kSumSlots;
   hipLaunchKernelGGL(k_gauss_max_partial, dim3(nb), dim3(kBlock), 0, s, *bv, ax, n, scratch);
   hipLaunchKernelGGL(k_gauss_max_final, dim3(1), dim3(kBlock), 0, s, scratch, nb, maxima);
-  hipLaunchKernelGGL(k_gauss_weights, dim3(grid_stream(n)), dim3(kBlock), 0, s, *bv, ax, -0.5 * log(fraction), maxima, n,
+  hipLaunchKernelGGL(k_gauss_weights, dim3(grid_for(n)), dim3(kBlock), 0, s, *bv, ax, -0.5 * log(fraction), maxima, n,
                      w_out);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_gaussian_intensity launch");
@@ -1076,7 +1078,7 @@ int art_make_source(int32_t kind, double size, const double rot[9], const double
   memset(&rs, 0, sizeof(rs));
   memcpy(rs.rot, rot, 9 * sizeof(double));
   memcpy(rs.centre, S, 3 * sizeof(double));
-  hipLaunchKernelGGL(k_make_source, dim3(grid_stream(n)), dim3(kBlock), 0, (hipStream_t)stream, kind, size, rs, first, n,
+  hipLaunchKernelGGL(k_make_source, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, kind, size, rs, first, n,
                      n_total, *out);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_make_source launch");
@@ -1115,7 +1117,7 @@ int art_make_extended_source(double radius, double divergence, int64_t n_points,
   memset(&rs, 0, sizeof(rs));
   memcpy(rs.rot, rot, 9 * sizeof(double));
   memcpy(rs.centre, S, 3 * sizeof(double));
-  hipLaunchKernelGGL(k_make_extended_source, dim3(grid_stream(n)), dim3(kBlock), 0, (hipStream_t)stream, radius,
+  hipLaunchKernelGGL(k_make_extended_source, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, radius,
                      divergence, n_points, rays_per_point, rs, first, n, *out);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_make_extended_source launch");
