@@ -57,8 +57,8 @@ inline int grid_for(int64_t n) {
 // Every stream is addressed through a 128-bit buffer descriptor (base, byte count) with the per-lane byte offset
 // in a 32-bit VGPR.  The hardware range check gives branch-free predication: a lane whose offset is out of range
 // loads 0 / stores nothing.  That is what lets dead rays skip their 8 output stores WITHOUT a branch around the
-// stores -- a branch would make the compiler drain every outstanding store (s_waitcnt vmcnt(0)) at the join and
-// undo the software pipelining below.  One launch covers at most 2^28 rays (32-bit byte offsets); the C ABI splits
+// stores -- a branch would make the compiler drain every outstanding store (s_waitcnt vmcnt(0)) at the join, between
+// the elements of a chain -- and the tail of a launch (slots >= n) needs no branch either.  One launch covers at most 2^28 rays (32-bit byte offsets); the C ABI splits
 // larger bundles into several launches.
 typedef int v2i32 __attribute__((ext_vector_type(2)));
 // Cache-policy bits of the buffer instructions (gfx942/gfx950 aux operand: 1 = sc0, 2 = nt, 16 = sc1).  Every ray
@@ -174,22 +174,26 @@ __global__ __launch_bounds__(kBlock) void k_trace_element(const ElemArg ea, cons
     __syncthreads();
     zern = s_zern;
   }
-  // one ray per thread (grid_stream): no loop.  Slots beyond n fall outside every descriptor: their loads return 0
-  // (alive = 0) and their stores are dropped, so the tail needs no branch; loads and stores are branch-free (see
-  // above), so dead rays cost no divergent store sequence either.
+  // Without defects: one ray per thread (grid_stream), no loop.  Slots beyond n fall outside every descriptor: their
+  // loads return 0 (alive = 0) and their stores are dropped, so the tail needs no branch.  With defects the
+  // workgroup has just staged its tables in LDS, which is worth amortising: persistent grid (grid_for) + loop.
   const BundleRsrc bi = make_rsrc(in, n), bo = make_rsrc(out, n);
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  art::Ray r;
-  r.inc = 0.0;
-  uint8_t a;
-  load_slot(bi, i, r, a);
-  bool ok = a != 0;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  do {
+    art::Ray r;
+    r.inc = 0.0;
+    uint8_t a;
+    load_slot(bi, i, r, a);
+    bool ok = a != 0;
 #ifdef ART_DIAG_NOCOMPUTE   // timing-only build: memory traffic without the intersection math (results are wrong)
-  r.path += e.mp[0];
+    r.path += e.mp[0];
 #else
-  if (ok) ok = art::trace_ray<KIND, DEFECT>(e, zern, r);
+    if (ok) ok = art::trace_ray<KIND, DEFECT>(e, zern, r);
 #endif
-  store_slot(bo, i, r, ok);
+    store_slot(bo, i, r, ok);
+    i += stride;
+  } while (DEFECT && i < n);
 }
 
 struct ChainArgs {
@@ -212,24 +216,28 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain(const ChainArgs a
         art::zern_pack(a.e[k].zern + d * ART_ZERN_STRIDE, s_zern + a.zoff[k] + d * ART_ZPACK_STRIDE, threadIdx.x, kBlock);
     __syncthreads();
   }
-  // one ray per thread (grid_stream): no loop.  Slots beyond n fall outside every descriptor: their loads return 0
-  // (alive = 0) and their stores are dropped, so the tail needs no branch.
+  // Without defects: one ray per thread (grid_stream), no loop; slots beyond n fall outside every descriptor (loads
+  // return 0 = dead, stores are dropped).  With defects: persistent grid + loop, to amortise the LDS staging above.
   const BundleRsrc bi = make_rsrc(in, n);
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  art::Ray r;
-  r.inc = 0.0;
-  uint8_t al;
-  load_slot(bi, i, r, al);
-  bool ok = al != 0;
-  for (int k = 0; k < a.n_elems; ++k) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  do {
+    art::Ray r;
+    r.inc = 0.0;
+    uint8_t al;
+    load_slot(bi, i, r, al);
+    bool ok = al != 0;
+    for (int k = 0; k < a.n_elems; ++k) {
 #ifdef ART_DIAG_NOCOMPUTE
-    r.path += a.e[k].mp[0];
+      r.path += a.e[k].mp[0];
 #else
-    if (ok) ok = art::trace_ray_dyn<DEFECT>(a.e[k], s_zern + a.zoff[k], r);
+      if (ok) ok = art::trace_ray_dyn<DEFECT>(a.e[k], s_zern + a.zoff[k], r);
 #endif
-    // no history view for this element -> zero-length descriptors: every store is dropped by the range check
-    store_slot(make_rsrc(a.out[k], a.out[k].alive != nullptr ? n : 0), i, r, ok);
-  }
+      // no history view for this element -> zero-length descriptors: every store is dropped by the range check
+      store_slot(make_rsrc(a.out[k], a.out[k].alive != nullptr ? n : 0), i, r, ok);
+    }
+    i += stride;
+  } while (DEFECT && i < n);
 }
 
 // ------------------------------------------------------------------------------------------- AoS -> SoA
@@ -729,13 +737,12 @@ int check_elem(const ArtElementDesc* e) {
 template <int KIND>
 void launch_element(const ArtElementDesc& e, const ArtBundleView& in, const ArtBundleView& out, int64_t n,
                     hipStream_t s) {
-  const int grid = grid_stream(n);
   ElemArg ea;
   ea.e[0] = e;
   if (e.n_defects > 0 || e.n_grid > 0)
-    hipLaunchKernelGGL((k_trace_element<KIND, true>), dim3(grid), dim3(kBlock), 0, s, ea, in, out, n);
+    hipLaunchKernelGGL((k_trace_element<KIND, true>), dim3(grid_for(n)), dim3(kBlock), 0, s, ea, in, out, n);
   else
-    hipLaunchKernelGGL((k_trace_element<KIND, false>), dim3(grid), dim3(kBlock), 0, s, ea, in, out, n);
+    hipLaunchKernelGGL((k_trace_element<KIND, false>), dim3(grid_stream(n)), dim3(kBlock), 0, s, ea, in, out, n);
 }
 
 }  // namespace
@@ -838,7 +845,8 @@ int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundl
                                          "element by element (art_trace_element)");
       const dim3 g(grid_stream(cnt)), b(kBlock);
       if (any_defect)
-        hipLaunchKernelGGL((k_trace_chain<true, 4>), g, b, (size_t)a.zern_doubles * sizeof(double), s, a, cur, cnt);
+        hipLaunchKernelGGL((k_trace_chain<true, 4>), dim3(grid_for(cnt)), b, (size_t)a.zern_doubles * sizeof(double), s, a,
+                           cur, cnt);
       else if (waves == 4)
         hipLaunchKernelGGL((k_trace_chain<false, 4>), g, b, 0, s, a, cur, cnt);
       else
