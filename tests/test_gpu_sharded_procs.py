@@ -15,6 +15,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    """A TCP port nobody listens on right now (the rendezvous of the worker processes)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _trace_shard(rank, world, n_total):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -58,7 +66,7 @@ def test_two_processes_one_gpu_match_single_process():
     ref_xyo, ref_alive, ref_stats = _trace_shard(0, 1, n_total)
     ctx = tmp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + (os.getpid() % 200)
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(rk, 2, port, n_total, q)) for rk in range(2)]
     for p in procs:
         p.start()

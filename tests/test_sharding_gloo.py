@@ -13,6 +13,14 @@ import torch.multiprocessing as tmp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    """A TCP port nobody listens on right now (the rendezvous of the worker processes)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _scene(n_total):
     import ART.ModuleMirror as mmirror
     import ART.ModuleMask as mmask
@@ -118,7 +126,7 @@ def test_two_rank_shards_match_single_process(n_total):
         _lib._BACKEND = old
     ctx = tmp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(rk, 2, port, n_total, q)) for rk in range(2)]
     for p in procs:
         p.start()
