@@ -221,11 +221,15 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain(const ChainArgs a
   const BundleRsrc bi = make_rsrc(in, n);
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  art::Ray r;
+  r.inc = 0.0;
+  uint8_t al;
+  load_slot(bi, i, r, al);
   do {
-    art::Ray r;
-    r.inc = 0.0;
-    uint8_t al;
-    load_slot(bi, i, r, al);
+    art::Ray rn;     // persistent (DEFECT) form: the next slot's inputs are in flight while this ray is traced
+    rn.inc = 0.0;
+    uint8_t an = 0;
+    if (DEFECT) load_slot(bi, i + stride, rn, an);
     bool ok = al != 0;
     for (int k = 0; k < a.n_elems; ++k) {
 #ifdef ART_DIAG_NOCOMPUTE
@@ -236,6 +240,8 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain(const ChainArgs a
       // no history view for this element -> zero-length descriptors: every store is dropped by the range check
       store_slot(make_rsrc(a.out[k], a.out[k].alive != nullptr ? n : 0), i, r, ok);
     }
+    r = rn;
+    al = an;
     i += stride;
   } while (DEFECT && i < n);
 }
