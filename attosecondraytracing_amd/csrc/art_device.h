@@ -10,7 +10,8 @@
 //   * the torus is NOT solved through its expanded quartic (coefficients ~1e15): candidates with
 //     z < -R lie on the outer half-tube, which is part of the boundary of the convex body
 //     K = disk(R) (+) ball(r); a line meets it at most twice, and H(t) = dist(P(t), disk)^2 - r^2 is
-//     convex in t, so monotone Newton from the bounding sphere finds exactly the reference's candidates.
+//     convex in t, so monotone Newton from outside K (start: an osculating spheroid that contains K) finds exactly
+//     the reference's candidates; self-intersecting tori add the inner convex body of the quartic's second factor.
 #pragma once
 #include <math.h>
 #include <stdint.h>
