@@ -273,6 +273,43 @@ def test_gpu_plain_c_consumer_of_the_abi(hip, tmp_path):
     assert r.returncode == 0 and "C_ABI_DEMO_OK" in r.stdout, r.stdout + r.stderr
 
 
+def test_gpu_step_captured_in_a_hip_graph(hip):
+    """A trace + read-out step captured with graph.CapturedStep replays to the same bits as eager launches, and a
+    replay picks up rays written in place into the captured source bundle."""
+    import torch
+    import bench
+    import ART.ModuleProcessing as mp
+    import ART.ModuleDetector as mdet
+    from attosecondraytracing_amd import _lib
+    from attosecondraytracing_amd.graph import CapturedStep
+    be = _lib.get_backend()
+    n = 50_000
+    chain, _ = bench.build_scene(3)
+    els = chain.optical_elements
+    src = bench.device_source(n, 0, n, be)
+    det = mdet.Detector(np.asarray(els[-1].position, dtype=float))
+    det.autoplace(mp.RayTracingCalculation(src, els)[-1], 600.0)
+
+    def step():
+        o = mp.RayTracingCalculation(src, els)
+        return o, det.readout(o[-1], sync=False)
+
+    o, r = step()
+    want_stats, want_X = r["stats_dev"].clone(), r["X"].clone()
+    cap = CapturedStep(step)
+    go, gr = cap.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(gr["stats_dev"], want_stats) and torch.equal(gr["X"], want_X)
+    assert torch.equal(go[0].data, o[0].data) and torch.equal(go[-1].alive, o[-1].alive)
+    # other rays through the same captured scene: every second ray switched off in place
+    src.alive[::2] = 0
+    cap.replay()
+    torch.cuda.synchronize()
+    assert int(gr["stats_dev"][0].item()) == n // 2
+    eager = step()[1]["stats_dev"]
+    assert torch.equal(gr["stats_dev"], eager)
+
+
 def test_gpu_error_paths(hip):
     """Bad arguments come back as error codes with a message, never as a crash."""
     import ctypes as C
