@@ -59,6 +59,20 @@ def main():
             continue
         out.append(f"| {k} | {len(d)} | {sum(d)/len(d)/1e3:.1f} | {min(d)/1e3:.1f} | {max(d)/1e3:.1f} | {g} | {big[0][2]} | {big[0][3]} | {big[0][4]} |")
     out.append("")
+    # the timed steps of bench.py are the LAST `steps` launches of the trace kernel (the ones before are scene set-up
+    # and warm-up): their average is what bench.py's roofline.kernel_ms measures with HIP events
+    steps = 20
+    if "--steps" in extra.split():
+        steps = int(extra.split()[extra.split().index("--steps") + 1])
+    for k, v in byk.items():
+        if k.startswith("k_trace_chain") or k.startswith("k_trace_element"):
+            g = max(x[0] for x in v)
+            big = [x[1] for x in v if x[0] == g]
+            per_step = 1 if k.startswith("k_trace_chain") else max(1, len(big) // (steps + 6))
+            last = big[-steps * per_step:]
+            if len(last) >= steps and sum(big) > 1e6:
+                out.append(f"`{k}`: average over the last {len(last)} launches (the timed steps) = {sum(last)/len(last)/1e3:.1f} us")
+    out.append("")
     # ---- PMC passes
     def pmc(tag, counter):
         f = glob.glob(os.path.join(src, "pmc_" + tag, "*", "*_counter_collection.csv"))
