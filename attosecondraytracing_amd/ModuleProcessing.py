@@ -107,6 +107,9 @@ def _as_bundle(rays, backend=None):
     return RayBundle.from_ray_list(rays, backend)
 
 
+_CHAIN_MAX = 8          # elements per fused launch (kChainMax in csrc/art_kernels.hip)
+
+
 # ------------------------------------------------------------------------------------------- the hot path
 def RayTracingCalculation(source_rays, optical_elements, IgnoreDefects=True, mode=None, history=True):
     """Propagate `source_rays` through `optical_elements` (ART/ModuleProcessing.py:250-313).
@@ -153,6 +156,13 @@ def RayTracingCalculation(source_rays, optical_elements, IgnoreDefects=True, mod
             prev = b
     if mode == "chain":
         views = [b.view() if b is not None else _abi.ArtBundleView() for b in outs]
+        if not history and m > _CHAIN_MAX:
+            # one fused launch covers at most 8 elements; the bundle handed from one launch to the next needs
+            # storage even when the caller wants no history: two scratch bundles, used alternately
+            scratch = [RayBundle.allocate(n, like=src, backend=be) for _ in range(min(2, (m - 1) // _CHAIN_MAX))]
+            for j, k in enumerate(range(_CHAIN_MAX - 1, m - 1, _CHAIN_MAX)):
+                views[k] = scratch[j % len(scratch)].view()
+            outs[-1]._keepalive = (keep, scratch)
         be.trace_chain(descs, src.view(), views, n)
     elif mode == "element":
         if not history and m > 1:

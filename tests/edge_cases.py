@@ -47,6 +47,31 @@ def run_edge_cases():
         wall = moe.OpticalElement(mmask.Mask(msupp.SupportRound(1e6)), np.array([0.0, 0.0, 10.0]),
                                   np.array([0.0, 0.0, -1.0]), np.array([1.0, 0.0, 0.0]))
         assert [len(o) for o in mp.RayTracingCalculation(_bundle(300), [wall, oe], mode=mode)] == [0, 0]
+    # a chain longer than one fused launch (8 elements): 19 bounces between two facing plane mirrors, with and
+    # without history, in both modes; the optical path is known in closed form
+    top = moe.OpticalElement(mmirror.MirrorPlane(msupp.SupportRound(1e4)), np.array([0.0, 0.0, 50.0]),
+                             np.array([0.0, 0.0, -1.0]), np.array([1.0, 0.0, 0.0]))
+    bottom = moe.OpticalElement(mmirror.MirrorPlane(msupp.SupportRound(1e4)), np.array([0.0, 0.0, 0.0]),
+                                np.array([0.0, 0.0, 1.0]), np.array([1.0, 0.0, 0.0]))
+    hall = [top, bottom] * 9 + [top]
+    rng = np.random.default_rng(0)
+    n = 300
+    P = np.stack([rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), np.full(n, 20.0)], axis=1)
+    V = np.stack([rng.uniform(-0.05, 0.05, n), rng.uniform(-0.05, 0.05, n), np.ones(n)], axis=1)
+    src = RayBundle.from_arrays(P, V, np.arange(n), np.ones(n))
+    dz = 1.0 / np.linalg.norm(V, axis=1)
+    expect = (30.0 + 18 * 50.0) / dz
+    results = []
+    for mode in ("chain", "element"):
+        for hist in (True, False):
+            out = mp.RayTracingCalculation(src, hall, mode=mode, history=hist)
+            assert len(out) == 19 and len(out[-1]) == n and (hist or all(o is None for o in out[:-1]))
+            assert np.abs(out[-1].paths_total() - expect).max() <= 1e-10 * 1000
+            results.append(out[-1].data.cpu().numpy())
+            if hist:
+                assert out[-1].path_segments().shape == (n, 20)
+    for r in results[1:]:
+        assert np.abs(r - results[0]).max() <= 1e-12 * 1000
     # non-finite inputs and rays parallel to the mirror plane are dropped, finite neighbours unaffected
     n = 130
     b = _bundle(n, 5)
