@@ -68,6 +68,15 @@ class TwinBackend:
 
     def trace_chain(self, descs, vin, vouts, n):
         m = len(descs)
+        # the argument rules of art_trace_chain (csrc/art_kernels.hip), so that host-shell mistakes show up without a GPU:
+        # the last view is mandatory, and a chain longer than one fused launch (8 elements) needs a view where one
+        # launch hands over to the next; Zernike tables of one launch must fit 64 KiB of LDS (502 doubles per defect)
+        if n > 0:
+            assert vouts[m - 1].alive, "the last output view is mandatory"
+            for k0 in range(0, m, 8):
+                k1 = min(k0 + 8, m)
+                assert vouts[k1 - 1].alive, "chains longer than 8 need a view every 8th element"
+                assert sum(d.n_defects for d in descs[k0:k1]) * 502 * 8 <= 64 * 1024, "Zernike tables exceed 64 KiB of LDS"
         darr = (_abi.ArtElementDesc * m)(*descs)
         varr = (_abi.ArtBundleView * m)(*vouts)
         assert self.lib.art_cpu_trace_chain(darr, m, C.byref(vin), varr, n) == 0
