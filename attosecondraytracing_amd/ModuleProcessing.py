@@ -108,6 +108,7 @@ def _as_bundle(rays, backend=None):
 
 
 _CHAIN_MAX = 8          # elements per fused launch (kChainMax in csrc/art_kernels.hip)
+_CHAIN_MAX_DEFECTS = 16  # Zernike defects per fused launch: 64 KiB of LDS / 502 doubles per packed table
 
 
 # ------------------------------------------------------------------------------------------- the hot path
@@ -154,6 +155,9 @@ def RayTracingCalculation(source_rays, optical_elements, IgnoreDefects=True, mod
             b.parent = prev
             b._keepalive = keep
             prev = b
+    if mode == "chain" and any(sum(d.n_defects for d in descs[k0:k0 + _CHAIN_MAX]) > _CHAIN_MAX_DEFECTS
+                               for k0 in range(0, m, _CHAIN_MAX)):
+        mode = "element"    # the Zernike tables of one fused launch would not fit its 64 KiB of LDS
     if mode == "chain":
         views = [b.view() if b is not None else _abi.ArtBundleView() for b in outs]
         if not history and m > _CHAIN_MAX:

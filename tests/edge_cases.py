@@ -72,6 +72,15 @@ def run_edge_cases():
                 assert out[-1].path_segments().shape == (n, 20)
     for r in results[1:]:
         assert np.abs(r - results[0]).max() <= 1e-12 * 1000
+    # more Zernike tables than one fused launch can stage in LDS (16): the chain is traced element by element instead
+    import ART.ModuleDefects as mdef
+    S = msupp.SupportRound(1e4)
+    warped = lambda: mmirror.DeformedMirror(mmirror.MirrorPlane(S), [mdef.Zernike(S, {(2, 1): 1e-6 * (k + 1)}) for k in range(4)])
+    wt = moe.OpticalElement(warped(), np.array([0.0, 0.0, 50.0]), np.array([0.0, 0.0, -1.0]), np.array([1.0, 0.0, 0.0]))
+    wb = moe.OpticalElement(warped(), np.array([0.0, 0.0, 0.0]), np.array([0.0, 0.0, 1.0]), np.array([1.0, 0.0, 0.0]))
+    a_ = mp.RayTracingCalculation(src, [wt, wb] * 3, mode="chain", IgnoreDefects=False)      # 24 tables
+    b_ = mp.RayTracingCalculation(src, [wt, wb] * 3, mode="element", IgnoreDefects=False)
+    assert len(a_[-1]) == n and np.array_equal(a_[-1].data.cpu().numpy(), b_[-1].data.cpu().numpy())
     # non-finite inputs and rays parallel to the mirror plane are dropped, finite neighbours unaffected
     n = 130
     b = _bundle(n, 5)
