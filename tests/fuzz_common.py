@@ -114,9 +114,14 @@ def random_scene(seed, n_rays=1500):
     d = float(rng.uniform(60.0, 1200.0))
     S = pos + d * w
     div = float(rng.uniform(0.3, 1.6) * size * max(np.cos(theta), 0.25) / d)
-    B = orc.point_source(S, -w, div, n_rays)
-    # jitter the origins so that they are not all one point (exercises per-ray origins in the transforms)
-    B.point = B.point + rng.normal(scale=0.05 * size, size=B.point.shape)
+    if (seed // 7) % 4 == 3:
+        # collimated beam (parallel rays: the degenerate leading coefficient of the parabola's quadratic, grazing
+        # cylinders, ...), wide enough to overfill the aperture in part of the trials; PlaneWaveDisk emits n - 1 rays
+        B = orc.plane_wave_disk(S, -w, float(rng.uniform(0.3, 1.6) * size), n_rays + 1)
+    else:
+        B = orc.point_source(S, -w, div, n_rays)
+        # jitter the origins so that they are not all one point (exercises per-ray origins in the transforms)
+        B.point = B.point + rng.normal(scale=0.05 * size, size=B.point.shape)
     elements = [e]
     if (seed // (3 * len(KINDS))) % 2 == 1:
         # second optic on the chief ray after the first (if the chief ray survives it)
