@@ -78,8 +78,8 @@ def random_pose(rng, e, pos, towards, theta):
 
 
 def random_scene(seed, n_rays=1500):
-    """One or two optics of random kinds in random poses + a cone of rays aimed at the first.  The second optic (every
-    other block of seeds) sits on the reflected / transmitted chief ray.  Returns (scene, arrays)."""
+    """One to four optics of random kinds in random poses + a bundle of rays aimed at the first; every further optic
+    sits on the reflected / transmitted chief ray of the chain so far.  Returns (scene, arrays)."""
     rng = np.random.default_rng(seed)
     kind = KINDS[seed % len(KINDS)]
     e, size, O = random_optic(rng, kind)
@@ -123,15 +123,18 @@ def random_scene(seed, n_rays=1500):
         # jitter the origins so that they are not all one point (exercises per-ray origins in the transforms)
         B.point = B.point + rng.normal(scale=0.05 * size, size=B.point.shape)
     elements = [e]
-    if (seed // (3 * len(KINDS))) % 2 == 1:
-        # second optic on the chief ray after the first (if the chief ray survives it)
-        chief = orc.make_bundle(S[None, :], -w[None, :], np.array([0]), np.array([np.nan]), None)
-        after = orc.ray_tracing_calculation(chief, orc.elements_from_scene({"elements": [e]}, arrays_extra), IgnoreDefects=True)[0]
-        if len(after) == 1:
-            e2, _, _ = random_optic(rng, KINDS[int(rng.integers(0, len(KINDS)))])
-            pos2 = after.point[0] + float(rng.uniform(50.0, 800.0)) * after.vector[0]
-            random_pose(rng, e2, pos2, -after.vector[0], np.deg2rad(rng.uniform(0.0, 75.0)))
-            elements.append(e2)
+    # further optics on the chief ray (0-3 of them, as long as the chief ray survives): each sits on the ray leaving
+    # the previous one, under a random incidence
+    chief = orc.make_bundle(S[None, :], -w[None, :], np.array([0]), np.array([np.nan]), None)
+    for _ in range((seed // (3 * len(KINDS))) % 4):
+        after = orc.ray_tracing_calculation(chief, orc.elements_from_scene({"elements": elements}, arrays_extra),
+                                            IgnoreDefects=True)[-1]
+        if len(after) != 1:
+            break
+        nxt, _, _ = random_optic(rng, KINDS[int(rng.integers(0, len(KINDS)))])
+        pos_n = after.point[0] + float(rng.uniform(50.0, 800.0)) * after.vector[0]
+        random_pose(rng, nxt, pos_n, -after.vector[0], np.deg2rad(rng.uniform(0.0, 75.0)))
+        elements.append(nxt)
     scene = {"elements": elements, "n_source": n_rays, "IgnoreDefects": not deformed}
     arrays = {"src_point": B.point, "src_vector": B.vector, "src_number": B.number,
               "src_intensity": np.full(n_rays, np.nan), **arrays_extra}
