@@ -354,7 +354,12 @@ def main():
                          "traffic_source": None if tr is None else tr[1] + " (rocprofv3 PMC, bytes per launch)",
                          "kernel": kname,
                          "kernel_ms": kernel_ms, "intersections_per_launch": inter_per_launch,
-                         "algorithmic_bytes_per_intersection": ALGO_BYTES_PER_INTERSECTION},
+                         "algorithmic_bytes_per_intersection": ALGO_BYTES_PER_INTERSECTION,
+                         # what the memory system really delivers: counted bytes / live kernel time.  `frac` above is
+                         # on the ALGORITHMIC 128 B per intersection and can exceed 1 for the fused
+                         # kernel, which reads a ray once per chain instead of once per element.
+                         "hbm_real_GBps": None if tr is None else tr[0] / (kernel_ms * 1e-3) / 1e9,
+                         "hbm_real_frac": None if tr is None else tr[0] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "trace_only_intersections_per_s": inter_per_step_rank / (trace_ms * 1e-3),
             "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
             "gather_to_rank0_ms": gather_ms,
