@@ -175,8 +175,8 @@ def profiled_traffic(kernel, n, mirrors, mode):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rays", type=int, default=10_000_000, help="rays per GPU")
     ap.add_argument("--mirrors", type=int, default=4)
     ap.add_argument("--mode", default=None, choices=[None, "chain", "element"])
