@@ -157,6 +157,10 @@ def main(OpticalChainList, SourceProperties, DetectorOptions, AnalysisOptions, s
                          "should be.")
     else:
         loop = True
+    if loop and len(OpticalChainList) > 1:
+        # the whole loop list in ONE launch (chains that differ only in poses share a device-resident scene table);
+        # run_ART below then finds every chain's result cached
+        moc.trace_chain_list(OpticalChainList)
     for i, chain in enumerate(OpticalChainList):
         print("Optical Chain " + str(i) + "/" + str(len(OpticalChainList)) + " ", end="", flush=True)
         results = run_ART(chain, SourceProperties, DetectorOptions, AnalysisOptions, loop)

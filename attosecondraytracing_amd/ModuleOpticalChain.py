@@ -15,6 +15,21 @@ from . import ModuleSource as msource
 from .bundle import RayBundle
 
 
+def trace_chain_list(chains, **kwargs):
+    """Trace every chain of a list whose cached result is stale in ONE launch (mp.RayTracingCalculationMany) and fill
+    the chains' caches, so that the `get_output_rays()` calls that follow (ARTmain.run_ART, one per chain,
+    ART/ARTmain.py:304-342) find their result ready.  A list as `OEPlacement` returns it -- chains that differ only in
+    poses -- shares one scene table; anything else falls back to one launch per chain."""
+    stale = [ch for ch in chains if ch._cache_key(kwargs) != ch._last_key and getattr(ch, "_program", None) is None]
+    if len(stale) > 1:
+        outs = mp.RayTracingCalculationMany([ch.source_rays for ch in stale], [ch.optical_elements for ch in stale],
+                                            **kwargs)
+        for ch, o in zip(stale, outs):
+            ch._output_rays = o
+            ch._last_key = ch._cache_key(kwargs)
+    return [ch.get_output_rays(**kwargs) for ch in chains]
+
+
 class OpticalChain:
     def __init__(self, source_rays, optical_elements, description="", loop_variable_name=None,
                  loop_variable_value=None):
@@ -25,6 +40,7 @@ class OpticalChain:
         self.loop_variable_value = loop_variable_value
         self._output_rays = None
         self._last_key = None
+        self._program = None
 
     # ------------------------------------------------------------------ properties
     @property
@@ -71,20 +87,46 @@ class OpticalChain:
             raise TypeError("loop_variable_value must be a number of types int or float.")
         self._loop_variable_value = loop_variable_value
 
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_program"] = None          # a captured HIP graph does not travel into an archive
+        return st
+
     # ------------------------------------------------------------------ tracing
     def copy_chain(self):
         return OpticalChain(self.source_rays, self.optical_elements, self.description)
 
+    def _cache_key(self, kwargs):
+        return (hash(self.source_rays), mp._hash_list_of_objects(self.optical_elements), tuple(sorted(kwargs.items())))
+
     def get_output_rays(self, **kwargs):
-        """List of ray bundles after each optical element; recomputed only when something changed."""
-        key = (hash(self.source_rays), mp._hash_list_of_objects(self.optical_elements),
-               tuple(sorted(kwargs.items())))
+        """List of ray bundles after each optical element; recomputed only when something changed.
+
+        A chain that was `compile()`d re-traces by rewriting its device-resident scene table and replaying a captured
+        HIP graph; the bundles it returns are then always the SAME objects (their arrays are overwritten by the next
+        re-trace), which is what makes a pose scan on small bundles GPU-bound instead of launch-bound."""
+        key = self._cache_key(kwargs)
         if key != self._last_key:
-            print("...ray-tracing...", end="", flush=True)
-            self._output_rays = mp.RayTracingCalculation(self.source_rays, self.optical_elements, **kwargs)
-            print("\r\033[K", end="", flush=True)
+            prog = getattr(self, "_program", None)
+            if prog is not None and prog.matches([self.source_rays], [self.optical_elements], kwargs):
+                prog.update([self.optical_elements])
+                self._output_rays = prog.run()[0]
+            else:
+                self._program = None
+                print("...ray-tracing...", end="", flush=True)
+                self._output_rays = mp.RayTracingCalculation(self.source_rays, self.optical_elements, **kwargs)
+                print("\r\033[K", end="", flush=True)
             self._last_key = key
         return self._output_rays
+
+    def compile(self, **kwargs):
+        """Opt in to graph replay for repeated re-traces of this chain with changed poses / source contents (same
+        optics, same ray count): see graph.SceneProgram.  Returns the program."""
+        from .graph import SceneProgram
+        self._program = SceneProgram([self.source_rays], [self.optical_elements], **kwargs)
+        self._output_rays = self._program.run()[0]
+        self._last_key = self._cache_key(kwargs)
+        return self._program
 
     def render(self):
         from . import ModuleAnalysisAndPlots as mplots

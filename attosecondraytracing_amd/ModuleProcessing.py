@@ -107,8 +107,7 @@ def _as_bundle(rays, backend=None):
     return RayBundle.from_ray_list(rays, backend)
 
 
-_CHAIN_MAX = 8          # elements per fused launch (kChainMax in csrc/art_kernels.hip)
-_CHAIN_MAX_DEFECTS = 16  # Zernike defects per fused launch: 64 KiB of LDS / 502 doubles per packed table
+_CHAIN_MAX = 8          # elements per fused launch (kChainMax in csrc/art_scene.h)
 
 
 # ------------------------------------------------------------------------------------------- the hot path
@@ -155,9 +154,6 @@ def RayTracingCalculation(source_rays, optical_elements, IgnoreDefects=True, mod
             b.parent = prev
             b._keepalive = keep
             prev = b
-    if mode == "chain" and any(sum(d.n_defects for d in descs[k0:k0 + _CHAIN_MAX]) > _CHAIN_MAX_DEFECTS
-                               for k0 in range(0, m, _CHAIN_MAX)):
-        mode = "element"    # the Zernike tables of one fused launch would not fit its 64 KiB of LDS
     if mode == "chain":
         views = [b.view() if b is not None else _abi.ArtBundleView() for b in outs]
         if not history and m > _CHAIN_MAX:
@@ -185,6 +181,58 @@ def RayTracingCalculation(source_rays, optical_elements, IgnoreDefects=True, mod
     else:
         raise ValueError("mode must be 'chain' or 'element'")
     return outs
+
+
+def RayTracingCalculationMany(source_rays_list, optical_elements_list, IgnoreDefects=True, history=True):
+    """`RayTracingCalculation` for a LIST of chains in ONE launch (art_trace_scene): what `OEPlacement` returns when one
+    of its arguments is a list -- 10-11 chains that differ only in poses (ART/ModuleProcessing.py:203-239), which the
+    reference's `ARTmain.main` traces one after the other (ARTmain.py:304-342).  The element descriptors of all chains
+    travel as one device-resident scene table; blockIdx.y selects the chain.  Returns one list of bundles per chain,
+    identical to separate calls.  Chains that cannot share a launch (different ray or element counts) are traced one
+    by one -- still on the device."""
+    sources = [_as_bundle(s) for s in source_rays_list]
+    c = len(sources)
+    if c != len(optical_elements_list):
+        raise ValueError("need one element list per source bundle")
+    if c == 0:
+        return []
+    m, n, be = len(optical_elements_list[0]), sources[0].n_slots, sources[0].backend
+    descs, keep = [], []
+    for els in optical_elements_list:
+        for oe in els:
+            d, k = element_descriptor(oe, IgnoreDefects, be)
+            descs.append(d)
+            keep.append(k)
+    uniform = (m > 0 and n > 0 and all(len(els) == m for els in optical_elements_list)
+               and all(s.n_slots == n and s.backend is be for s in sources) and not any(d.nonfinite for d in descs))
+    if c == 1 or not uniform:
+        return [RayTracingCalculation(s, els, IgnoreDefects, None, history)
+                for s, els in zip(sources, optical_elements_list)]
+    if history:
+        grid = RayBundle.allocate_grid(n, c, m, sources, be)
+    else:
+        grid = [[None] * (m - 1) + [RayBundle.allocate(n, like=s, backend=be)] for s in sources]
+    views, scratch = [], []
+    for ci, outs in enumerate(grid):
+        prev = sources[ci]
+        for k, b in enumerate(outs):
+            if b is None and (k + 1) % _CHAIN_MAX == 0:      # hand-over bundle between two fused launches
+                b = RayBundle.allocate(n, like=sources[ci], backend=be)
+                scratch.append(b)
+                views.append(b.view())
+                continue
+            if b is not None:
+                b.parent = prev
+                b._keepalive = (keep, scratch)
+                prev = b
+            views.append(b.view() if b is not None else _abi.ArtBundleView())
+    host, dev = be.scene_alloc(c, m)
+    flags = be.scene_pack(descs, [s.view() for s in sources], views, c, m, host)
+    be.scene_upload(host, dev)
+    be.trace_scene(dev, c, m, flags, n)
+    for outs in grid:
+        outs[-1]._keepalive = (keep, scratch, host, dev)
+    return grid
 
 
 # ------------------------------------------------------------------------------------------- placement

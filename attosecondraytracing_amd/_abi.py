@@ -1,7 +1,7 @@
 """ctypes mirror of include/art_hip.h (structs, enums, prototypes).  Keep in sync with ART_ABI_VERSION."""
 import ctypes as C
 
-ART_ABI_VERSION = 7
+ART_ABI_VERSION = 8
 
 ART_OK = 0
 ART_ERR_BAD_ARG = -1
@@ -76,6 +76,10 @@ PROTOTYPES = {
                                     C.c_int64, C.c_void_p]),
     "art_trace_chain": (C.c_int, [C.POINTER(ArtElementDesc), C.c_int32, C.POINTER(ArtBundleView),
                                   C.POINTER(ArtBundleView), C.c_int64, C.c_void_p]),
+    "art_scene_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
+    "art_scene_pack": (C.c_int, [C.POINTER(ArtElementDesc), C.c_int32, C.c_int32, C.POINTER(ArtBundleView),
+                                 C.POINTER(ArtBundleView), C.c_void_p]),
+    "art_trace_scene": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
     "art_pack_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(ArtBundleView), C.c_void_p]),
     "art_transform_bundle": (C.c_int, [c_double_p, c_double_p, C.c_int32, C.POINTER(ArtBundleView),
                                        C.POINTER(ArtBundleView), C.c_int64, C.c_void_p]),

@@ -106,6 +106,37 @@ class HipBackend:
         self.check(self._timed(lambda: self.fn["art_trace_chain"](darr, m, C.byref(view_in), varr, n, sp)),
                    "art_trace_chain")
 
+    # scene table (include/art_hip.h: art_scene_bytes / art_scene_pack / art_trace_scene): many chains, one launch
+    def scene_alloc(self, n_chains, n_elems):
+        """(pinned host image, device image) uint8 tensors of art_scene_bytes(n_chains, n_elems)."""
+        nb = int(self.fn["art_scene_bytes"](n_chains, n_elems))
+        if nb <= 0:
+            raise ArtError("art_scene_bytes: bad chain or element count")
+        return (torch.empty(nb, dtype=torch.uint8, pin_memory=True),
+                torch.empty(nb, dtype=torch.uint8, device=self.device))
+
+    def scene_pack(self, descs, views_in, views_out, n_chains, n_elems, host_image):
+        """Pack descriptors (flat, chain-major) and views into the host image; returns the scene flags."""
+        darr = (_abi.ArtElementDesc * (n_chains * n_elems))(*descs)
+        iarr = (_abi.ArtBundleView * n_chains)(*views_in)
+        oarr = (_abi.ArtBundleView * (n_chains * n_elems))(*views_out)
+        rc = self.fn["art_scene_pack"](darr, n_chains, n_elems, iarr, oarr, host_image.data_ptr())
+        if rc < 0:
+            self.check(rc, "art_scene_pack")
+        return rc
+
+    def scene_upload(self, host_image, dev_image):
+        """Host image -> device image on the current stream; returns an event the host waits for before it re-packs."""
+        dev_image.copy_(host_image, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
+
+    def trace_scene(self, dev_image, n_chains, n_elems, flags, n):
+        sp = self.stream_ptr()
+        self.check(self._timed(lambda: self.fn["art_trace_scene"](dev_image.data_ptr(), n_chains, n_elems, flags, n, sp)),
+                   "art_trace_scene")
+
     def pack_rays(self, points, vectors, path0, n, view):
         self.check(self.fn["art_pack_rays"](points.data_ptr(), vectors.data_ptr(),
                                             None if path0 is None else path0.data_ptr(), n, C.byref(view),
@@ -126,16 +157,16 @@ class HipBackend:
 
     def detector_readout(self, ddesc, view, w, n, centres=(0.0, 0.0, 0.0), p3=None, XY=None, opl=None, to_host=True):
         """Fused read-out + statistics (art_detector_readout); returns the 24 statistics."""
-        out = self.zeros(24) if n == 0 else self.empty(24)
-        if n > 0:
-            p = [t.data_ptr() for t in p3] if p3 is not None else [None, None, None]
-            xy = [t.data_ptr() for t in XY] if XY is not None else [None, None]
-            self.check(self.fn["art_detector_readout"](C.byref(ddesc), C.byref(view), None if w is None else w.data_ptr(),
-                                                       n, float(centres[0]), float(centres[1]), float(centres[2]),
-                                                       p[0], p[1], p[2], xy[0], xy[1],
-                                                       None if opl is None else opl.data_ptr(),
-                                                       self._red_scratch().data_ptr(), out.data_ptr(),
-                                                       self.stream_ptr()), "art_detector_readout")
+        out = self.empty(24)      # n == 0: the library writes the reduction identities (0, +inf, -inf)
+        p = [t.data_ptr() for t in p3] if (p3 is not None and n > 0) else [None, None, None]
+        xy = [t.data_ptr() for t in XY] if (XY is not None and n > 0) else [None, None]
+        self.check(self.fn["art_detector_readout"](C.byref(ddesc), C.byref(view),
+                                                   None if (w is None or n == 0) else w.data_ptr(),
+                                                   n, float(centres[0]), float(centres[1]), float(centres[2]),
+                                                   p[0], p[1], p[2], xy[0], xy[1],
+                                                   None if (opl is None or n == 0) else opl.data_ptr(),
+                                                   self._red_scratch().data_ptr(), out.data_ptr(),
+                                                   self.stream_ptr()), "art_detector_readout")
         return out.cpu().numpy() if to_host else out
 
     def detector_scan_moments(self, ddesc, view, w, n, co, span=0.0):
@@ -154,11 +185,10 @@ class HipBackend:
         return self.scratch("red", self.fn["art_reduce_scratch_doubles"](), torch.float64)
 
     def detector_stats(self, alive, X, Y, opl, w, n, to_host=True):
+        out = self.empty(16)      # n == 0: one workgroup with nothing to add leaves the reduction identities
+        ptr = lambda t: None if (t is None or n == 0) else t.data_ptr()
         if n == 0:
-            out = self.zeros(16)
-            return out.cpu().numpy() if to_host else out
-        out = self.empty(16)
-        ptr = lambda t: None if t is None else t.data_ptr()
+            alive = self.zeros(1, torch.uint8)
         self.check(self.fn["art_detector_stats"](alive.data_ptr(), ptr(X), ptr(Y), ptr(opl), ptr(w), n,
                                                  self._red_scratch().data_ptr(), out.data_ptr(), self.stream_ptr()),
                    "art_detector_stats")

@@ -7,6 +7,8 @@ stays fixed along a chain: slot i of every bundle is source ray i, so `number`, 
 `wavelength` are shared, not copied.  The list-of-survivors view the reference API exposes
 (`len()`, indexing, iteration in source order) is produced lazily by a stable device compaction."""
 
+import os
+
 import numpy as np
 import torch
 
@@ -77,7 +79,9 @@ class RayBundle:
     # measured 0.33 ms instead of 0.24 ms per 1e7-ray element trace.
     @staticmethod
     def _pitch(n, unit=64):
-        return max(unit, -(-int(n) // unit) * unit)
+        # ART_PITCH_EXTRA (diagnostic, multiples of 512 B): extra padding per row, to move the rows of a block against
+        # each other in the HBM channel interleave (measured: no effect)
+        return max(unit, -(-int(n) // unit) * unit) + unit * int(os.environ.get("ART_PITCH_EXTRA", "0"))
 
     @classmethod
     def _rows(cls, n, device, count=None):
@@ -87,8 +91,9 @@ class RayBundle:
         if count is None:
             return (torch.empty((8, pd), dtype=torch.float64, device=device)[:, :n],
                     torch.empty(pa, dtype=torch.uint8, device=device)[:n])
-        return (torch.empty((count, 8, pd), dtype=torch.float64, device=device)[:, :, :n],
-                torch.empty((count, pa), dtype=torch.uint8, device=device)[:, :n])
+        lead = tuple(count) if isinstance(count, (tuple, list)) else (count,)
+        return (torch.empty(lead + (8, pd), dtype=torch.float64, device=device)[..., :n],
+                torch.empty(lead + (pa,), dtype=torch.uint8, device=device)[..., :n])
 
     @classmethod
     def allocate(cls, n, like=None, backend=None):
@@ -105,6 +110,14 @@ class RayBundle:
         be = backend or like.backend
         data, alive = cls._rows(n, be.device, count)
         return [cls(data[k], alive[k], like.number, like.intensity, like.wavelength, like, be) for k in range(count)]
+
+    @classmethod
+    def allocate_grid(cls, n, chains, count, likes, backend=None):
+        """[chains][count] bundles out of two allocations: the histories of a list of chains traced in one launch."""
+        be = backend or likes[0].backend
+        data, alive = cls._rows(n, be.device, (chains, count))
+        return [[cls(data[c, k], alive[c, k], likes[c].number, likes[c].intensity, likes[c].wavelength, likes[c], be)
+                 for k in range(count)] for c in range(chains)]
 
     @classmethod
     def from_arrays(cls, point, vector, number=None, intensity=None, wavelength=None, path0=None, backend=None):

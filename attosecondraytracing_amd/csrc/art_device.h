@@ -201,95 +201,70 @@ ART_HD int quadratic_roots(double a, double b, double c, double& t1, double& t2)
 // Zernike defects (ART/ModuleDefects.py:149-174; polynomials of ART/recursive_zernike_generator.py:35-254).
 // The host expands the summed surface into monomials (exact: the recurrences have integer coefficients) and hands
 // over the polynomial and its two partial derivatives as dense [p][q] tables (layout: art_hip.h).  Per ray this is a
-// bivariate Horner scheme whose coefficients every lane reads from the same LDS address (broadcast, conflict-free).
-// A Horner chain is one dependent LDS read + FMA per coefficient, i.e. latency-bound; so the kernels re-pack the
-// tables, once per workgroup while staging them in LDS, into the order the scheme consumes them -- row m (p = deg - m)
-// as A[p][m], .., A[p][0] -- with every row padded IN FRONT with zeros to a multiple of 4 (a leading zero leaves a
-// Horner chain unchanged): the inner loop then fetches 4 coefficients with two 16-byte reads and runs 4 FMAs per
-// LDS round trip, without any per-coefficient control flow.
+// bivariate Horner scheme: row p (the coefficient of x^p) is a polynomial in y, the rows are folded by a Horner
+// scheme in x.
 //
-// Packed table of one defect (ART_ZPACK_STRIDE doubles, 16-byte aligned parts): [0] R, [1] N, then h (ART_ZPACK_T0
-// slots), dh/dx and dh/dy (ART_ZPACK_T1 slots each).
-ART_HD constexpr int zpack_rows_size(int deg) {      // sum over rows m = 0..deg of (m + 1) rounded up to 4
-  int t = 0;
-  for (int m = 0; m <= deg; ++m) t += ((m + 1 + 3) / 4) * 4;
-  return t;
+// Coefficients are the same for every ray, i.e. WAVE-UNIFORM.  The evaluators are specialised at compile time per
+// order bucket (NMAX = 4, 8, 12, 16; a table of order N runs in the smallest bucket >= N, the entries of degree > N
+// are zero and a leading zero leaves a Horner chain unchanged bit for bit), fully unrolled, and read the table
+// through a pointer type chosen by the caller:
+//   * `zuni_t` (device default): the constant address space -> scalar loads (s_load_dwordx2..x16 through the scalar
+//     cache) into SGPRs, one copy per WAVE; v_fma_f64 takes the coefficient as its scalar operand.  No LDS, no
+//     staging pass, no barrier; the unrolled rows are independent dependency chains the scheduler interleaves.
+//   * a plain pointer into LDS (-DART_ZERN_LDS, kept for the comparison recorded in DESIGN.md): the dense tables are
+//     staged once per workgroup and every lane reads the same LDS address (broadcast) -- 64 copies per wave of every
+//     coefficient through the LDS pipe, which is what bounded the order-16 surface in round 1.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ART_ZERN_LDS)
+typedef const double __attribute__((address_space(4)))* zuni_t;
+#define ART_ZUNI(p) ((art::zuni_t)(p))
+// a * b + c with c wave-uniform: the VOP3 form with the coefficient as its one scalar operand.  Left to itself the
+// compiler selects the two-address v_fmac_f64 (d += a * b), whose addend must sit in a VGPR, and copies every
+// coefficient there first -- two v_mov_b32 per FMA, i.e. three times the VALU work, and 288 VGPRs of live copies.
+__device__ __forceinline__ double fma_uc(double a, double b, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+  return d;
 }
-#define ART_ZPACK_T0 (art::zpack_rows_size(ART_ZERN_MAX_ORDER))          /* 180 */
-#define ART_ZPACK_T1 (art::zpack_rows_size(ART_ZERN_MAX_ORDER - 1))      /* 160 */
-#define ART_ZPACK_STRIDE (2 + ART_ZPACK_T0 + 2 * ART_ZPACK_T1)           /* 502, even */
+#else
+typedef const double* zuni_t;
+#define ART_ZUNI(p) (p)
+ART_HD double fma_uc(double a, double b, double c) { return fma(a, b, c); }
+#endif
 
-// dense entry j (0 .. 3*DIM^2-1) of a defect table -> slot in the packed table, or -1 if its degree exceeds N
-ART_HD int zern_pack_slot(int N, int j) {
-  const int poly = j / (ART_ZERN_DIM * ART_ZERN_DIM), rem = j - poly * ART_ZERN_DIM * ART_ZERN_DIM;
-  const int p = rem / ART_ZERN_DIM, q = rem - p * ART_ZERN_DIM;
-  const int deg = (poly == 0) ? N : N - 1;
-  if (p + q > deg) return -1;
-  const int m = deg - p;
-  int off = 0;
-  for (int r = 0; r < m; ++r) off += ((r + 1 + 3) / 4) * 4;
-  const int lead = ((m + 1 + 3) / 4) * 4 - (m + 1);              // zeros in front of row m
-  const int base = 2 + (poly == 0 ? 0 : ART_ZPACK_T0 + (poly - 1) * ART_ZPACK_T1);
-  return base + off + lead + (m - q);
-}
+#define ART_ZPOLY (ART_ZERN_DIM * ART_ZERN_DIM)   /* doubles per dense polynomial table */
 
-// stage one defect: dense table `src` (ART_ZERN_STRIDE doubles) -> packed table `dst` (ART_ZPACK_STRIDE doubles,
-// zero-filled first); called by every thread of the workgroup with its index (host twin: tid = 0, nthreads = 1).
-// The caller synchronises the workgroup between zern_pack_clear and zern_pack.
-ART_HD void zern_pack_clear(double* dst, int tid, int nthreads) {
-  for (int j = tid; j < ART_ZPACK_STRIDE; j += nthreads) dst[j] = 0.0;
-}
-ART_HD void zern_pack(const double* src, double* dst, int tid, int nthreads) {
-  const int N = (int)src[1];
-  if (tid == 0) { dst[0] = src[0]; dst[1] = src[1]; }
-  for (int j = tid; j < 3 * ART_ZERN_DIM * ART_ZERN_DIM; j += nthreads) {
-    const int slot = zern_pack_slot(N, j);
-    if (slot >= 0) dst[slot] = src[2 + j];
-  }
-}
-
-struct Coef4 { double a, b, c, d; };
-ART_HD Coef4 ld_coef4(const double* P) {      // P is 16-byte aligned: two 128-bit LDS reads on the device
-  Coef4 v;
-  v.a = P[0]; v.b = P[1]; v.c = P[2]; v.d = P[3];
-  return v;
-}
+ART_HD constexpr int zern_bucket(int N) { return N <= 4 ? 4 : (N <= 8 ? 8 : (N <= 12 ? 12 : 16)); }
 
 // h = get_offset (:168-174)
-ART_HD double zernike_offset(const double* tab, double px, double py) {
+template <int NMAX, typename TP>
+ART_HD double zernike_offset_t(TP tab, double px, double py) {
   const double iR = rcp_full(tab[0]);
-  const int N = (int)tab[1];
   const double x = px * iR, y = py * iR;
-  const double* P = tab + 2;
   double acc = 0.0;
-  for (int m = 0; m <= N; ++m) {
-    double in = 0.0;
-    for (int g = 0; g < m + 1; g += 4) {
-      const Coef4 c = ld_coef4(P);
-      P += 4;
-      in = fma(fma(fma(fma(in, y, c.a), y, c.b), y, c.c), y, c.d);
-    }
+#pragma unroll
+  for (int p = NMAX; p >= 0; --p) {
+    double in = tab[2 + p * ART_ZERN_DIM + NMAX - p];
+#pragma unroll
+    for (int q = NMAX - p - 1; q >= 0; --q) in = fma_uc(in, y, tab[2 + p * ART_ZERN_DIM + q]);
     acc = fma(acc, x, in);
   }
   return acc;
 }
 
-// (gX, gY): get_normal (:159-166) returns (-gX, -gY, 1)
-ART_HD void zernike_slopes(const double* tab, double px, double py, double& gX, double& gY) {
+// (gX, gY): get_normal (:159-166) returns (-gX, -gY, 1); both derivative polynomials (degree N-1) in one pass
+template <int NMAX, typename TP>
+ART_HD void zernike_slopes_t(TP tab, double px, double py, double& gX, double& gY) {
   const double iR = rcp_full(tab[0]);
-  const int M = (int)tab[1] - 1;
   const double x = px * iR, y = py * iR;
-  // both derivative polynomials in one pass (two independent Horner chains), degree N-1
-  const double* PX = tab + 2 + ART_ZPACK_T0;
-  const double* PY = PX + ART_ZPACK_T1;
   double ax = 0.0, ay = 0.0;
-  for (int m = 0; m <= M; ++m) {
-    double ix = 0.0, iy = 0.0;
-    for (int g = 0; g < m + 1; g += 4) {
-      const Coef4 cx = ld_coef4(PX), cy = ld_coef4(PY);
-      PX += 4; PY += 4;
-      ix = fma(fma(fma(fma(ix, y, cx.a), y, cx.b), y, cx.c), y, cx.d);
-      iy = fma(fma(fma(fma(iy, y, cy.a), y, cy.b), y, cy.c), y, cy.d);
+#pragma unroll
+  for (int p = NMAX - 1; p >= 0; --p) {
+    double ix = tab[2 + ART_ZPOLY + p * ART_ZERN_DIM + NMAX - 1 - p];
+    double iy = tab[2 + 2 * ART_ZPOLY + p * ART_ZERN_DIM + NMAX - 1 - p];
+#pragma unroll
+    for (int q = NMAX - 2 - p; q >= 0; --q) {
+      ix = fma_uc(ix, y, tab[2 + ART_ZPOLY + p * ART_ZERN_DIM + q]);
+      iy = fma_uc(iy, y, tab[2 + 2 * ART_ZPOLY + p * ART_ZERN_DIM + q]);
     }
     ax = fma(ax, x, ix);
     ay = fma(ay, x, iy);
@@ -298,12 +273,35 @@ ART_HD void zernike_slopes(const double* tab, double px, double py, double& gX, 
   gY = ay * iR;
 }
 
+// bucket dispatch on the table's order (wave-uniform branch)
+template <typename TP>
+ART_HD double zernike_offset(TP tab, double px, double py) {
+  const int N = (int)tab[1];
+  if (N <= 4) return zernike_offset_t<4>(tab, px, py);
+  if (N <= 8) return zernike_offset_t<8>(tab, px, py);
+  if (N <= 12) return zernike_offset_t<12>(tab, px, py);
+  return zernike_offset_t<16>(tab, px, py);
+}
+template <typename TP>
+ART_HD void zernike_slopes(TP tab, double px, double py, double& gX, double& gY) {
+  const int N = (int)tab[1];
+  if (N <= 4) return zernike_slopes_t<4>(tab, px, py, gX, gY);
+  if (N <= 8) return zernike_slopes_t<8>(tab, px, py, gX, gY);
+  if (N <= 12) return zernike_slopes_t<12>(tab, px, py, gX, gY);
+  return zernike_slopes_t<16>(tab, px, py, gX, gY);
+}
+
 // Gridded height map: bilinear lookup (ART/ModuleDefects.py:131-137; SciPy RegularGridInterpolator, linear)
 ART_HD double grid_offset(const ArtGridDefect& g, double px, double py) {
-  const double fx = (px - g.x0) / g.dx, fy = (py - g.y0) / g.dy;
-  int ix = (int)floor(fx), iy = (int)floor(fy);
-  ix = ix < 0 ? 0 : (ix > g.nx - 2 ? g.nx - 2 : ix);
-  iy = iy < 0 ? 0 : (iy > g.ny - 2 ? g.ny - 2 : iy);
+  // Cell coordinates clamped to the grid BEFORE the integer conversion (a NaN or huge coordinate must not reach the
+  // cast; fmin/fmax drop a NaN): a point outside the map reads the edge value.  Hits lie inside the mirror's support,
+  // which the map covers -- the host shell refuses a map that does not (the reference's interpolator raises for such
+  // a point, ART/ModuleDefects.py:108-110).
+  const double fx = fmin(fmax((px - g.x0) / g.dx, 0.0), (double)(g.nx - 1));
+  const double fy = fmin(fmax((py - g.y0) / g.dy, 0.0), (double)(g.ny - 1));
+  int ix = (int)fx, iy = (int)fy;
+  ix = ix > g.nx - 2 ? g.nx - 2 : ix;
+  iy = iy > g.ny - 2 ? g.ny - 2 : iy;
   const double tx = fx - (double)ix, ty = fy - (double)iy;
   const double* r0 = g.h + (int64_t)ix * g.ny + iy;
   const double* r1 = r0 + g.ny;
@@ -549,6 +547,8 @@ inline void prepare_element(ArtElementDesc& e) {
 // ---------------------------------------------------------------------------------------------------------
 // One element acting on one ray (ART/ModuleProcessing.py:284-311 for a single ray).
 // Returns false when the ray is lost (missed the optic / blocked by the mask).
+// `zern`: the element's dense Zernike tables (n_defects x ART_ZERN_STRIDE doubles) -- e.zern itself (device memory,
+// read through scalar loads) or, in the -DART_ZERN_LDS build, their copy in LDS.
 template <int KIND, bool DEFECT>
 ART_HD bool trace_ray(const ArtElementDesc& e, const double* zern, Ray& r) {
   // lab -> optic frame (:289-295)
@@ -578,7 +578,7 @@ ART_HD bool trace_ray(const ArtElementDesc& e, const double* zern, Ray& r) {
       // h / cos(alpha), h = summed defect offsets at (P - centre), alpha = angle(-u, base normal)
       double h = 0.0;
       for (int d = 0; d < e.n_defects; ++d)
-        h += zernike_offset(zern + d * ART_ZPACK_STRIDE, Px - e.centre[0], Py - e.centre[1]);
+        h += zernike_offset(ART_ZUNI(zern + d * ART_ZERN_STRIDE), Px - e.centre[0], Py - e.centre[1]);
       for (int d = 0; d < e.n_grid; ++d) h += grid_offset(e.grid[d], Px - e.centre[0], Py - e.centre[1]);
       const double cosa = -dot3(ux, uy, uz, nx, ny, nz);
       const double s = div_full(h, cosa);
@@ -592,7 +592,7 @@ ART_HD bool trace_ray(const ArtElementDesc& e, const double* zern, Ray& r) {
         double gXs = -nx * inz, gYs = -ny * inz;
         for (int d = 0; d < e.n_defects; ++d) {
           double gX, gY;
-          zernike_slopes(zern + d * ART_ZPACK_STRIDE, Px - e.centre[0], Py - e.centre[1], gX, gY);
+          zernike_slopes(ART_ZUNI(zern + d * ART_ZERN_STRIDE), Px - e.centre[0], Py - e.centre[1], gX, gY);
           gXs += gX; gYs += gY;
         }
         const double inv = rsqrt_full(fma(gXs, gXs, fma(gYs, gYs, 1.0)));

@@ -2,8 +2,9 @@
 //
 // One ray per lane, SoA fp64 streams read and written with coalesced, non-temporal 8-byte accesses (64 lanes x
 // 8 B = 512 B per wave instruction and per array; 16 B per lane in the read-out), element descriptors in kernel
-// arguments (scalar loads -> SGPRs, broadcast for free), Zernike coefficient tables staged once per workgroup in
-// LDS, wavefront ballot on the torus Newton loop.  No MFMA: the path is streaming fp64 VALU work against HBM.
+// arguments or in a device-resident scene table (either way scalar loads -> SGPRs, broadcast for free), Zernike
+// coefficient tables read through the scalar cache as well (wave-uniform; -DART_ZERN_LDS stages them in LDS instead),
+// wavefront ballot on the torus Newton loop.  No MFMA: the path is streaming fp64 VALU work against HBM.
 #include <hip/hip_runtime.h>
 
 #include <math.h>
@@ -12,6 +13,7 @@
 #include <string.h>
 
 #include "art_device.h"
+#include "art_scene.h"
 
 namespace {
 
@@ -19,7 +21,6 @@ constexpr int kBlock = 256;          // 4 waves per workgroup
 constexpr int kMaxBlocks = 256 * 8;  // reductions: 256 CUs x 8 workgroups, grid-stride beyond that (one partial each)
 constexpr int kReadoutBlocks = kMaxBlocks;  // fused read-out: persistent workgroups -- every workgroup ends with a 24-slot
                                            // reduction, so MORE workgroups cost more (16384: 244 us instead of 176 us)
-constexpr int kChainMax = 8;         // elements per fused launch (kernel-argument budget)
 
 thread_local char g_err[512] = "";
 
@@ -81,13 +82,14 @@ struct BundleRsrc {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)bytes, 0x00020000);
 }
-__device__ __forceinline__ BundleRsrc make_rsrc(const ArtBundleView& v, int64_t n) {
+// descriptors of the n slots [first, first + n) of a view
+__device__ __forceinline__ BundleRsrc make_rsrc(const ArtBundleView& v, int64_t n, int64_t first = 0) {
   const unsigned b8 = (unsigned)(n * 8), b1 = (unsigned)n;
   BundleRsrc r;
-  r.ox = rsrc_of(v.ox, b8); r.oy = rsrc_of(v.oy, b8); r.oz = rsrc_of(v.oz, b8);
-  r.dx = rsrc_of(v.dx, b8); r.dy = rsrc_of(v.dy, b8); r.dz = rsrc_of(v.dz, b8);
-  r.path = rsrc_of(v.path, b8); r.inc = rsrc_of(v.incidence, b8);
-  r.alive = rsrc_of(v.alive, b1);
+  r.ox = rsrc_of(v.ox + first, b8); r.oy = rsrc_of(v.oy + first, b8); r.oz = rsrc_of(v.oz + first, b8);
+  r.dx = rsrc_of(v.dx + first, b8); r.dy = rsrc_of(v.dy + first, b8); r.dz = rsrc_of(v.dz + first, b8);
+  r.path = rsrc_of(v.path + first, b8); r.inc = rsrc_of(v.incidence + first, b8);
+  r.alive = rsrc_of(v.alive + first, b1);
   return r;
 }
 __device__ __forceinline__ double ld_f64(__amdgpu_buffer_rsrc_t rs, unsigned off) {
@@ -160,23 +162,33 @@ struct ElemArg {
   ArtElementDesc e[1];
 };
 
+#ifdef ART_ZERN_LDS
+// Comparison build: the dense Zernike tables are staged in LDS once per workgroup and read by every
+// lane from the same address, instead of travelling through the scalar cache.  To amortise the staging these kernels
+// keep a persistent grid + loop, as in round 1.
+constexpr bool kDefectLoop = true;
+__device__ __forceinline__ void stage_tables(const double* src, double* dst, int doubles) {
+  for (int j = threadIdx.x; j < doubles; j += kBlock) dst[j] = src[j];
+}
+#else
+constexpr bool kDefectLoop = false;
+#endif
+
+// One ray per thread (grid_stream), no loop.  Slots beyond n fall outside every descriptor: their loads return 0
+// (alive = 0) and their stores are dropped, so the tail needs no branch.
 template <int KIND, bool DEFECT>
 __global__ __launch_bounds__(kBlock) void k_trace_element(const ElemArg ea, const ArtBundleView in,
                                                           const ArtBundleView out, const int64_t n) {
   const ArtElementDesc& e = ea.e[blockIdx.y];
-  __shared__ __attribute__((aligned(16))) double s_zern[DEFECT ? ART_MAX_DEFECTS * ART_ZPACK_STRIDE : 2];
-  const double* zern = nullptr;
-  if (DEFECT) {   // dense caller tables -> packed, row-padded Horner-order tables in LDS (art_device.h)
-    for (int d = 0; d < e.n_defects; ++d) art::zern_pack_clear(s_zern + d * ART_ZPACK_STRIDE, threadIdx.x, kBlock);
-    __syncthreads();
-    for (int d = 0; d < e.n_defects; ++d)
-      art::zern_pack(e.zern + d * ART_ZERN_STRIDE, s_zern + d * ART_ZPACK_STRIDE, threadIdx.x, kBlock);
+  const double* zern = e.zern;
+#ifdef ART_ZERN_LDS
+  __shared__ double s_zern[DEFECT ? ART_MAX_DEFECTS * ART_ZERN_STRIDE : 2];
+  if (DEFECT) {
+    stage_tables(e.zern, s_zern, e.n_defects * ART_ZERN_STRIDE);
     __syncthreads();
     zern = s_zern;
   }
-  // Without defects: one ray per thread (grid_stream), no loop.  Slots beyond n fall outside every descriptor: their
-  // loads return 0 (alive = 0) and their stores are dropped, so the tail needs no branch.  With defects the
-  // workgroup has just staged its tables in LDS, which is worth amortising: persistent grid (grid_for) + loop.
+#endif
   const BundleRsrc bi = make_rsrc(in, n), bo = make_rsrc(out, n);
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -193,57 +205,112 @@ __global__ __launch_bounds__(kBlock) void k_trace_element(const ElemArg ea, cons
 #endif
     store_slot(bo, i, r, ok);
     i += stride;
-  } while (DEFECT && i < n);
+  } while (DEFECT && kDefectLoop && i < n);
 }
 
-struct ChainArgs {
-  ArtElementDesc e[kChainMax];
-  ArtBundleView out[kChainMax];
-  int32_t zoff[kChainMax];  // offset (doubles) of element k's Zernike table in dynamic LDS
-  int32_t n_elems;
-  int32_t zern_doubles;     // total dynamic LDS doubles (0 when no element carries defects)
-};
+using art::ChainArgs;
+using art::kChainMax;
 
-// whole chain, ray resident in registers; history written for every element whose view is non-null
-template <bool DEFECT, int WAVES>
-__global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain(const ChainArgs a, const ArtBundleView in, const int64_t n) {
-  extern __shared__ __attribute__((aligned(16))) double s_zern[];  // packed Zernike tables of all elements, staged once per workgroup
+#ifdef ART_STORE_LDS4
+// Experiment: the 8 fp64 outputs of an element go through LDS so that every wave instruction
+// stores 16 B per lane = 1 KiB of ONE stream (wave w owns streams 2w and 2w+1 of the workgroup's 256 rays) instead of
+// 8 B per lane = 512 B.  Dead rays' slots receive unspecified values (their alive byte is 0).
+__device__ __forceinline__ void store_tile_lds4(const ArtBundleView& v, const int64_t n, const int64_t first,
+                                                const int64_t tile0, const art::Ray& r, const bool ok,
+                                                double (*s_out)[kBlock]) {
+  const int t = threadIdx.x;
+  s_out[0][t] = r.ox; s_out[1][t] = r.oy; s_out[2][t] = r.oz;
+  s_out[3][t] = r.dx; s_out[4][t] = r.dy; s_out[5][t] = r.dz;
+  s_out[6][t] = r.path; s_out[7][t] = r.inc;
+  const unsigned nb = (unsigned)(v.alive != nullptr ? n : 0);
+  __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(ok ? 1 : 0), rsrc_of(v.alive + first, nb), (int)(unsigned)(tile0 + t), 0,
+                                       ART_ST_AUX);
+  __syncthreads();
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;
+  double* const* rows = &v.ox;   // ox, oy, oz, dx, dy, dz, path, incidence are consecutive pointers
+#pragma unroll
+  for (int js = 0; js < 2; ++js) {
+    const int j = 2 * w + js;
+    const __amdgpu_buffer_rsrc_t rs = rsrc_of(rows[j] + first, nb * 8u);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int s0 = h * 128 + 2 * l;
+      st_2f64(rs, (unsigned)(tile0 + s0) * 8u, s_out[j][s0], s_out[j][s0 + 1]);
+    }
+  }
+  __syncthreads();
+}
+#endif
+
+// Whole chain with the ray resident in registers; history written for every element whose view is non-null.
+// `a` lives in kernel arguments (k_trace_chain) or in the device-resident scene table (k_trace_scene): either way
+// its fields are wave-uniform and fetched by scalar loads where they are used.  Rays [first, first + n) of every view.
+template <bool DEFECT>
+__device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t first, const int64_t n, double* s_zern) {
+#ifdef ART_ZERN_LDS
   if (DEFECT) {
-    for (int j = threadIdx.x; j < a.zern_doubles; j += kBlock) s_zern[j] = 0.0;
-    __syncthreads();
-    for (int k = 0; k < a.n_elems; ++k)
-      for (int d = 0; d < a.e[k].n_defects; ++d)
-        art::zern_pack(a.e[k].zern + d * ART_ZERN_STRIDE, s_zern + a.zoff[k] + d * ART_ZPACK_STRIDE, threadIdx.x, kBlock);
+    int off = 0;
+    for (int k = 0; k < a.n_elems; ++k) {
+      stage_tables(a.e[k].zern, s_zern + off, a.e[k].n_defects * ART_ZERN_STRIDE);
+      off += a.e[k].n_defects * ART_ZERN_STRIDE;
+    }
     __syncthreads();
   }
-  // Without defects: one ray per thread (grid_stream), no loop; slots beyond n fall outside every descriptor (loads
-  // return 0 = dead, stores are dropped).  With defects: persistent grid + loop, to amortise the LDS staging above.
-  const BundleRsrc bi = make_rsrc(in, n);
+#endif
+#ifdef ART_STORE_LDS4
+  __shared__ __attribute__((aligned(16))) double s_out[8][kBlock];
+#endif
+#ifdef ART_XCD_REMAP
+  // experiment: workgroups are dealt round-robin to the 8 XCDs; give every XCD one contiguous eighth of the tiles
+  const int64_t per_xcd = ((int64_t)gridDim.x + 7) / 8;
+  const int64_t tile = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+#else
+  const int64_t tile = blockIdx.x;
+#endif
+  const BundleRsrc bi = make_rsrc(a.in, n, first);
   const int64_t stride = (int64_t)gridDim.x * kBlock;
-  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  art::Ray r;
-  r.inc = 0.0;
-  uint8_t al;
-  load_slot(bi, i, r, al);
+  int64_t i = tile * kBlock + threadIdx.x;
   do {
-    art::Ray rn;     // persistent (DEFECT) form: the next slot's inputs are in flight while this ray is traced
-    rn.inc = 0.0;
-    uint8_t an = 0;
-    if (DEFECT) load_slot(bi, i + stride, rn, an);
+    art::Ray r;
+    r.inc = 0.0;
+    uint8_t al;
+    load_slot(bi, i, r, al);
     bool ok = al != 0;
+    const double* zk = s_zern;
     for (int k = 0; k < a.n_elems; ++k) {
 #ifdef ART_DIAG_NOCOMPUTE
       r.path += a.e[k].mp[0];
 #else
-      if (ok) ok = art::trace_ray_dyn<DEFECT>(a.e[k], s_zern + a.zoff[k], r);
+#ifdef ART_ZERN_LDS
+      if (ok) ok = art::trace_ray_dyn<DEFECT>(a.e[k], zk, r);
+      zk += a.e[k].n_defects * ART_ZERN_STRIDE;
+#else
+      if (ok) ok = art::trace_ray_dyn<DEFECT>(a.e[k], a.e[k].zern, r);
 #endif
+#endif
+#ifdef ART_STORE_LDS4
+      store_tile_lds4(a.out[k], n, first, tile * kBlock, r, ok, s_out);
+#else
       // no history view for this element -> zero-length descriptors: every store is dropped by the range check
-      store_slot(make_rsrc(a.out[k], a.out[k].alive != nullptr ? n : 0), i, r, ok);
+      store_slot(make_rsrc(a.out[k], a.out[k].alive != nullptr ? n : 0, first), i, r, ok);
+#endif
     }
-    r = rn;
-    al = an;
     i += stride;
-  } while (DEFECT && i < n);
+  } while (DEFECT && kDefectLoop && i < n);
+}
+
+template <bool DEFECT, int WAVES>
+__global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain(const ChainArgs a, const int64_t n) {
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];   // used by the -DART_ZERN_LDS build only
+  chain_body<DEFECT>(a, 0, n, s_dyn);
+}
+
+// Many chains in one launch: blockIdx.y = chain, descriptors in the device-resident scene table (art_scene.h).
+template <bool DEFECT, int WAVES>
+__global__ __launch_bounds__(kBlock, WAVES) void k_trace_scene(const ChainArgs* __restrict__ tab, const int64_t first,
+                                                               const int64_t n) {
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  chain_body<DEFECT>(tab[blockIdx.y], first, n, s_dyn);
 }
 
 // ------------------------------------------------------------------------------------------- AoS -> SoA
@@ -746,7 +813,8 @@ void launch_element(const ArtElementDesc& e, const ArtBundleView& in, const ArtB
   ElemArg ea;
   ea.e[0] = e;
   if (e.n_defects > 0 || e.n_grid > 0)
-    hipLaunchKernelGGL((k_trace_element<KIND, true>), dim3(grid_for(n)), dim3(kBlock), 0, s, ea, in, out, n);
+    hipLaunchKernelGGL((k_trace_element<KIND, true>), dim3(kDefectLoop ? grid_for(n) : grid_stream(n)), dim3(kBlock), 0,
+                       s, ea, in, out, n);
   else
     hipLaunchKernelGGL((k_trace_element<KIND, false>), dim3(grid_stream(n)), dim3(kBlock), 0, s, ea, in, out, n);
 }
@@ -804,6 +872,24 @@ int art_trace_element(const ArtElementDesc* e, const ArtBundleView* in, const Ar
   return ART_OK;
 }
 
+// launch one segment (<= 8 elements) of one or many chains
+namespace {
+#ifdef ART_ZERN_LDS
+inline size_t zern_lds_bytes(const ChainArgs& a) {
+  size_t d = 0;
+  for (int k = 0; k < a.n_elems; ++k) d += (size_t)a.e[k].n_defects;
+  return d * ART_ZERN_STRIDE * sizeof(double);
+}
+#endif
+// register budget of the fused kernel in waves per SIMD: 5 (96 VGPRs, no spills) measures 2.5 % faster than 4
+// (98 VGPRs, which the allocation granule rounds to 104 = 4 waves); 6 needs 12 spilled registers and is 20 % slower.
+// ART_CHAIN_WAVES=4 selects the other build for comparison.
+inline int chain_waves() {
+  const char* wv = getenv("ART_CHAIN_WAVES");
+  return wv ? atoi(wv) : 5;
+}
+}  // namespace
+
 int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundleView* in, const ArtBundleView* outs,
                     int64_t n, void* stream) {
   if (!elems || !outs || n_elems <= 0) return fail(ART_ERR_BAD_ARG, "empty chain");
@@ -823,11 +909,7 @@ int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundl
     // the chunk's last bundle is the next chunk's input: it must exist
     if (!view_ok(&outs[k0 + m - 1])) return fail(ART_ERR_BAD_ARG, "chains longer than 8 need a view every 8th element");
   }
-  // register budget of the fused kernel in waves per SIMD: 5 (96 VGPRs, no spills) measures 2.5 % faster than 4
-  // (98 VGPRs, which the allocation granule rounds to 104 = 4 waves); 6 needs 12 spilled registers and is 20 % slower.
-  // ART_CHAIN_WAVES=4 selects the other build for comparison.
-  const char* wv = getenv("ART_CHAIN_WAVES");
-  const int waves = wv ? atoi(wv) : 5;
+  const int waves = chain_waves();
   const int64_t chunk = max_rays_per_launch();
   for (int64_t off = 0; off < n; off += chunk) {
     const int64_t cnt = (n - off < chunk) ? n - off : chunk;
@@ -835,33 +917,76 @@ int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundl
     for (int k0 = 0; k0 < n_elems; k0 += kChainMax) {
       ChainArgs a;
       memset(&a, 0, sizeof(a));
-      bool any_defect = false;
       const int m = (n_elems - k0 < kChainMax) ? n_elems - k0 : kChainMax;
       a.n_elems = m;
+      a.in = cur;
       for (int k = 0; k < m; ++k) {
         a.e[k] = elems[k0 + k];
         art::prepare_element(a.e[k]);
         a.out[k] = view_at(outs[k0 + k], off);
-        a.zoff[k] = a.zern_doubles;
-        a.zern_doubles += a.e[k].n_defects * ART_ZPACK_STRIDE;
-        if (a.e[k].n_defects > 0 || a.e[k].n_grid > 0) any_defect = true;
+        if (a.e[k].n_defects > 0 || a.e[k].n_grid > 0) a.flags |= 1;
       }
-      if ((size_t)a.zern_doubles * sizeof(double) > 64 * 1024)
-        return fail(ART_ERR_UNSUPPORTED, "Zernike tables of one fused launch exceed 64 KiB of LDS: trace this chain "
-                                         "element by element (art_trace_element)");
+      size_t lds = 0;
+#ifdef ART_ZERN_LDS
+      lds = zern_lds_bytes(a);
+      if (lds > 64 * 1024) return fail(ART_ERR_UNSUPPORTED, "ART_ZERN_LDS build: Zernike tables of one fused launch exceed 64 KiB");
+#endif
       const dim3 g(grid_stream(cnt)), b(kBlock);
-      if (any_defect)
-        hipLaunchKernelGGL((k_trace_chain<true, 4>), dim3(grid_for(cnt)), b, (size_t)a.zern_doubles * sizeof(double), s, a,
-                           cur, cnt);
+      if (a.flags & 1)
+        hipLaunchKernelGGL((k_trace_chain<true, 4>), dim3(kDefectLoop ? grid_for(cnt) : grid_stream(cnt)), b, lds, s, a, cnt);
       else if (waves == 4)
-        hipLaunchKernelGGL((k_trace_chain<false, 4>), g, b, 0, s, a, cur, cnt);
+        hipLaunchKernelGGL((k_trace_chain<false, 4>), g, b, 0, s, a, cnt);
       else
-        hipLaunchKernelGGL((k_trace_chain<false, 5>), g, b, 0, s, a, cur, cnt);
+        hipLaunchKernelGGL((k_trace_chain<false, 5>), g, b, 0, s, a, cnt);
       cur = a.out[m - 1];
     }
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_trace_chain launch");
+  return ART_OK;
+}
+
+int64_t art_scene_bytes(int32_t n_chains, int32_t n_elems) {
+  if (n_chains <= 0 || n_elems <= 0) return 0;
+  return art::scene_bytes(n_chains, n_elems);
+}
+
+int art_scene_pack(const ArtElementDesc* elems, int32_t n_chains, int32_t n_elems, const ArtBundleView* ins,
+                   const ArtBundleView* outs, void* image) {
+  const char* msg = "";
+  const int rc = art::scene_pack(elems, n_chains, n_elems, ins, outs, image, &msg);
+  if (rc < 0) return fail(rc, msg);
+  return rc;
+}
+
+int art_trace_scene(const void* image_dev, int32_t n_chains, int32_t n_elems, int32_t flags, int64_t n, void* stream) {
+  if (!image_dev) return fail(ART_ERR_BAD_ARG, "scene image is NULL");
+  if (n_chains <= 0 || n_chains > 65535 || n_elems <= 0) return fail(ART_ERR_BAD_ARG, "bad chain or element count");
+  if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
+  if (n == 0) return ART_OK;
+#ifdef ART_ZERN_LDS
+  if (flags & 1) return fail(ART_ERR_UNSUPPORTED, "ART_ZERN_LDS build: scenes with defects go through art_trace_chain");
+#endif
+  hipStream_t s = (hipStream_t)stream;
+  const ChainArgs* tab = art::scene_table(image_dev);
+  const int S = art::scene_segments(n_elems);
+  const int waves = chain_waves();
+  const int64_t chunk = max_rays_per_launch();
+  for (int64_t off = 0; off < n; off += chunk) {
+    const int64_t cnt = (n - off < chunk) ? n - off : chunk;
+    const dim3 g(grid_stream(cnt), n_chains), b(kBlock);
+    for (int sg = 0; sg < S; ++sg) {
+      const ChainArgs* seg = tab + (int64_t)sg * n_chains;
+      if (flags & 1)
+        hipLaunchKernelGGL((k_trace_scene<true, 4>), g, b, 0, s, seg, off, cnt);
+      else if (waves == 4)
+        hipLaunchKernelGGL((k_trace_scene<false, 4>), g, b, 0, s, seg, off, cnt);
+      else
+        hipLaunchKernelGGL((k_trace_scene<false, 5>), g, b, 0, s, seg, off, cnt);
+    }
+  }
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail_hip(err, "art_trace_scene launch");
   return ART_OK;
 }
 
@@ -919,8 +1044,11 @@ int art_detector_readout(const ArtDetectorDesc* d, const ArtBundleView* b, const
   if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
   hipStream_t s = (hipStream_t)stream;
   if (n == 0) {
-    hipError_t e0 = hipMemsetAsync(out24, 0, kReadoutSlots * sizeof(double), s);
-    if (e0 != hipSuccess) return fail_hip(e0, "hipMemsetAsync");
+    // an empty shard must not pollute a cross-rank fold: the final kernel over zero partials writes the reduction
+    // identities (0 for sums, +inf / -inf for the min / max slots 2-5 and 12-13)
+    hipLaunchKernelGGL(k_readout_final, dim3(kReadoutSlots), dim3(kBlock), 0, s, scratch, 0, out24);
+    hipError_t e0 = hipGetLastError();
+    if (e0 != hipSuccess) return fail_hip(e0, "art_detector_readout launch");
     return ART_OK;
   }
   if (!view_ok(b)) return fail(ART_ERR_BAD_ARG, "bundle view has a NULL array");

@@ -33,3 +33,116 @@ class CapturedStep:
     def replay(self):
         self.graph.replay()
         return self.outputs
+
+
+class SceneProgram:
+    """A compiled scene: device-resident scene table (include/art_hip.h: art_scene_pack / art_trace_scene) +
+    preallocated per-element output bundles + a captured HIP graph of the launch(es).
+
+        prog = SceneProgram(sources, element_lists)      # one launch for all chains, captured
+        outs = prog.run()                                 # replay -> [chain][element] bundles (always the same objects)
+        prog.update(new_element_lists)                    # same optics, new poses: rewrites the table in place
+        outs = prog.run()
+
+    The launch reads nothing but the table and the bundles, so a re-trace of a modified scene costs one small
+    host-to-device copy and one graph launch -- no descriptor marshalling, no allocation, no per-launch Python.  This is
+    what a pose scan (the misalignment loop lists of ART/ModuleOpticalChain.py:371-657, an alignment optimiser) or a
+    repeated trace of small bundles (1e4-1e6 rays, where an eager launch is host-bound) should use.  To trace other
+    rays, overwrite the source bundles' tensors in place.  `post`: optional callable `post(outputs)` captured right
+    behind the trace (e.g. a `Detector.readout(..., sync=False)`); its return value is `self.post_result`.
+
+    Results are bit-identical to `RayTracingCalculation`; the returned bundles are overwritten by the next `run()`."""
+
+    def __init__(self, sources, element_lists, IgnoreDefects=True, post=None, capture=True):
+        from . import ModuleProcessing as mp
+        from . import _abi
+        from .bundle import RayBundle
+        self._mp, self._abi = mp, _abi
+        self.sources = [mp._as_bundle(s) for s in sources]
+        self.c, self.m = len(self.sources), len(element_lists[0])
+        self.n = self.sources[0].n_slots
+        self.be = self.sources[0].backend
+        self.IgnoreDefects = bool(IgnoreDefects)
+        if self.c == 0 or self.m == 0 or self.n == 0:
+            raise ValueError("SceneProgram needs at least one chain, one element and one ray")
+        if any(len(e) != self.m for e in element_lists) or any(s.n_slots != self.n for s in self.sources):
+            raise ValueError("all chains of a SceneProgram share the element count and the ray count")
+        self.outputs = RayBundle.allocate_grid(self.n, self.c, self.m, self.sources, self.be)
+        for ci, outs in enumerate(self.outputs):
+            prev = self.sources[ci]
+            for b in outs:
+                b.parent = prev
+                prev = b
+        self._views_in = [s.view() for s in self.sources]
+        self._views_out = [b.view() for outs in self.outputs for b in outs]
+        self.host, self.dev = self.be.scene_alloc(self.c, self.m)
+        self._uploaded = None
+        self._signature = None
+        self.post, self.post_result = post, None
+        self.update(element_lists)
+        self.graph = None
+        if capture and self.be.name == "hip":
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self._launch()
+            torch.cuda.current_stream().wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._launch()
+
+    def _structure(self, element_lists, descs):
+        """What a captured launch has baked in: counts, optic kinds and whether defects are present."""
+        return (len(element_lists), len(element_lists[0]), tuple(d.kind for d in descs),
+                tuple((d.n_defects > 0 or d.n_grid > 0) for d in descs))
+
+    def matches(self, sources, element_lists, kwargs=None):
+        """Can this program re-trace the given scene (same bundles, same structure, same options)?"""
+        kwargs = kwargs or {}
+        if set(kwargs) - {"IgnoreDefects"} or bool(kwargs.get("IgnoreDefects", True)) != self.IgnoreDefects:
+            return False
+        if len(sources) != self.c or any(a is not b for a, b in zip(sources, self.sources)):
+            return False
+        if len(element_lists) != self.c or any(len(e) != self.m for e in element_lists):
+            return False
+        descs = [self._mp.element_descriptor(oe, self.IgnoreDefects, self.be)[0] for els in element_lists for oe in els]
+        return self._structure(element_lists, descs) == self._signature and not any(d.nonfinite for d in descs)
+
+    def update(self, element_lists):
+        """New poses / parameters for the same optics: re-pack the table and copy it over the device image."""
+        descs, keep = [], []
+        for els in element_lists:
+            for oe in els:
+                d, k = self._mp.element_descriptor(oe, self.IgnoreDefects, self.be)
+                if d.nonfinite:
+                    raise ValueError("an element has non-finite parameters")
+                descs.append(d)
+                keep.append(k)
+        sig = self._structure(element_lists, descs)
+        if self._signature is not None and sig != self._signature:
+            raise ValueError("SceneProgram.update: the optics changed (kinds / counts / defects); build a new program")
+        self._signature = sig
+        if self._uploaded is not None:
+            self._uploaded.synchronize()       # the previous copy has read the pinned image
+        self.flags = self.be.scene_pack(descs, self._views_in, self._views_out, self.c, self.m, self.host)
+        self._uploaded = self.be.scene_upload(self.host, self.dev)
+        self._keep = keep
+        for outs in self.outputs:
+            for b in outs:
+                b.touch()
+
+    def _launch(self):
+        self.be.trace_scene(self.dev, self.c, self.m, self.flags, self.n)
+        if self.post is not None:
+            self.post_result = self.post(self.outputs)
+
+    def run(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._launch()
+        for outs in self.outputs:
+            for b in outs:
+                b.touch()
+        return self.outputs

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ART_ABI_VERSION 7
+#define ART_ABI_VERSION 8
 
 /* error codes */
 #define ART_OK 0
@@ -62,7 +62,8 @@ enum ArtSupportKind {
  * of ART/recursive_zernike_generator.py have integer monomial coefficients; the host expands
  *     h(x,y) = sum_nm c_nm Z_nm(x,y) = sum_pq A[p][q] x^p y^q        (x, y = (P - centre) / R)
  * exactly and stores A and its two partial derivatives, so that the kernels evaluate three bivariate Horner
- * schemes out of LDS instead of carrying the recurrence rows in registers.  Layout, for defect d:
+ * schemes instead of carrying the recurrence rows in registers (the coefficients are wave-uniform: they reach the
+ * lanes through scalar loads, one copy per wave; entries of total degree > N must be zero).  Layout, for defect d:
  *   base = d * ART_ZERN_STRIDE
  *   [base+0] = R (Support._CircumCirc()),  [base+1] = max total degree N (2..ART_ZERN_MAX_ORDER)
  *   [base+2            + p*ART_ZERN_DIM + q] = A[p][q]        coefficient of x^p y^q of h
@@ -147,6 +148,26 @@ int art_trace_element(const ArtElementDesc* e, const ArtBundleView* in, const Ar
  * outs[n_elems-1] is mandatory.  Same results as n_elems calls of art_trace_element.                   */
 int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundleView* in,
                     const ArtBundleView* outs, int64_t n, void* stream);
+
+/* MANY chains in ONE launch (ART/ModuleProcessing.py:203-239: OEPlacement with a list-valued argument returns 10-11
+ * chains that differ only in poses, which ARTmain.py:304-342 traces one after the other; the misalignment loop lists of
+ * ART/ModuleOpticalChain.py:371-657 likewise).  All chains have n_elems elements and bundles of n slots.  The
+ * descriptors do not fit kernel arguments, so they travel as a SCENE IMAGE in device memory:
+ *   1. art_scene_bytes(n_chains, n_elems)      size of the image;
+ *   2. art_scene_pack(...)                     fills a HOST buffer of that size -- pure host code, no HIP call;
+ *                                              elems[c * n_elems + k], ins[c], outs[c * n_elems + k] (rules of
+ *                                              art_trace_chain: outs[..].alive == NULL skips that history bundle, the
+ *                                              last view of a chain and every 8th are mandatory).  Returns flags >= 0
+ *                                              to pass on to art_trace_scene, or a negative error code;
+ *   3. the caller copies the image to DEVICE memory (its own allocation and memcpy);
+ *   4. art_trace_scene(image_dev, ...)         ONE kernel launch per 8 elements: grid.y = chain, grid.x = 256-ray tile.
+ * A launch reads nothing but the device image and the bundles: re-packing new poses into the same device buffer and
+ * replaying a captured HIP graph re-traces a modified scene without host-side launch work.  Same per-ray results as
+ * art_trace_chain, bit for bit.                                                                                      */
+int64_t art_scene_bytes(int32_t n_chains, int32_t n_elems);
+int art_scene_pack(const ArtElementDesc* elems, int32_t n_chains, int32_t n_elems, const ArtBundleView* ins,
+                   const ArtBundleView* outs, void* image_host);
+int art_trace_scene(const void* image_dev, int32_t n_chains, int32_t n_elems, int32_t flags, int64_t n, void* stream);
 
 /* Bundle from array-of-structs input (the layout a caller holding ART Ray lists / (n,3) NumPy arrays has):
  * points[n][3], vectors[n][3] (DEVICE, row-major) -> SoA view; directions normalised like the Ray.vector setter

@@ -7,6 +7,7 @@
 #define ART_HOST_TWIN 1
 #include <vector>
 #include "../../attosecondraytracing_amd/csrc/art_device.h"
+#include "../../attosecondraytracing_amd/csrc/art_scene.h"
 
 #include <string.h>
 
@@ -24,24 +25,11 @@ inline void store_ray(const ArtBundleView& v, int64_t i, const art::Ray& r) {
 }
 }  // namespace
 
-// the kernels stage the caller's dense Zernike tables in LDS in packed, row-padded Horner order (art_device.h
-// zern_pack); the twin packs them into a host buffer the same way
-static std::vector<double> pack_tables(const ArtElementDesc& e) {
-  std::vector<double> out;
-  if (e.n_defects > 0 && e.zern) {
-    out.assign((size_t)e.n_defects * ART_ZPACK_STRIDE, 0.0);
-    for (int d = 0; d < e.n_defects; ++d) art::zern_pack(e.zern + d * ART_ZERN_STRIDE, out.data() + d * ART_ZPACK_STRIDE, 0, 1);
-  }
-  return out;
-}
-
 extern "C" {
 
 int art_cpu_trace_element(const ArtElementDesc* e_in, const ArtBundleView* in, const ArtBundleView* out, int64_t n) {
   ArtElementDesc ec = *e_in;
   art::prepare_element(ec);
-  const std::vector<double> packed = pack_tables(ec);
-  ec.zern = packed.empty() ? nullptr : packed.data();
   const ArtElementDesc* e = &ec;
   for (int64_t i = 0; i < n; ++i) {
     bool ok = in->alive[i] != 0;
@@ -59,12 +47,7 @@ int art_cpu_trace_element(const ArtElementDesc* e_in, const ArtBundleView* in, c
 int art_cpu_trace_chain(const ArtElementDesc* elems_in, int32_t n_elems, const ArtBundleView* in,
                         const ArtBundleView* outs, int64_t n) {
   std::vector<ArtElementDesc> elems(elems_in, elems_in + n_elems);
-  std::vector<std::vector<double>> packed(n_elems);
-  for (int k = 0; k < n_elems; ++k) {
-    art::prepare_element(elems[k]);
-    packed[k] = pack_tables(elems[k]);
-    elems[k].zern = packed[k].empty() ? nullptr : packed[k].data();
-  }
+  for (int k = 0; k < n_elems; ++k) art::prepare_element(elems[k]);
   // rays are independent: all host cores (used by bench.py's all-cores CPU figure; the tests do not care)
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; ++i) {
@@ -76,6 +59,42 @@ int art_cpu_trace_chain(const ArtElementDesc* elems_in, int32_t n_elems, const A
       if (outs[k].alive != nullptr) {
         if (ok) store_ray(outs[k], i, r);
         outs[k].alive[i] = ok ? 1 : 0;
+      }
+    }
+  }
+  return 0;
+}
+
+// scene table (csrc/art_scene.h): the same host-side packer as the HIP library, then one host loop per chain segment
+int64_t art_cpu_scene_bytes(int32_t n_chains, int32_t n_elems) {
+  if (n_chains <= 0 || n_elems <= 0) return 0;
+  return art::scene_bytes(n_chains, n_elems);
+}
+
+int art_cpu_scene_pack(const ArtElementDesc* elems, int32_t n_chains, int32_t n_elems, const ArtBundleView* ins,
+                       const ArtBundleView* outs, void* image) {
+  const char* msg = "";
+  return art::scene_pack(elems, n_chains, n_elems, ins, outs, image, &msg);
+}
+
+int art_cpu_trace_scene(const void* image, int32_t n_chains, int32_t n_elems, int32_t flags, int64_t n) {
+  const art::ChainArgs* tab = art::scene_table(image);
+  const int S = art::scene_segments(n_elems);
+  for (int sg = 0; sg < S; ++sg) {
+    for (int c = 0; c < n_chains; ++c) {
+      const art::ChainArgs& a = tab[(int64_t)sg * n_chains + c];
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < n; ++i) {
+        bool ok = a.in.alive[i] != 0;
+        art::Ray r;
+        if (ok) load_ray(a.in, i, r);
+        for (int k = 0; k < a.n_elems; ++k) {
+          if (ok) ok = art::trace_ray_dyn<true>(a.e[k], a.e[k].zern, r);
+          if (a.out[k].alive != nullptr) {
+            if (ok) store_ray(a.out[k], i, r);
+            a.out[k].alive[i] = ok ? 1 : 0;
+          }
+        }
       }
     }
   }

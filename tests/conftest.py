@@ -17,6 +17,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
 
 
+PARITY_REPORT = []
+
+
+def report(line):
+    """A line for the end-of-run parity summary (shown with -q too, so the driver's GPUTEST tail carries the worst
+    relative errors measured on the GPU)."""
+    PARITY_REPORT.append(str(line))
+
+
+def pytest_terminal_summary(terminalreporter):
+    if PARITY_REPORT:
+        terminalreporter.write_line("---- parity summary (worst relative errors; bars: 1e-10, incidence 1e-9 rad) ----")
+        for line in PARITY_REPORT:
+            terminalreporter.write_line(line)
+
+
 def load_golden(name):
     """Load one fixture: returns (scene dict, arrays dict)."""
     z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)

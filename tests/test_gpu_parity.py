@@ -5,7 +5,7 @@ delays 1e-10 of the mean travel time (BASELINE.json north_star)."""
 import numpy as np
 import pytest
 
-from conftest import chain_golden_names, load_golden
+from conftest import chain_golden_names, load_golden, report
 import parity_common as pc
 
 pytestmark = pytest.mark.gpu
@@ -32,7 +32,20 @@ def test_gpu_chain_matches_reference(hip, name, mode):
     els = pc.build_elements(scene, a)
     src = pc.source_bundle(a, scene)
     out = mp.RayTracingCalculation(src, els, IgnoreDefects=scene.get("IgnoreDefects", True), mode=mode)
-    pc.check_outputs(out, a, scene)
+    w = pc.check_outputs(out, a, scene)
+    _GOLDEN_WORST.setdefault(mode, {})
+    for k, v in w.items():
+        if v > _GOLDEN_WORST[mode].get(k, (0.0, ""))[0]:
+            _GOLDEN_WORST[mode][k] = (v, name)
+
+
+_GOLDEN_WORST = {}
+
+
+def test_gpu_golden_summary(hip):
+    """Not a check of its own: puts the worst errors of the golden chains (above) into the end-of-run summary."""
+    for mode, w in _GOLDEN_WORST.items():
+        report(f"[parity goldens, {mode} mode] " + "  ".join(f"{k} {v:.2e} ({n})" for k, (v, n) in sorted(w.items())))
 
 
 @pytest.mark.parametrize("name", [n for n in chain_golden_names() if not n.startswith("frame_")])
@@ -96,11 +109,15 @@ def test_gpu_vs_oracle_seeded_c3(hip):
         els.append(orc.Element(orc.Optic(kind, orc.Support(sk, o.support._abi_params()), params, [], o.type),
                                np.asarray(oe.position, float), oe.normal, oe.majoraxis))
     ref = orc.ray_tracing_calculation(B, els)
+    worst = [0.0, 0.0, 0.0]
     for o, q in zip(out, ref):
         assert np.array_equal(o.numbers(), q.number)
-        assert np.abs(o.points() - q.point).max() <= 1e-10 * 2000
-        assert np.abs(o.vectors() - q.vector).max() <= 1e-10
-        assert np.abs(o.paths_total() - q.path.sum(axis=1)).max() <= 1e-10 * q.path.sum(axis=1).mean()
+        scale = max(1.0, np.abs(q.point).max())            # 1e-10 of max|ref|, not of a fixed length
+        e = (np.abs(o.points() - q.point).max() / scale, np.abs(o.vectors() - q.vector).max(),
+             np.abs(o.paths_total() - q.path.sum(axis=1)).max() / q.path.sum(axis=1).mean())
+        worst = [max(a, b) for a, b in zip(worst, e)]
+        assert e[0] <= 1e-10 and e[1] <= 1e-10 and e[2] <= 1e-10, e
+    report(f"[parity c3 1e5 vs oracle] worst rel err: pos {worst[0]:.2e} dir {worst[1]:.2e} path {worst[2]:.2e}")
 
 
 def test_gpu_full_size_properties(hip):
@@ -120,9 +137,10 @@ def test_gpu_full_size_properties(hip):
     for a, b in zip(out_c, out_e):
         assert torch.equal(a.alive, b.alive)
         m = a.alive.bool()
-        assert float((a.data[0:3, m] - b.data[0:3, m]).abs().max()) <= 1e-13 * 2000
+        scale = max(1.0, float(b.data[0:3, m].abs().max()))
+        assert float((a.data[0:3, m] - b.data[0:3, m]).abs().max()) <= 1e-13 * scale
         assert float((a.data[3:6, m] - b.data[3:6, m]).abs().max()) <= 1e-13
-        assert float((a.data[6:8, m] - b.data[6:8, m]).abs().max()) <= 1e-13 * 2000
+        assert float((a.data[6:8, m] - b.data[6:8, m]).abs().max()) <= 1e-13 * scale
     last = out_c[-1]
     m = last.alive.bool()
     assert abs(int(m.sum().item()) / n - 0.673) < 0.01      # SURVEY: mask passes 67.3 %
@@ -463,15 +481,22 @@ def test_gpu_full_size_sampled_against_oracle(hip, scene):
     host = src.data.index_select(1, st).cpu().numpy()
     B = orc.make_bundle(host[0:3].T, host[3:6].T, slots, np.ones(len(slots)))
     ref = orc.ray_tracing_calculation(B, _oracle_elements(chain), IgnoreDefects=ignore)
-    scale = 2000.0
+    worst = [0.0, 0.0, 0.0, 0.0]
     for o, q in zip(out, ref):
         alive = o.alive.index_select(0, st).cpu().numpy().astype(bool)
         assert np.array_equal(slots[alive], q.number), "survivors differ on the sampled slots"
         d = o.data.index_select(1, st).cpu().numpy()[:, alive]
-        assert np.abs(d[0:3].T - q.point).max() <= 1e-10 * scale
-        assert np.abs(d[3:6].T - q.vector).max() <= 1e-10
-        assert np.abs(d[6] - q.path.sum(axis=1)).max() <= 1e-10 * max(q.path.sum(axis=1).mean(), 1.0)
-        assert np.abs(d[7] - q.incidence).max() <= 1e-9
+        scale = max(1.0, np.abs(q.point).max())            # 1e-10 of max|ref|: ~25-100 mm for C5
+        e = (np.abs(d[0:3].T - q.point).max() / scale, np.abs(d[3:6].T - q.vector).max(),
+             np.abs(d[6] - q.path.sum(axis=1)).max() / max(q.path.sum(axis=1).mean(), 1.0),
+             np.abs(d[7] - q.incidence).max())
+        worst = [max(a, b) for a, b in zip(worst, e)]
+        assert e[0] <= 1e-10, f"position error {e[0]:.3e} of max|ref| = {scale:.1f} mm"
+        assert e[1] <= 1e-10, f"direction error {e[1]:.3e}"
+        assert e[2] <= 1e-10, f"path error {e[2]:.3e}"
+        assert e[3] <= 1e-9, f"incidence error {e[3]:.3e}"
+    report(f"[parity {scene} full size, 20000 slots vs oracle] worst rel err: pos {worst[0]:.2e} dir {worst[1]:.2e} "
+          f"path {worst[2]:.2e} inc {worst[3]:.2e} rad")
     assert len(ref[-1]) > 5_000
 
 
@@ -480,3 +505,47 @@ def test_gpu_torus_hit_distance_vs_long_double_truth(hip, name):
     """The kernels' hardware-seeded reciprocal / rsqrt paths against an 80-bit truth (tests/test_accuracy_truth.py)."""
     from test_accuracy_truth import check_against_truth
     check_against_truth(name)
+
+
+# ------------------------------------------------------------------------------------------------ scene table
+def test_gpu_batched_loop_lists_match_reference(hip):
+    """Many chains in ONE launch (art_scene_pack / art_trace_scene): the reference's loop-list chains C2 (chains 0/5/10
+    of 11) and C3 (chains 0/4/9 of 10, ART/ModuleProcessing.py:203-239) from one batched call each, against their
+    fixtures and bit-for-bit against the single-chain launches."""
+    import scene_cases
+    for names in (("c2_fxf_chain00", "c2_fxf_chain05", "c2_fxf_chain10"),
+                  ("c3_twisted_chain00", "c3_twisted_chain04", "c3_twisted_chain09")):
+        w = scene_cases.run_batched_goldens(names)
+        report(f"[parity batched {names[0][:2]}] worst rel err: " + " ".join(f"{k} {v:.2e}" for k, v in w.items()))
+
+
+def test_gpu_batched_variants(hip):
+    import scene_cases
+    scene_cases.run_batched_variants()
+
+
+def test_gpu_scene_program_replays(hip):
+    """graph.SceneProgram: pose updates rewrite the device-resident table, the captured HIP graph is replayed."""
+    import scene_cases
+    scene_cases.run_program_updates()
+    scene_cases.run_chain_list_cache()
+
+
+def test_gpu_batched_full_size_c2(hip):
+    """BASELINE C2 size: 11 chains x 1e6 rays in one launch == 11 single launches, bit for bit."""
+    import torch
+    import ART.ModuleMirror as mmirror, ART.ModuleMask as mmask, ART.ModuleSupport as msupp, ART.ModuleProcessing as mp
+    SP = {"Divergence": 50e-3 / 2, "SourceSize": 0, "Wavelength": 50e-6, "DeltaFT": 0.5, "NumberRays": 1_000_000}
+    Mask = mmask.Mask(msupp.SupportRoundHole(20, 14e-3 * 500, 0, 0))
+    R, r = mmirror.ReturnOptimalToroidalRadii(500, 80)
+    Tor = mmirror.MirrorToroidal(R, r, msupp.SupportRectangle(150, 32))
+    chains = mp.OEPlacement(SP, [Mask, Tor, Tor], [400, 100, np.linspace(300, 700, 11).tolist()], [0, 80, -80], [0, 0, 0],
+                            "C2")
+    assert len(chains) == 11
+    many = mp.RayTracingCalculationMany([c.source_rays for c in chains], [c.optical_elements for c in chains])
+    for c, o in zip(chains, many):
+        for x, y in zip(o, mp.RayTracingCalculation(c.source_rays, c.optical_elements)):
+            assert torch.equal(x.alive, y.alive)
+            m = x.alive.bool()
+            assert torch.equal(x.data[:, m], y.data[:, m])
+        assert 0.4 < len(o[-1]) / 1e6 < 0.6          # SURVEY: C2 1e6 -> 4.9e5

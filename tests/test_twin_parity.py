@@ -95,3 +95,22 @@ def test_twin_zernike_high_order_vs_oracle(twin):
         assert np.abs(out.paths_total() - ref.path.sum(axis=1)).max() <= 1e-10 * 100
     with pytest.raises(NotImplementedError):
         mdef.Zernike(S, {(17, 3): 1e-5})
+
+
+def test_twin_batched_loop_lists_match_reference(twin):
+    """Many chains in one launch (scene table): the reference's loop-list chains C2 (chains 0/5/10 of 11) and C3
+    (chains 0/4/9 of 10) from ONE batched call each, against their fixtures and the single-chain launches."""
+    import scene_cases
+    scene_cases.run_batched_goldens(("c2_fxf_chain00", "c2_fxf_chain05", "c2_fxf_chain10"))
+    scene_cases.run_batched_goldens(("c3_twisted_chain00", "c3_twisted_chain04", "c3_twisted_chain09"))
+
+
+def test_twin_batched_variants(twin):
+    import scene_cases
+    scene_cases.run_batched_variants()
+
+
+def test_twin_scene_program(twin):
+    import scene_cases
+    scene_cases.run_program_updates()
+    scene_cases.run_chain_list_cache()

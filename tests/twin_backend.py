@@ -70,16 +70,42 @@ class TwinBackend:
         m = len(descs)
         # the argument rules of art_trace_chain (csrc/art_kernels.hip), so that host-shell mistakes show up without a GPU:
         # the last view is mandatory, and a chain longer than one fused launch (8 elements) needs a view where one
-        # launch hands over to the next; Zernike tables of one launch must fit 64 KiB of LDS (502 doubles per defect)
+        # launch hands over to the next
         if n > 0:
             assert vouts[m - 1].alive, "the last output view is mandatory"
             for k0 in range(0, m, 8):
                 k1 = min(k0 + 8, m)
                 assert vouts[k1 - 1].alive, "chains longer than 8 need a view every 8th element"
-                assert sum(d.n_defects for d in descs[k0:k1]) * 502 * 8 <= 64 * 1024, "Zernike tables exceed 64 KiB of LDS"
         darr = (_abi.ArtElementDesc * m)(*descs)
         varr = (_abi.ArtBundleView * m)(*vouts)
         assert self.lib.art_cpu_trace_chain(darr, m, C.byref(vin), varr, n) == 0
+
+    # scene table: the same packer (csrc/art_scene.h) compiled into the twin, "device" image = the host image
+    def scene_alloc(self, n_chains, n_elems):
+        f = self.lib.art_cpu_scene_bytes
+        f.restype, f.argtypes = C.c_int64, [C.c_int32, C.c_int32]
+        img = torch.empty(int(f(n_chains, n_elems)), dtype=torch.uint8)
+        return img, img
+
+    def scene_pack(self, descs, views_in, views_out, n_chains, n_elems, host_image):
+        f = self.lib.art_cpu_scene_pack
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(_abi.ArtElementDesc), C.c_int32, C.c_int32, C.POINTER(_abi.ArtBundleView),
+                      C.POINTER(_abi.ArtBundleView), C.c_void_p]
+        darr = (_abi.ArtElementDesc * (n_chains * n_elems))(*descs)
+        iarr = (_abi.ArtBundleView * n_chains)(*views_in)
+        oarr = (_abi.ArtBundleView * (n_chains * n_elems))(*views_out)
+        rc = f(darr, n_chains, n_elems, iarr, oarr, host_image.data_ptr())
+        assert rc >= 0, rc
+        return rc
+
+    def scene_upload(self, host_image, dev_image):
+        return None
+
+    def trace_scene(self, dev_image, n_chains, n_elems, flags, n):
+        f = self.lib.art_cpu_trace_scene
+        f.restype, f.argtypes = C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64]
+        assert f(dev_image.data_ptr(), n_chains, n_elems, flags, n) == 0
 
     def pack_rays(self, points, vectors, path0, n, view):
         f = self.lib.art_cpu_pack_rays
@@ -149,6 +175,7 @@ class TwinBackend:
         o = opl[a] if opl is not None else z
         ww = w[a] if w is not None else np.ones_like(z)
         out = np.zeros(16)
+        out[[2, 4, 12]], out[[3, 5, 13]] = np.inf, -np.inf       # reduction identities when nothing is alive
         if len(z):
             out[:14] = [len(z), o.sum(), x.min(), x.max(), y.min(), y.max(), x.sum(), y.sum(), ww.sum(),
                         (ww * x).sum(), (ww * y).sum(), (ww * o).sum(), o.min(), o.max()]
