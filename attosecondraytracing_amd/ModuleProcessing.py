@@ -86,7 +86,15 @@ def _build_descriptor(oe, IgnoreDefects, backend):
             d.n_defects = len(zern)
         if grids:
             arr = (_abi.ArtGridDefect * len(grids))()
+            rect = np.asarray(optic.support._CircumRect(), dtype=float)
             for g, D in zip(arr, grids):
+                # The kernels clamp a look-up outside the map to its edge; the reference's interpolator raises there
+                # (ART/ModuleDefects.py:108-110, RegularGridInterpolator with bounds_error=True).  Hits lie inside the
+                # mirror's support, so the two only differ when the support is larger than the map: refuse that here.
+                half = np.array([max(abs(D._X[0]), abs(D._X[-1])), max(abs(D._Y[0]), abs(D._Y[-1]))])
+                if (rect / 2 > half * (1 + 1e-12)).any():
+                    raise ValueError(f"One of the requested xi is out of bounds: the mirror support ({rect[0]:g} x "
+                                     f"{rect[1]:g} mm) is larger than the Fourrier map ({2 * half[0]:g} x {2 * half[1]:g} mm)")
                 fields, dev = D._abi_grid(be)
                 keep.append(dev)
                 for k_, v_ in fields.items():

@@ -47,6 +47,7 @@ class HipBackend:
         self.device = torch.device("cuda", torch.cuda.current_device())
         self._scratch = {}
         self.trace_events = None   # set to a list to collect (start, end) HIP events around each trace launch
+        self.readout_events = None  # likewise around each fused read-out (kernel + final fold)
 
     # ------------------------------------------------------------------ helpers
     def last_error(self):
@@ -82,15 +83,16 @@ class HipBackend:
         return t
 
     # ------------------------------------------------------------------ entry points
-    def _timed(self, call):
-        """Run one launch; when trace_events is a list, bracket it with HIP events recorded on the launch stream."""
-        if self.trace_events is None:
+    def _timed(self, call, sink="trace_events"):
+        """Run one launch; when the sink list is set, bracket it with HIP events recorded on the launch stream."""
+        events = getattr(self, sink)
+        if events is None:
             return call()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = call()
         e1.record()
-        self.trace_events.append((e0, e1))
+        events.append((e0, e1))
         return rc
 
     def trace_element(self, desc, view_in, view_out, n):
@@ -160,13 +162,12 @@ class HipBackend:
         out = self.empty(24)      # n == 0: the library writes the reduction identities (0, +inf, -inf)
         p = [t.data_ptr() for t in p3] if (p3 is not None and n > 0) else [None, None, None]
         xy = [t.data_ptr() for t in XY] if (XY is not None and n > 0) else [None, None]
-        self.check(self.fn["art_detector_readout"](C.byref(ddesc), C.byref(view),
-                                                   None if (w is None or n == 0) else w.data_ptr(),
-                                                   n, float(centres[0]), float(centres[1]), float(centres[2]),
-                                                   p[0], p[1], p[2], xy[0], xy[1],
-                                                   None if (opl is None or n == 0) else opl.data_ptr(),
-                                                   self._red_scratch().data_ptr(), out.data_ptr(),
-                                                   self.stream_ptr()), "art_detector_readout")
+        sp, scratch = self.stream_ptr(), self._red_scratch()
+        self.check(self._timed(lambda: self.fn["art_detector_readout"](
+            C.byref(ddesc), C.byref(view), None if (w is None or n == 0) else w.data_ptr(), n, float(centres[0]),
+            float(centres[1]), float(centres[2]), p[0], p[1], p[2], xy[0], xy[1],
+            None if (opl is None or n == 0) else opl.data_ptr(), scratch.data_ptr(), out.data_ptr(), sp),
+            "readout_events"), "art_detector_readout")
         return out.cpu().numpy() if to_host else out
 
     def detector_scan_moments(self, ddesc, view, w, n, co, span=0.0):

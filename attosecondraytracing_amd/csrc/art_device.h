@@ -545,6 +545,40 @@ inline void prepare_element(ArtElementDesc& e) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// KIND >= 0: compile-time optic kind; KIND = ART_KIND_DYN: wave-uniform run-time switch on e.kind.  The run-time form
+// lets the fused chain kernel WITH defects share one copy of everything that does not depend on the kind (frame
+// changes, the unrolled Zernike evaluators, reflection, incidence angle) instead of one copy per kind.
+#define ART_KIND_DYN (-1)
+
+template <int KIND>
+ART_HD bool intersect_k(const ArtElementDesc& e, double Ax, double Ay, double Az, double ux, double uy, double uz,
+                        double& t) {
+  if (KIND != ART_KIND_DYN) return intersect<(KIND < 0 ? 0 : KIND)>(e, Ax, Ay, Az, ux, uy, uz, t);
+  switch (e.kind) {
+    case ART_PLANE: return intersect<ART_PLANE>(e, Ax, Ay, Az, ux, uy, uz, t);
+    case ART_SPHERE: return intersect<ART_SPHERE>(e, Ax, Ay, Az, ux, uy, uz, t);
+    case ART_PARABOLA: return intersect<ART_PARABOLA>(e, Ax, Ay, Az, ux, uy, uz, t);
+    case ART_TORUS: return intersect<ART_TORUS>(e, Ax, Ay, Az, ux, uy, uz, t);
+    case ART_ELLIPSOID: return intersect<ART_ELLIPSOID>(e, Ax, Ay, Az, ux, uy, uz, t);
+    case ART_CYLINDER: return intersect<ART_CYLINDER>(e, Ax, Ay, Az, ux, uy, uz, t);
+    default: return intersect<ART_MASK>(e, Ax, Ay, Az, ux, uy, uz, t);
+  }
+}
+
+template <int KIND>
+ART_HD void base_normal_k(const ArtElementDesc& e, double x, double y, double z, double& nx, double& ny, double& nz) {
+  if (KIND != ART_KIND_DYN) return base_normal<(KIND < 0 ? 0 : KIND)>(e, x, y, z, nx, ny, nz);
+  switch (e.kind) {
+    case ART_SPHERE: return base_normal<ART_SPHERE>(e, x, y, z, nx, ny, nz);
+    case ART_PARABOLA: return base_normal<ART_PARABOLA>(e, x, y, z, nx, ny, nz);
+    case ART_TORUS: return base_normal<ART_TORUS>(e, x, y, z, nx, ny, nz);
+    case ART_ELLIPSOID: return base_normal<ART_ELLIPSOID>(e, x, y, z, nx, ny, nz);
+    case ART_CYLINDER: return base_normal<ART_CYLINDER>(e, x, y, z, nx, ny, nz);
+    default: return base_normal<ART_PLANE>(e, x, y, z, nx, ny, nz);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // One element acting on one ray (ART/ModuleProcessing.py:284-311 for a single ray).
 // Returns false when the ray is lost (missed the optic / blocked by the mask).
 // `zern`: the element's dense Zernike tables (n_defects x ART_ZERN_STRIDE doubles) -- e.zern itself (device memory,
@@ -558,11 +592,11 @@ ART_HD bool trace_ray(const ArtElementDesc& e, const double* zern, Ray& r) {
   mat3_apply(e.fwd, r.dx, r.dy, r.dz, ux, uy, uz);
 
   double t;
-  if (!intersect<KIND>(e, Ax, Ay, Az, ux, uy, uz, t)) return false;
+  if (!intersect_k<KIND>(e, Ax, Ay, Az, ux, uy, uz, t)) return false;
   double Px = fma(t, ux, Ax), Py = fma(t, uy, Ay), Pz = fma(t, uz, Az);
 
   double vx, vy, vz, inc;
-  if (KIND == ART_MASK) {
+  if (KIND == ART_MASK || (KIND == ART_KIND_DYN && e.kind == ART_MASK)) {
     // _TransmitMaskRay, ModuleMask.py:93-108: direction unchanged, incidence = angle(v, ez)
     vx = ux; vy = uy; vz = uz;
     inc = kahan_angle_unit(ux, uy, uz, 0.0, 0.0, 1.0);
@@ -571,7 +605,7 @@ ART_HD bool trace_ray(const ArtElementDesc& e, const double* zern, Ray& r) {
 #ifdef ART_DIAG_NONORMAL
     nx = 0.0; ny = 0.0; nz = 1.0 + 1e-30 * Px;
 #else
-    base_normal<KIND>(e, Px, Py, Pz, nx, ny, nz);
+    base_normal_k<KIND>(e, Px, Py, Pz, nx, ny, nz);
 #endif
     if (DEFECT && (e.n_defects > 0 || e.n_grid > 0)) {
       // DeformedMirror._get_intersection, ModuleMirror.py:969-980: slide the hit point along the ray by
@@ -584,7 +618,7 @@ ART_HD bool trace_ray(const ArtElementDesc& e, const double* zern, Ray& r) {
       const double s = div_full(h, cosa);
       t -= s;
       Px = fma(-s, ux, Px); Py = fma(-s, uy, Py); Pz = fma(-s, uz, Pz);
-      base_normal<KIND>(e, Px, Py, Pz, nx, ny, nz);
+      base_normal_k<KIND>(e, Px, Py, Pz, nx, ny, nz);
       if (e.flags & ART_FLAG_PERTURBED_NORMAL) {
         // DeformedMirror.get_normal, ModuleMirror.py:952-961 with normal_add (ModuleGeometry.py:394-407):
         // surface slopes add up
@@ -624,16 +658,20 @@ ART_HD bool trace_ray(const ArtElementDesc& e, const double* zern, Ray& r) {
   return true;
 }
 
-// runtime dispatch on the optic kind (wave-uniform)
+// runtime dispatch on the optic kind (wave-uniform).  Without defects: one fully specialised body per kind (the
+// headline path; registers and schedule as tuned in round 1).  With defects: ONE body whose kind-dependent parts
+// (intersection, undeformed normal) switch at run time -- a sixth of the code, and the register allocator no longer
+// has to satisfy six inlined copies of the unrolled Zernike evaluators at once.
 template <bool DEFECT>
 ART_HD bool trace_ray_dyn(const ArtElementDesc& e, const double* zern, Ray& r) {
+  if (DEFECT) return trace_ray<ART_KIND_DYN, true>(e, zern, r);
   switch (e.kind) {
-    case ART_PLANE: return trace_ray<ART_PLANE, DEFECT>(e, zern, r);
-    case ART_SPHERE: return trace_ray<ART_SPHERE, DEFECT>(e, zern, r);
-    case ART_PARABOLA: return trace_ray<ART_PARABOLA, DEFECT>(e, zern, r);
-    case ART_TORUS: return trace_ray<ART_TORUS, DEFECT>(e, zern, r);
-    case ART_ELLIPSOID: return trace_ray<ART_ELLIPSOID, DEFECT>(e, zern, r);
-    case ART_CYLINDER: return trace_ray<ART_CYLINDER, DEFECT>(e, zern, r);
+    case ART_PLANE: return trace_ray<ART_PLANE, false>(e, zern, r);
+    case ART_SPHERE: return trace_ray<ART_SPHERE, false>(e, zern, r);
+    case ART_PARABOLA: return trace_ray<ART_PARABOLA, false>(e, zern, r);
+    case ART_TORUS: return trace_ray<ART_TORUS, false>(e, zern, r);
+    case ART_ELLIPSOID: return trace_ray<ART_ELLIPSOID, false>(e, zern, r);
+    case ART_CYLINDER: return trace_ray<ART_CYLINDER, false>(e, zern, r);
     default: return trace_ray<ART_MASK, false>(e, zern, r);
   }
 }

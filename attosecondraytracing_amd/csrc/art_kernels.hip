@@ -47,6 +47,38 @@ inline int grid_stream(int64_t n) {
   return (int)b;
 }
 
+// Workgroup -> tile mapping of the streaming kernels (`xmap`, a kernel argument).  The hardware deals consecutive
+// workgroup ids round-robin to the 8 XCDs, so with the identity mapping each XCD's L2 sees every 8th 2-KiB piece of
+// every stream.  xmap = k > 0 hands each XCD runs of 2^(k-1) CONSECUTIVE tiles instead (groups of 8 * 2^(k-1) tiles are
+// shared out among the XCDs); xmap < 0 gives every XCD one contiguous eighth of the launch; 0 = identity.  The grid is
+// rounded up to a whole number of groups (grid_stream_mapped); tiles beyond the bundle fall outside every buffer
+// descriptor and do nothing.  Measured in DESIGN.md 5 (round 2).
+__device__ __forceinline__ int64_t tile_of(const unsigned b, const unsigned nb, const int xmap) {
+  if (xmap == 0) return b;
+  if (xmap < 0) return (int64_t)(b & 7u) * (nb >> 3) + (b >> 3);
+  const unsigned sh = (unsigned)(xmap - 1), span_sh = sh + 3u;
+  const unsigned r = b & ((1u << span_sh) - 1u);
+  return (int64_t)(((b >> span_sh) << span_sh) + ((r & 7u) << sh) + (r >> 3));
+}
+
+// ART_XCD_MAP: "0" identity, "-1" eighths, "k" runs of 2^(k-1) tiles per XCD (default below)
+inline int xcd_map() {
+  static const int v = [] {
+    const char* e = getenv("ART_XCD_MAP");
+    const int x = e ? atoi(e) : -1;
+    return (x < -1 || x > 16) ? 0 : x;
+  }();
+  return v;
+}
+
+inline int grid_stream_mapped(int64_t n, int xmap) {
+  int64_t b = (n + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  const int64_t span = (xmap == 0) ? 1 : (xmap < 0 ? 8 : ((int64_t)8 << (xmap - 1)));
+  b = (b + span - 1) / span * span;
+  return (int)b;   // <= 2^20 + span workgroups for 2^28 rays
+}
+
 inline int grid_for(int64_t n) {
   int64_t b = (n + kBlock - 1) / kBlock;
   if (b < 1) b = 1;
@@ -178,7 +210,7 @@ constexpr bool kDefectLoop = false;
 // (alive = 0) and their stores are dropped, so the tail needs no branch.
 template <int KIND, bool DEFECT>
 __global__ __launch_bounds__(kBlock) void k_trace_element(const ElemArg ea, const ArtBundleView in,
-                                                          const ArtBundleView out, const int64_t n) {
+                                                          const ArtBundleView out, const int64_t n, const int xmap) {
   const ArtElementDesc& e = ea.e[blockIdx.y];
   const double* zern = e.zern;
 #ifdef ART_ZERN_LDS
@@ -191,7 +223,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_element(const ElemArg ea, cons
 #endif
   const BundleRsrc bi = make_rsrc(in, n), bo = make_rsrc(out, n);
   const int64_t stride = (int64_t)gridDim.x * kBlock;
-  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int64_t i = tile_of(blockIdx.x, gridDim.x, xmap) * kBlock + threadIdx.x;
   do {
     art::Ray r;
     r.inc = 0.0;
@@ -246,7 +278,8 @@ __device__ __forceinline__ void store_tile_lds4(const ArtBundleView& v, const in
 // `a` lives in kernel arguments (k_trace_chain) or in the device-resident scene table (k_trace_scene): either way
 // its fields are wave-uniform and fetched by scalar loads where they are used.  Rays [first, first + n) of every view.
 template <bool DEFECT>
-__device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t first, const int64_t n, double* s_zern) {
+__device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t first, const int64_t n, const int xmap,
+                                           double* s_zern) {
 #ifdef ART_ZERN_LDS
   if (DEFECT) {
     int off = 0;
@@ -260,13 +293,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
 #ifdef ART_STORE_LDS4
   __shared__ __attribute__((aligned(16))) double s_out[8][kBlock];
 #endif
-#ifdef ART_XCD_REMAP
-  // experiment: workgroups are dealt round-robin to the 8 XCDs; give every XCD one contiguous eighth of the tiles
-  const int64_t per_xcd = ((int64_t)gridDim.x + 7) / 8;
-  const int64_t tile = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-#else
-  const int64_t tile = blockIdx.x;
-#endif
+  const int64_t tile = tile_of(blockIdx.x, gridDim.x, xmap);
   const BundleRsrc bi = make_rsrc(a.in, n, first);
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   int64_t i = tile * kBlock + threadIdx.x;
@@ -300,17 +327,17 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
 }
 
 template <bool DEFECT, int WAVES>
-__global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain(const ChainArgs a, const int64_t n) {
+__global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain(const ChainArgs a, const int64_t n, const int xmap) {
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];   // used by the -DART_ZERN_LDS build only
-  chain_body<DEFECT>(a, 0, n, s_dyn);
+  chain_body<DEFECT>(a, 0, n, xmap, s_dyn);
 }
 
 // Many chains in one launch: blockIdx.y = chain, descriptors in the device-resident scene table (art_scene.h).
 template <bool DEFECT, int WAVES>
 __global__ __launch_bounds__(kBlock, WAVES) void k_trace_scene(const ChainArgs* __restrict__ tab, const int64_t first,
-                                                               const int64_t n) {
+                                                               const int64_t n, const int xmap) {
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-  chain_body<DEFECT>(tab[blockIdx.y], first, n, s_dyn);
+  chain_body<DEFECT>(tab[blockIdx.y], first, n, xmap, s_dyn);
 }
 
 // ------------------------------------------------------------------------------------------- AoS -> SoA
@@ -812,11 +839,13 @@ void launch_element(const ArtElementDesc& e, const ArtBundleView& in, const ArtB
                     hipStream_t s) {
   ElemArg ea;
   ea.e[0] = e;
+  const int xm = xcd_map();
   if (e.n_defects > 0 || e.n_grid > 0)
-    hipLaunchKernelGGL((k_trace_element<KIND, true>), dim3(kDefectLoop ? grid_for(n) : grid_stream(n)), dim3(kBlock), 0,
-                       s, ea, in, out, n);
+    hipLaunchKernelGGL((k_trace_element<KIND, true>), dim3(kDefectLoop ? grid_for(n) : grid_stream_mapped(n, xm)),
+                       dim3(kBlock), 0, s, ea, in, out, n, kDefectLoop ? 0 : xm);
   else
-    hipLaunchKernelGGL((k_trace_element<KIND, false>), dim3(grid_stream(n)), dim3(kBlock), 0, s, ea, in, out, n);
+    hipLaunchKernelGGL((k_trace_element<KIND, false>), dim3(grid_stream_mapped(n, xm)), dim3(kBlock), 0, s, ea, in, out, n,
+                       xm);
 }
 
 }  // namespace
@@ -888,6 +917,11 @@ inline int chain_waves() {
   const char* wv = getenv("ART_CHAIN_WAVES");
   return wv ? atoi(wv) : 5;
 }
+// the fused kernel WITH defects: 4 waves (126 VGPRs, no spills) or 5 (96 VGPRs, 25 spilled dwords); ART_DEFECT_WAVES
+inline int defect_waves() {
+  const char* wv = getenv("ART_DEFECT_WAVES");
+  return wv ? atoi(wv) : 4;
+}
 }  // namespace
 
 int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundleView* in, const ArtBundleView* outs,
@@ -931,13 +965,18 @@ int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundl
       lds = zern_lds_bytes(a);
       if (lds > 64 * 1024) return fail(ART_ERR_UNSUPPORTED, "ART_ZERN_LDS build: Zernike tables of one fused launch exceed 64 KiB");
 #endif
-      const dim3 g(grid_stream(cnt)), b(kBlock);
-      if (a.flags & 1)
-        hipLaunchKernelGGL((k_trace_chain<true, 4>), dim3(kDefectLoop ? grid_for(cnt) : grid_stream(cnt)), b, lds, s, a, cnt);
+      const int xm = xcd_map();
+      const dim3 g(grid_stream_mapped(cnt, xm)), b(kBlock);
+      if ((a.flags & 1) && defect_waves() == 5)
+        hipLaunchKernelGGL((k_trace_chain<true, 5>), dim3(kDefectLoop ? grid_for(cnt) : grid_stream_mapped(cnt, xm)), b, lds,
+                           s, a, cnt, kDefectLoop ? 0 : xm);
+      else if (a.flags & 1)
+        hipLaunchKernelGGL((k_trace_chain<true, 4>), dim3(kDefectLoop ? grid_for(cnt) : grid_stream_mapped(cnt, xm)), b, lds,
+                           s, a, cnt, kDefectLoop ? 0 : xm);
       else if (waves == 4)
-        hipLaunchKernelGGL((k_trace_chain<false, 4>), g, b, 0, s, a, cnt);
+        hipLaunchKernelGGL((k_trace_chain<false, 4>), g, b, 0, s, a, cnt, xm);
       else
-        hipLaunchKernelGGL((k_trace_chain<false, 5>), g, b, 0, s, a, cnt);
+        hipLaunchKernelGGL((k_trace_chain<false, 5>), g, b, 0, s, a, cnt, xm);
       cur = a.out[m - 1];
     }
   }
@@ -974,15 +1013,18 @@ int art_trace_scene(const void* image_dev, int32_t n_chains, int32_t n_elems, in
   const int64_t chunk = max_rays_per_launch();
   for (int64_t off = 0; off < n; off += chunk) {
     const int64_t cnt = (n - off < chunk) ? n - off : chunk;
-    const dim3 g(grid_stream(cnt), n_chains), b(kBlock);
+    const int xm = xcd_map();
+    const dim3 g(grid_stream_mapped(cnt, xm), n_chains), b(kBlock);
     for (int sg = 0; sg < S; ++sg) {
       const ChainArgs* seg = tab + (int64_t)sg * n_chains;
-      if (flags & 1)
-        hipLaunchKernelGGL((k_trace_scene<true, 4>), g, b, 0, s, seg, off, cnt);
+      if ((flags & 1) && defect_waves() == 5)
+        hipLaunchKernelGGL((k_trace_scene<true, 5>), g, b, 0, s, seg, off, cnt, xm);
+      else if (flags & 1)
+        hipLaunchKernelGGL((k_trace_scene<true, 4>), g, b, 0, s, seg, off, cnt, xm);
       else if (waves == 4)
-        hipLaunchKernelGGL((k_trace_scene<false, 4>), g, b, 0, s, seg, off, cnt);
+        hipLaunchKernelGGL((k_trace_scene<false, 4>), g, b, 0, s, seg, off, cnt, xm);
       else
-        hipLaunchKernelGGL((k_trace_scene<false, 5>), g, b, 0, s, seg, off, cnt);
+        hipLaunchKernelGGL((k_trace_scene<false, 5>), g, b, 0, s, seg, off, cnt, xm);
     }
   }
   hipError_t err = hipGetLastError();

@@ -97,10 +97,13 @@ def gather_readout(X, Y, opl, alive, dst=0, pack=None, sizes=None, async_op=Fals
 
 
 def sample_slots(n, k, device):
-    """`k` evenly spaced slot indices of a shard of n slots (all of them if n <= k), as an int64 tensor on `device`."""
+    """`k` evenly spaced slot indices of a shard of n slots (all of them if n <= k), as an int64 tensor on `device`:
+    slot j = floor(j (n-1) / (k-1)) in integer arithmetic -- strictly increasing for k <= n, first 0, last n-1, and
+    never n (a float32 linspace rounds n-1 up to n above 2^24 slots)."""
+    n, k = int(n), int(k)
     if n <= k:
         return torch.arange(n, dtype=torch.int64, device=device)
-    return torch.unique(torch.linspace(0, n - 1, k, device=device).to(torch.int64))
+    return (torch.arange(k, dtype=torch.int64, device=device) * (n - 1)) // max(k - 1, 1)
 
 
 def gather_sample(X, Y, opl, alive, slots, dst=0, pack=None):
@@ -135,6 +138,8 @@ class Exchange:
         self.slots = (sample_slots(n_slots, per_rank, backend.device) if per_rank
                       else torch.empty(0, dtype=torch.int64, device=backend.device))
         self.k = int(self.slots.numel())
+        # art_exchange_pack reads X/Y/opl/alive[slot] without a bounds check of its own
+        assert self.k == 0 or (int(self.slots.min()) >= 0 and int(self.slots.max()) < int(n_slots)), "sample slot out of range"
         self.stride = 24 + 4 * self.k
         self.send = torch.empty(self.stride, dtype=torch.float64, device=backend.device)
         self.recv = torch.empty(self.world * self.stride, dtype=torch.float64, device=backend.device)
@@ -149,3 +154,49 @@ class Exchange:
             self.recv.copy_(self.send)
         self.be.exchange_fold(self.recv, self.world, self.stride, self.stats)
         return self.stats, self.recv.view(self.world, self.stride)[:, 24:].reshape(self.world, self.k, 4)
+
+
+class ReadoutGather:
+    """The gather BASELINE.json's north_star names: every ray's read-out (X, Y, optical path: fp64; alive: 1 byte;
+    25 B/ray) from every shard to rank `dst` in ONE collective.  The four arrays are packed into one byte buffer per
+    rank ([3, n] fp64 followed by [n] uint8, padded to 8 bytes) so that a single `gather` moves them; on the xGMI mesh
+    every peer has its own link into the root, so the collective is bound by one link per peer, not by a ring.
+
+    `buffers` independent send/receive sets let the gather of step i (RCCL's stream) overlap the tracing of step i+1:
+    `start(b, ...)` waits for the previous use of set b, packs (three row copies + one byte copy on the caller's
+    stream) and enqueues the collective; `drain()` waits for everything in flight; `result(b)` returns, on dst, views
+    ([world, 3, n] fp64, [world, n] uint8) of receive set b -- rank-major = global ray order for equal shards."""
+
+    def __init__(self, n, world, rank, device, dst=0, buffers=2):
+        self.n, self.world, self.rank, self.dst = int(n), int(world), int(rank), int(dst)
+        self.nbytes = (25 * self.n + 7) // 8 * 8
+        self.send = [torch.empty(self.nbytes, dtype=torch.uint8, device=device) for _ in range(buffers)]
+        self.recv = [[torch.empty(self.nbytes, dtype=torch.uint8, device=device) for _ in range(self.world)]
+                     if self.rank == self.dst else None for _ in range(buffers)]
+        self.work = [None] * buffers
+
+    def _split(self, buf):
+        return buf[:24 * self.n].view(torch.float64).view(3, self.n), buf[24 * self.n:25 * self.n]
+
+    def start(self, b, X, Y, opl, alive):
+        if self.work[b] is not None:
+            self.work[b].wait()
+        xyo, al = self._split(self.send[b])
+        xyo[0].copy_(X); xyo[1].copy_(Y); xyo[2].copy_(opl)
+        al.copy_(alive)
+        if dist.is_available() and dist.is_initialized():
+            self.work[b] = dist.gather(self.send[b], self.recv[b], dst=self.dst, async_op=True)     # ONE collective
+        elif self.recv[b] is not None:
+            self.recv[b][0].copy_(self.send[b])
+
+    def drain(self):
+        for b, w in enumerate(self.work):
+            if w is not None:
+                w.wait()
+                self.work[b] = None
+
+    def result(self, b):
+        if self.recv[b] is None:
+            return None, None
+        parts = [self._split(t) for t in self.recv[b]]
+        return torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts])

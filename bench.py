@@ -1,47 +1,98 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark: ray-surface intersections/s on MI355X (BASELINE.json metric).
+"""bench.py -- ray-surface intersections/s on MI355X (BASELINE.json metric), one JSON line on stdout.
 
-Workload at N=1 ("relay4"): a point source (half-angle 20 mrad) of 1e7 rays through 4 toroidal mirrors
-(two f-x-f relays with the C3 scene's toroid: f = 600 mm, 80 deg incidence, 200x30 mm aperture), then the
-detector read-out -- 1e7 rays x 4 mirrors = 4e7 ray-surface intersections per step, every ray surviving.
-A step = one pass of the hot path over one resident bundle:
-    RayTracingCalculation(source, elements)  -> all 4 per-element bundles written (full history, as the API returns)
-    Detector.readout(last)                   -> X, Y, optical path per ray + the 16 global statistics
-    (N > 1) all-reduce of the 24 read-out statistics over RCCL (the delays need the GLOBAL mean path)
-Inputs are resident in HBM before the timed region and so are the results after it: at N = 1 nothing is copied to
-the host inside a step, and at N > 1 the per-ray read-out likewise stays in the HBM of the rank that owns the shard.
-Collecting it on rank 0 -- the single RCCL gather of (X, Y, optical path, alive), 25 B/ray -- is an on-demand
-operation like the D2H copy; `--gather full` puts it into every step (overlapped with the next step's tracing on
-RCCL's own stream).  Whatever the mode, the gather is executed and timed after the timed region and reported
-(`gather_to_rank0_ms`): it is per-link bound (one xGMI link per peer into the root), i.e. ~3 ms per 1e7-ray shard
-against ~1 ms of compute, which is why it is not the default step.
-N > 1 is weak scaling: every rank traces its own 1e7-ray shard (index range of a N*1e7-ray source), no collective
-on the tracing path.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config relay4|C2|C3|C4|C5]
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+Default workload ("relay4", the headline BASELINE.json's metric is quoted on): a point source (half-angle 20 mrad) of
+1e7 rays per GPU through 4 toroidal mirrors (two f-x-f relays with the C3 scene's toroid: f = 600 mm, 80 deg, 200 x 30 mm),
+then the detector read-out: 4e7 ray-surface intersections per GPU and step, every ray surviving, full per-element
+history written as the API returns it.  `--config` selects the other BASELINE.json configurations (same JSON contract):
+  C2  CONFIG_2toroidals_f-x-f: 11 chains (loop list over the toroid distance) x 1e6 rays x (mask + 2 toroids), traced by
+      ONE launch from a device-resident scene table, + 11 read-outs; the whole step replayed from a HIP graph
+  C3  CONFIG_2toroidals_twisted: 10 chains (incidence-plane twist) x 1e7 rays x (mask + 2 toroids) + read-outs, one launch
+  C4  8-element mixed chain (OAP, plane, 2 toroids, 2 planes, OAP, plane), 1.25e7 rays per GPU (1e8 over 8 GPUs)
+  C5  CONFIG_deformed geometry with a 6th-order Zernike defect, IgnoreDefects=False (perturbed normals), 1e7 rays
+
+A step = one pass of the hot path over resident bundles:
+    RayTracingCalculation(source, elements)   every per-element bundle written
+    Detector.readout(last)                    X, Y, optical path per ray + 24 global statistics (fused reductions)
+    N > 1:  + ONE RCCL all-gather per step carrying every shard's 24 statistics and an evenly spaced 20000-ray sample of
+            the read-out (the delays are relative to the GLOBAL mean path, ART/ModuleDetector.py:277; the plots draw a
+            sample) -- this is `value`;
+            and, measured in a second timed region of the same K steps, the same step + ONE RCCL gather of every ray's
+            read-out (X, Y, optical path, alive: 25 B/ray, the gather BASELINE.json's north_star names) to rank 0 in
+            every step, double-buffered behind the next step's tracing -- this is `value_full_gather`.
+Inputs are resident in HBM before the timed region; nothing is copied to the host inside a step.  N > 1 is weak scaling:
+every rank traces its own shard (index range of an N x rays source), no collective on the tracing path.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process is only a LAUNCHER -- it starts N worker
+processes of itself (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, free rendezvous port on 127.0.0.1) before
+anything touches the GPU, relays rank 0's JSON line and exits non-zero if a worker fails.  Under torchrun (WORLD_SIZE set)
+it is a worker.  A worker fails if the process group's size differs from --gpus.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_INTERSECTION = 128.0   # read 48+8+4, write 48+8+8+4
-HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ALGO_BYTES_READOUT = 88.0             # read 48+8+4, write 8+8+8+4
+HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6300 GB/s is what a copy achieves)
+CONFIGS = ("relay4", "C2", "C3", "C4", "C5")
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+# =========================================================================================== launcher (no GPU, no torch)
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_workers(n, argv):
+    """Start n workers of this script, one per GPU; relay rank 0's stdout (the JSON line); fail if any worker fails.
+    Runs before any torch.cuda / HIP call of this process: nothing here initialises the GPU."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = subprocess.PIPE if r == 0 else sys.stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
+    line, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(-9)
+    if any(rc != 0 for rc in rcs):
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        log(f"[bench] worker exit codes {rcs}: failing")
+        sys.stdout.write(line.decode(errors="replace"))
+        return 1
+    sys.stdout.write(line.decode(errors="replace"))
+    sys.stdout.flush()
+    return 0
+
+
+# =========================================================================================== scenes
 def build_scene(n_mirrors, small_n=1000):
-    """Element poses through the product's own OEPlacement (1-ray alignment traces on the GPU)."""
+    """relay<M>: element poses through the product's own OEPlacement (1-ray alignment traces on the GPU)."""
     import ART.ModuleMirror as mmirror
     import ART.ModuleSupport as msupp
     import ART.ModuleProcessing as mp
@@ -55,69 +106,150 @@ def build_scene(n_mirrors, small_n=1000):
     return chain, (R, r)
 
 
-def device_source(n, first, n_total, be):
-    """Shard [first, first+n) of an n_total-ray point source, generated on the device."""
+def scene_c2():
+    """examples/CONFIG_2toroidals_f-x-f.py:19-68: mask -> toroid -> toroid at 11 distances (loop list)."""
+    import numpy as np
+    import ART.ModuleMirror as mmirror, ART.ModuleMask as mmask, ART.ModuleSupport as msupp, ART.ModuleProcessing as mp
+    SP = {"Divergence": 50e-3 / 2, "SourceSize": 0, "Wavelength": 50e-6, "DeltaFT": 0.5, "NumberRays": 1000}
+    Mask = mmask.Mask(msupp.SupportRoundHole(20, 14e-3 * 500, 0, 0))
+    R, r = mmirror.ReturnOptimalToroidalRadii(500, 80)
+    Tor = mmirror.MirrorToroidal(R, r, msupp.SupportRectangle(150, 32))
+    chains = mp.OEPlacement(SP, [Mask, Tor, Tor], [400, 100, np.linspace(300, 700, 11).tolist()], [0, 80, -80], [0, 0, 0], "C2")
+    return [c.optical_elements for c in chains], ("point", 0.025), 500.0
+
+
+def scene_c3():
+    """examples/CONFIG_2toroidals_twisted.py:19-67: mask -> toroid -> toroid, incidence plane twisted in 10 steps."""
+    import numpy as np
+    import ART.ModuleMirror as mmirror, ART.ModuleMask as mmask, ART.ModuleSupport as msupp, ART.ModuleProcessing as mp
+    SP = {"Divergence": 50e-3 / 2, "SourceSize": 0, "Wavelength": 50e-6, "DeltaFT": 0.5, "NumberRays": 1000}
+    Mask = mmask.Mask(msupp.SupportRoundHole(30, 41e-3 / 2 * 500, 0, 0))
+    R, r = mmirror.ReturnOptimalToroidalRadii(600, 80)
+    Tor = mmirror.MirrorToroidal(R, r, msupp.SupportRectangle(200, 30))
+    chains = mp.OEPlacement(SP, [Mask, Tor, Tor], [500, 100, 600], [0, 80, -80], [0, 0, np.linspace(-90, 90, 10).tolist()], "C3")
+    return [c.optical_elements for c in chains], ("point", 0.025), 600.0
+
+
+def scene_c4():
+    """8 elements mixing OAP, plane and toroidal mirrors (not in the reference; >= 90 % survive)."""
+    import ART.ModuleMirror as mmirror, ART.ModuleSupport as msupp, ART.ModuleProcessing as mp
+    SP = {"Divergence": 0.03, "SourceSize": 0, "Wavelength": 50e-6, "DeltaFT": 0.5, "NumberRays": 1000}
+    oap = mmirror.MirrorParabolic(200, 60, msupp.SupportRound(20))
+    plane = mmirror.MirrorPlane(msupp.SupportRound(30))
+    R, r = mmirror.ReturnOptimalToroidalRadii(400, 78)
+    tor = mmirror.MirrorToroidal(R, r, msupp.SupportRectangle(180, 30))
+    oap2 = mmirror.MirrorParabolic(150, 45, msupp.SupportRound(25))
+    ch = mp.OEPlacement(SP, [oap, plane, tor, tor, plane, plane, oap2, plane], [200, 150, 250, 800, 650, 120, 140, 60],
+                        [0, 45, 78, -78, 30, -30, 0, 20], [0, 0, 0, 0, 90, 0, 0, 45], "C4")
+    return [ch.optical_elements], ("point", 0.03), 100.0
+
+
+def scene_c5():
+    """examples/CONFIG_deformed.py:19-57 geometry with a Zernike defect, perturbed normals."""
+    import ART.ModuleMirror as mmirror, ART.ModuleSupport as msupp, ART.ModuleProcessing as mp, ART.ModuleDefects as mdef
+    S = msupp.SupportRectangle(40, 40)
+    M = mmirror.MirrorParabolic(25.4, 0, S)
+    Z = mdef.Zernike(S, {(2, 1): 1e-4, (3, 1): 5e-5, (4, 2): 2e-5, (3, 3): -3e-5, (5, 2): 1e-5, (6, 3): -4e-6, (2, 0): 2.5e-5})
+    SP = {"Divergence": 0, "SourceSize": 40, "Wavelength": 800e-6, "DeltaFT": 0, "NumberRays": 1000}
+    ch = mp.OEPlacement(SP, [mmirror.DeformedMirror(M, [Z])], [15], [0], Description="C5")
+    return [ch.optical_elements], ("plane", 20.0), 25.4
+
+
+def device_source(n, first, n_total, be, kind=("point", 0.02), wavelength=50e-6):
+    """Shard [first, first+n) of an n_total-ray source (point: half-angle; plane: disk radius), generated on the device."""
+    import numpy as np
+    import torch
     from attosecondraytracing_amd.bundle import RayBundle
-    b = RayBundle.allocate(n, backend=be)
-    b.wavelength = 50e-6
-    rot = np.array([[0.0, 0.0, 1.0], [0.0, 1.0, 0.0], [-1.0, 0.0, 0.0]])  # ez -> ex
     from attosecondraytracing_amd import ModuleGeometry as mgeo
+    b = RayBundle.allocate(n, backend=be)
+    b.wavelength = wavelength
     rot = mgeo.rotation_matrix(np.array([0.0, 0.0, 1.0]), np.array([1.0, 0.0, 0.0]))
-    be.make_source(0, 0.02, rot, np.zeros(3), first, n, n_total, b.view())
+    be.make_source(0 if kind[0] == "point" else 1, kind[1], rot, np.zeros(3), first, n, n_total, b.view())
     b.intensity = torch.ones(n, dtype=torch.float64, device=be.device)
     return b
 
 
-def cpu_baseline(chain, Rr, n_sample):
-    """The CPU oracle (NumPy port of the reference algorithm) on a bounded sample of the same workload."""
+# =========================================================================================== CPU baseline (the oracle)
+def oracle_elements(elements):
+    """The product's OpticalElements as oracle elements (checker side: the oracle is test infrastructure)."""
+    import numpy as np
     from oracle import art_oracle as orc
-    R, r = Rr
-    B = orc.point_source([0.0, 0.0, 0.0], [1.0, 0.0, 0.0], 0.02, n_sample, 50e-6)
-    els = [orc.Element(orc.Optic("torus", orc.Support("rect", [200, 30]), {"R": R, "r": r}, [], "Toroidal Mirror"),
-                       np.asarray(oe.position, float), oe.normal, oe.majoraxis) for oe in chain.optical_elements]
+    kinds = {0: "plane", 1: "sphere", 2: "parabola", 3: "torus", 4: "ellipsoid", 5: "cylinder", 6: "mask"}
+    sups = {0: "round", 1: "roundhole", 2: "rect", 3: "recthole", 4: "rectrecthole"}
+    els = []
+    for oe in elements:
+        o = oe.type
+        base = getattr(o, "Mirror", o)
+        kind = kinds[o._abi_kind]
+        params = {}
+        if kind == "torus":
+            params = {"R": base.majorradius, "r": base.minorradius}
+        elif kind in ("sphere", "cylinder"):
+            params = {"R": base.radius}
+        elif kind == "parabola":
+            params = {"feff": base.feff, "offaxis_rad": base.offaxisangle, "p": base.p}
+        elif kind == "ellipsoid":
+            params = {"a": base.a, "b": base.b, "offaxis_rad": base._offaxisangle}
+        defects = [orc.ZernikeDefect(dict(d.coefficients), d.R) for d in getattr(o, "DeformationList", [])]
+        els.append(orc.Element(orc.Optic(kind, orc.Support(sups[o.support._abi_kind], o.support._abi_params()), params,
+                                         defects, o.type), np.asarray(oe.position, float), oe.normal, oe.majoraxis))
+    return els
+
+
+def cpu_baseline(elements, src_kind, det_dist, n_sample, ignore_defects):
+    """The CPU oracle (NumPy port of the reference algorithm) on a bounded sample of the same workload (one chain)."""
+    import numpy as np
+    from oracle import art_oracle as orc
+    if src_kind[0] == "point":
+        B = orc.point_source([0.0, 0.0, 0.0], [1.0, 0.0, 0.0], src_kind[1], n_sample, 50e-6)
+    else:
+        B = orc.plane_wave_disk([0.0, 0.0, 0.0], [1.0, 0.0, 0.0], src_kind[1], n_sample, 50e-6)
+    els = oracle_elements(elements)
     t0 = time.perf_counter()
-    out = orc.ray_tracing_calculation(B, els)
-    D = orc.detector_autoplace(out[-1], 600.0)
+    out = orc.ray_tracing_calculation(B, els, IgnoreDefects=ignore_defects)
+    D = orc.detector_autoplace(out[-1], det_dist)
     delays = orc.detector_delays(D, out[-1])
     dt = time.perf_counter() - t0
-    inter = n_sample + sum(len(o) for o in out[:-1])
-    return inter / dt, inter, dt, {"last": out[-1], "detector": D, "delays": delays}
+    inter = len(B) + sum(len(o) for o in out[:-1])
+    return inter / dt, inter, dt, {"source": B, "last": out[-1], "detector": D, "delays": delays}
 
 
-def parity_against(oracle_result, chain, n_sample, be, mode):
-    """The second half of BASELINE.json's metric ("fp64 delay max-rel-err"): the same n_sample-ray workload traced on
-    the GPU and compared with what the oracle just computed for the CPU baseline."""
+def parity_against(oracle_result, elements, be, mode, ignore_defects):
+    """Second half of BASELINE.json's metric ("fp64 delay max-rel-err"): the cpu_baseline sample traced on the GPU and
+    compared with what the oracle computed for it."""
+    import numpy as np
     import ART.ModuleProcessing as mp
     import ART.ModuleDetector as mdet
     from oracle import art_oracle as orc
-    ref, Do = oracle_result["last"], oracle_result["detector"]
-    src = device_source(n_sample, 0, n_sample, be)
-    last = mp.RayTracingCalculation(src, chain.optical_elements, mode=mode)[-1]
+    from attosecondraytracing_amd.bundle import RayBundle
+    ref, Do, B = oracle_result["last"], oracle_result["detector"], oracle_result["source"]
+    src = RayBundle.from_arrays(B.point, B.vector, B.number, np.ones(len(B)), 50e-6, backend=be)
+    last = mp.RayTracingCalculation(src, elements, IgnoreDefects=ignore_defects, mode=mode)[-1]
     same = bool(np.array_equal(last.numbers(), ref.number))
     det = mdet.Detector(np.asarray(Do.refpoint, float), np.asarray(Do.centre, float), np.asarray(Do.normal, float))
-    res = {"rays": n_sample, "survivor_indices_equal": same}
+    res = {"rays": len(B), "survivors": int(len(ref)), "survivor_indices_equal": same}
     if same and len(ref) > 0:
         mean_path = float(np.mean(orc.optical_paths(Do, ref)))
         d = np.asarray(det.get_Delays(last))
         res["delay_max_rel_err"] = float(np.abs(d - oracle_result["delays"]).max() / (mean_path / orc.LightSpeed * 1e15))
         res["position_max_rel_err"] = float(np.abs(last.points() - ref.point).max() / max(1.0, np.abs(ref.point).max()))
         res["path_max_rel_err"] = float(np.abs(last.paths_total() - ref.path.sum(axis=1)).max() / mean_path)
-        res["note"] = "GPU vs oracle on the cpu_baseline sample; delays and paths relative to the mean optical path"
+        res["note"] = ("GPU vs oracle on the cpu_baseline sample; delays and paths relative to the mean optical path, "
+                       "positions to max|ref|; bar 1e-10")
     return res
 
 
-def cpu_twin_allcores(chain, n_sample):
+def cpu_twin_allcores(elements, src_kind, n_sample, ignore_defects):
     """Second CPU figure, for scale: the kernels' own per-ray code compiled by g++ (oracle/twin, the test suite's CPU
-    twin) with OpenMP over rays on all host cores, on a sample of the same workload.  Not the reference's algorithm
+    twin) with OpenMP over rays on the host cores, on a sample of the same workload.  Not the reference's algorithm
     (that is cpu_baseline, the oracle): it shows what the same arithmetic does on the host CPU."""
     import ctypes as C
-    import subprocess
+    import numpy as np
     from attosecondraytracing_amd import _abi
     import ART.ModuleProcessing as mp
     from oracle import art_oracle as orc
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    # threads: the cores this process may use, at most 16 (a one-GPU box's share of its host)
-    threads = min(len(os.sched_getaffinity(0)), 16)
+    threads = min(len(os.sched_getaffinity(0)), 16)     # a one-GPU box's share of its host
     os.environ["OMP_NUM_THREADS"] = str(threads)
     lib = C.CDLL(os.path.join(ROOT, "oracle", "_twin", "libart_twin.so"))
     try:        # libgomp is usually initialised already (torch links it): set the team size through its API as well
@@ -127,8 +259,12 @@ def cpu_twin_allcores(chain, n_sample):
     lib.art_cpu_trace_chain.restype = C.c_int
     lib.art_cpu_trace_chain.argtypes = [C.POINTER(_abi.ArtElementDesc), C.c_int32, C.POINTER(_abi.ArtBundleView),
                                         C.POINTER(_abi.ArtBundleView), C.c_int64]
-    B = orc.point_source([0.0, 0.0, 0.0], [1.0, 0.0, 0.0], 0.02, n_sample, 50e-6)
-    m = len(chain.optical_elements)
+    if src_kind[0] == "point":
+        B = orc.point_source([0.0, 0.0, 0.0], [1.0, 0.0, 0.0], src_kind[1], n_sample, 50e-6)
+    else:
+        B = orc.plane_wave_disk([0.0, 0.0, 0.0], [1.0, 0.0, 0.0], src_kind[1], n_sample, 50e-6)
+    n_sample = len(B)
+    m = len(elements)
 
     def block():
         d = np.zeros((8, n_sample))
@@ -141,7 +277,9 @@ def cpu_twin_allcores(chain, n_sample):
     sd, sa, sv = block()
     sd[0:3], sd[3:6] = B.point.T, B.vector.T
     outs = [block() for _ in range(m)]
-    descs = (_abi.ArtElementDesc * m)(*[mp.element_descriptor(oe)[0] for oe in chain.optical_elements])
+    # descriptors built afresh (not the cached ones, whose defect tables are DEVICE pointers): tables in host memory
+    keep = [mp._build_descriptor(oe, ignore_defects, _HostTables()) for oe in elements]
+    descs = (_abi.ArtElementDesc * m)(*[k[0] for k in keep])
     views = (_abi.ArtBundleView * m)(*[o[2] for o in outs])
     best = None
     for _ in range(3):
@@ -154,40 +292,40 @@ def cpu_twin_allcores(chain, n_sample):
     return inter / best, inter, best, threads
 
 
-def profiled_traffic(kernel, n, mirrors, mode):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same workload
-    (profiles/rNN_relay<M>_<mode>.json, written by tools/summarize_profile.py from separate --pmc FETCH_SIZE /
-    WRITE_SIZE passes with the gfx950 x2 read correction).  None when no matching profile is committed."""
+class _HostTables:
+    """Stand-in backend for element_descriptor in cpu_twin_allcores: defect tables stay in host memory."""
+    device = "cpu"
+
+    @staticmethod
+    def from_numpy(a, dtype=None):
+        import numpy as np
+        import torch
+        return torch.from_numpy(np.array(a, copy=True))
+
+
+def profiled_traffic(config, kernel_prefix, rays):
+    """HBM bytes per launch of the kernel whose name starts with `kernel_prefix`, from the newest committed rocprofv3
+    PMC summary of this workload (profiles/rNN_<config>*.json, written by tools/summarize_profile.py from separate
+    --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 read correction).  None when no matching profile exists."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_relay{mirrors}_{mode}.json"))):
+    pats = [f"r*_{config}.json", f"r*_{config}_*.json"]
+    files = sorted({f for p in pats for f in glob.glob(os.path.join(ROOT, "profiles", p))})
+    for f in files:
         try:
             j = json.load(open(f))
         except Exception:
             continue
-        stem = "k_trace_chain<false" if mode == "chain" else "k_trace_element<3, false"
-        hits = [k for k in j.get("per_launch", {}) if k.startswith(stem)]
-        if j.get("rays_per_gpu") == n and hits:
-            best = (j["per_launch"][hits[0]]["total_bytes"], os.path.relpath(f, ROOT))
+        hits = [k for k in j.get("per_launch", {}) if k.startswith(kernel_prefix)]
+        if j.get("rays_per_gpu") == rays and hits:
+            best = (j["per_launch"][hits[0]]["total_bytes"], os.path.relpath(f, ROOT), hits[0])
     return best
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--rays", type=int, default=10_000_000, help="rays per GPU")
-    ap.add_argument("--mirrors", type=int, default=4)
-    ap.add_argument("--mode", default=None, choices=[None, "chain", "element"])
-    ap.add_argument("--gather", default="sample", choices=["sample", "ondemand", "full"],
-                    help="N > 1, what is exchanged inside every step: 'sample' (default) = the 24 statistics + an evenly "
-                         "spaced 20000-ray sample of the read-out (what the plots consume) in ONE all-gather; "
-                         "'ondemand' = the statistics only; 'full' = statistics + every ray's read-out gathered to "
-                         "rank 0, double-buffered behind the next step.  The full gather is always executed and timed "
-                         "once after the steps (gather_to_rank0_ms).")
-    ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="rays of the CPU-baseline sample (0 = skip)")
-    args = ap.parse_args()
+# =========================================================================================== worker
+def worker(args):
+    import numpy as np
+    import torch
 
     # the contract is ONE JSON line on stdout: route everything libraries print there (RCCL prints a version banner
     # on first use) to stderr until the result line is written
@@ -195,189 +333,287 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    # ART_FORCE_DIST=1 runs the multi-rank code path (process group, all-reduce, gather) even with one rank: a way to
+    # ART_BENCH_BACKEND_HOOK="module:function" (TEST HOOK, tests/test_bench_launcher.py): install another backend
+    # before the workload starts, so that the launcher and the distributed logic of this file can be exercised by CPU
+    # ranks over gloo.  Never set on a GPU box; the product itself has no such switch (attosecondraytracing_amd/_lib.py).
+    hook = os.environ.get("ART_BENCH_BACKEND_HOOK")
+    on_gpu = hook is None
+    if on_gpu:
+        torch.cuda.set_device(local)
+    # ART_FORCE_DIST=1 runs the multi-rank code path (process group, all-gather, gather) even with one rank: a way to
     # exercise the RCCL calls on a single-GPU box
-    use_dist = world > 1 or os.environ.get("ART_FORCE_DIST") == "1"
+    use_dist = env_world > 1 or os.environ.get("ART_FORCE_DIST") == "1"
+    world = 1
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(os.environ.get("ART_DIST_BACKEND", "nccl"), rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
-    if world != args.gpus and rank == 0:
-        log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+        backend = os.environ.get("ART_DIST_BACKEND", "nccl")
+        kw = {"device_id": torch.device("cuda", local)} if (on_gpu and backend == "nccl") else {}
+        dist.init_process_group(backend, rank=rank, world_size=env_world, **kw)
+        world = dist.get_world_size()       # what RCCL actually saw
+    if world != args.gpus:
+        log(f"[bench] FATAL: --gpus {args.gpus} but the process group has {world} rank(s)")
+        if use_dist:
+            dist.destroy_process_group()
+        return 3
 
-    if rank == 0 or not use_dist:
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+
+    if hook:
+        mod, fn = hook.split(":")
+        getattr(__import__(mod), fn)()
+    elif rank == 0 or not use_dist:
         import __graft_entry__
         __graft_entry__.ensure_built()       # no-op when libart_hip.so is up to date
-    if use_dist:
-        dist.barrier()
+    barrier()
     from attosecondraytracing_amd import _lib, sharding
+    from attosecondraytracing_amd.graph import SceneProgram
     import ART.ModuleProcessing as mp
     import ART.ModuleDetector as mdet
     be = _lib.get_backend()
     mode = args.mode or mp.DEFAULT_TRACE_MODE
 
-    chain, Rr = build_scene(args.mirrors)
-    els = chain.optical_elements
-    n = args.rays
+    # ------------------------------------------------------------------ workload
+    cfg = args.config
+    ignore_defects = True
+    if cfg == "relay4":
+        chain, _ = build_scene(args.mirrors)
+        element_lists, src_kind, det_dist = [chain.optical_elements], ("point", 0.02), 600.0
+        n = args.rays or 10_000_000
+        label = (f"relay{args.mirrors}: point source 20 mrad -> {args.mirrors} toroidal mirrors (f=600 mm, 80 deg, "
+                 f"200x30 mm) -> detector")
+    elif cfg == "C2":
+        element_lists, src_kind, det_dist = scene_c2()
+        n = args.rays or 1_000_000
+        label = "C2 CONFIG_2toroidals_f-x-f: 11 chains (toroid distance 300..700 mm) x (mask + 2 toroids) -> detector"
+    elif cfg == "C3":
+        element_lists, src_kind, det_dist = scene_c3()
+        n = args.rays or 10_000_000
+        label = "C3 CONFIG_2toroidals_twisted: 10 chains (incidence-plane twist -90..90 deg) x (mask + 2 toroids) -> detector"
+    elif cfg == "C4":
+        element_lists, src_kind, det_dist = scene_c4()
+        n = args.rays or 12_500_000
+        label = "C4 8-element mixed chain (OAP, plane, 2 toroids, 2 planes, OAP, plane) -> detector; 1e8 rays over 8 GPUs"
+    else:
+        element_lists, src_kind, det_dist = scene_c5()
+        n = args.rays or 10_000_000
+        ignore_defects = False
+        label = "C5 CONFIG_deformed geometry: parabola f=25.4 mm + 6th-order Zernike defect, perturbed normals -> detector"
+    n_chains, n_elems = len(element_lists), len(element_lists[0])
     n_total = n * world
     lo, hi = sharding.shard_range(n_total, rank, world)
-    src = device_source(hi - lo, lo, n_total, be)
+    assert hi - lo == n
+    wl = 800e-6 if cfg == "C5" else 50e-6
+    # one resident source shard shared by all chains (OEPlacement gives every chain of a loop list the same source)
+    src = device_source(n, lo, n_total, be, src_kind, wl)
+    batched = n_chains > 1
+    # small bundles are launch-bound: replay the whole step (trace + read-outs) from a HIP graph
+    use_graph = on_gpu and (args.graph == "on" or (args.graph == "auto" and batched))
 
-    # detector: placed once (untimed) from the mean ray of the last bundle, like ARTmain.setup_detector
-    out = mp.RayTracingCalculation(src, els, mode=mode)
-    det = mdet.Detector(np.asarray(els[-1].position, dtype=float))
-    det.autoplace(out[-1], 600.0)
-    entering = [n] + [len(o) for o in out[:-1]]
-    surv_last = len(out[-1])
-    inter_per_step_rank = int(sum(entering))
-    del out
-
-    packs, works = [], [None, None]
-    gather_each_step = use_dist and args.gather == "full"
-    sample_each_step = use_dist and args.gather == "sample"
-    exchange = sharding.Exchange(be, n, sample=20000 if sample_each_step else 0) if use_dist else None
-    sample_k = exchange.k if exchange else 0
-    last_sample = [None]
+    # detectors: placed once (untimed) from the mean ray of each chain's last bundle, like ARTmain.setup_detector
+    if batched:
+        outs0 = mp.RayTracingCalculationMany([src] * n_chains, element_lists, IgnoreDefects=ignore_defects)
+    else:
+        outs0 = [mp.RayTracingCalculation(src, element_lists[0], IgnoreDefects=ignore_defects, mode=mode)]
+    # Rank 0 places them (its shard holds the innermost rays of the Vogel spiral, so it always has survivors) and
+    # broadcasts the poses: every rank reads out on the same detector planes, as a single-process run would.
+    dets, entering, surv_last = [], 0, []
+    for els, out in zip(element_lists, outs0):
+        det = mdet.Detector(np.asarray(els[-1].position, dtype=float))
+        if rank == 0:
+            det.autoplace(out[-1], det_dist)
+        dets.append(det)
+        entering += n + sum(len(o) for o in out[:-1])
+        surv_last.append(len(out[-1]))
     if use_dist:
-        import torch.distributed as dist
-        # double-buffered gather buffers: the gather of step i (RCCL, its own stream) overlaps the tracing of
-        # step i+1; a buffer is reused only after the gather that read it has been waited for
-        for _ in range(2):
-            pk = {"send": torch.empty((3, n), dtype=torch.float64, device=be.device),
-                  "asend": torch.empty(n, dtype=torch.uint8, device=be.device)}
-            if rank == 0:
-                pk["recv"] = [torch.empty((3, n), dtype=torch.float64, device=be.device) for _ in range(world)]
-                pk["arecv"] = [torch.empty(n, dtype=torch.uint8, device=be.device) for _ in range(world)]
-            packs.append(pk)
-    step_no = [0]
-    last_stats = [None]
+        poses = [[(d.centre, d.normal, d.refpoint) for d in dets]]
+        dist.broadcast_object_list(poses, src=0)
+        dets = [mdet.Detector(np.asarray(rp, float), np.asarray(c, float), np.asarray(nn, float)) for c, nn, rp in poses[0]]
+        # index-range shards of a radially ordered source do not lose the same number of rays at a mask: the job's
+        # units per step are the sum over ranks
+        t = torch.tensor([entering, surv_last[-1]], dtype=torch.int64, device=be.device)
+        dist.all_reduce(t)
+        inter_per_step_job, surv_last_job = int(t[0].item()), int(t[1].item())
+    else:
+        inter_per_step_job, surv_last_job = int(entering), surv_last[-1]
+    inter_per_step_rank = int(entering)
+    del outs0
 
-    def step():
+    def readouts(outs):
+        return [d.readout(o[-1], sync=False) for d, o in zip(dets, outs)]
+
+    program = None
+    if batched or use_graph:
+        program = SceneProgram([src] * n_chains, element_lists, IgnoreDefects=ignore_defects,
+                               post=readouts, capture=use_graph)
+
+    def trace_and_readout():
+        if program is not None:
+            o = program.run()
+            return o, program.post_result
+        o = [mp.RayTracingCalculation(src, element_lists[0], IgnoreDefects=ignore_defects, mode=mode)]
+        return o, readouts(o)
+
+    # ------------------------------------------------------------------ N > 1 exchanges
+    exchange = sharding.Exchange(be, n, sample=20000) if use_dist else None
+    sample_k = exchange.k if exchange else 0
+    gather = sharding.ReadoutGather(n, world, rank, be.device, dst=0, buffers=2) if use_dist else None
+    state = {"stats": None, "sample": None, "step": 0}
+
+    def step(full_gather):
         # nothing in a step blocks the host: launches queue up like the steps of a training loop
-        o = mp.RayTracingCalculation(src, els, mode=mode)
-        r = det.readout(o[-1], sync=False)
+        o, r = trace_and_readout()
         if use_dist:
-            # ONE collective per step: statistics of every shard (+ a sample of every shard's read-out)
-            last_stats[0], last_sample[0] = exchange(r["stats_dev"], r["X"], r["Y"], r["opl"], o[-1].alive)
-        if gather_each_step:
-            b = step_no[0] % 2
-            step_no[0] += 1
-            if works[b] is not None:
-                for w in works[b]:
-                    w.wait()
-            works[b] = sharding.gather_readout(r["X"], r["Y"], r["opl"], o[-1].alive, 0, packs[b],
-                                               sizes=[n] * world, async_op=True)
+            # ONE collective per step: statistics of every shard + a sample of every shard's read-out (last chain)
+            state["stats"], state["sample"] = exchange(r[-1]["stats_dev"], r[-1]["X"], r[-1]["Y"], r[-1]["opl"], o[-1][-1].alive)
+            if full_gather:
+                # + ONE gather of every ray's read-out to rank 0, overlapped with the next step's tracing
+                gather.start(state["step"] % 2, r[-1]["X"], r[-1]["Y"], r[-1]["opl"], o[-1][-1].alive)
+                state["step"] += 1
         return o, r
 
-    def drain():
-        for b in range(2):
-            if works[b] is not None:
-                for w in works[b]:
-                    w.wait()
-                works[b] = None
+    def timed(full_gather, steps, collect_events):
+        for _ in range(args.warmup):
+            step(full_gather)
+        if gather:
+            gather.drain()
+        barrier()
+        sync()
+        if collect_events:
+            be.trace_events, be.readout_events = [], []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            o, r = step(full_gather)
+        t_enq = time.perf_counter() - t0     # host time to enqueue all steps (diagnostic: host-bound if ~ dt)
+        if gather:
+            gather.drain()                   # every gather has landed on rank 0 before the clock stops
+        sync()
+        barrier()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dt], dtype=torch.float64, device=be.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        ev = (be.trace_events, be.readout_events) if collect_events else None
+        if collect_events:
+            be.trace_events, be.readout_events = None, None
+        return dt, t_enq, o, r, ev
 
-    for _ in range(args.warmup):
-        step()
-    drain()
+    dt, t_enq, o, r, ev = timed(False, args.steps, on_gpu and program is None)
+    dt_full = None
     if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    be.trace_events = []          # HIP events bracketing every trace launch, on the launch stream
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        o, r = step()
-    t_enq = time.perf_counter() - t0   # host time to enqueue all steps (diagnostic: host-bound if ~ dt)
-    drain()                       # every gather has landed on rank 0 before the clock stops
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=be.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    evs, be.trace_events = be.trace_events, None
-    gather_ms = None
-    if use_dist:
-        # the on-demand collection of the last step's read-out on rank 0, timed (second of two runs)
-        for rep in range(2):
-            torch.cuda.synchronize()
-            dist.barrier()
-            tg = time.perf_counter()
-            XYO, alv = sharding.gather_readout(r["X"], r["Y"], r["opl"], o[-1].alive, 0, packs[0], sizes=[n] * world)
-            torch.cuda.synchronize()
-            dist.barrier()
-            gather_ms = (time.perf_counter() - tg) * 1e3
-        if rank == 0 and sample_each_step:
-            S = last_sample[0]
-            assert S.shape == (world, sample_k, 4)
-            own = torch.stack([r["X"], r["Y"], r["opl"]]).index_select(1, exchange.slots).T
-            assert torch.equal(S[0][:, 0:3], own)                        # rank 0's own part of the last step's sample
+        dt_full, _, o, r, _ = timed(True, args.steps, False)
         if rank == 0:
-            assert XYO.shape == (3, n * world) and int(alv.sum().item()) > 0
-            assert torch.equal(XYO[:, :n], torch.stack([r["X"], r["Y"], r["opl"]]))   # rank 0's own shard, in place
-    stats_host = (last_stats[0] if use_dist else r["stats_dev"]).cpu().numpy()
-    assert stats_host[0] == surv_last * (world if use_dist else 1) and np.isfinite(stats_host[1])
-    launches = 1 if mode == "chain" else args.mirrors
-    assert len(evs) == launches * args.steps
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))   # average duration of one trace launch
-    trace_ms = kernel_ms * launches
-    inter_per_launch = inter_per_step_rank / launches
-    achieved = ALGO_BYTES_PER_INTERSECTION * inter_per_launch / (kernel_ms * 1e-3) / 1e9
+            XYO, alv = gather.result((state["step"] - 1) % 2)
+            assert XYO.shape == (world, 3, n) and int(alv.sum().item()) > 0
+            assert torch.equal(XYO[0], torch.stack([r[-1]["X"], r[-1]["Y"], r[-1]["opl"]]))   # rank 0's own shard
+            S = state["sample"]
+            assert S.shape == (world, sample_k, 4)
+            own = torch.stack([r[-1]["X"], r[-1]["Y"], r[-1]["opl"]]).index_select(1, exchange.slots).T
+            assert torch.equal(S[0][:, 0:3], own)              # rank 0's own part of the last step's sample
+    stats_host = (state["stats"] if use_dist else r[-1]["stats_dev"]).cpu().numpy()
+    assert stats_host[0] == surv_last_job and np.isfinite(stats_host[1]), (stats_host[0], surv_last_job)
+
+    # ------------------------------------------------------------------ kernel durations (HIP events on the launch stream)
+    kernel_ms = readout_ms = None
+    launches = 1
+    if on_gpu:
+        if ev is None:
+            # graph-replayed steps cannot carry events inside the graph: the same launches, eager, right after the timed
+            # region (same resident data)
+            be.trace_events, be.readout_events = [], []
+            for _ in range(min(args.steps, 20)):
+                program._launch()
+            sync()
+            ev = (be.trace_events, be.readout_events)
+            be.trace_events, be.readout_events = None, None
+        tr_ev, ro_ev = ev
+        steps_ev = len(ro_ev) // n_chains
+        launches = max(1, len(tr_ev) // max(steps_ev, 1))
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in tr_ev]))       # average duration of one trace launch
+        readout_ms = float(np.mean([a.elapsed_time(b) for a, b in ro_ev]))      # one read-out (kernel + 24-slot fold)
 
     if rank == 0:
-        kname = "k_trace_chain<false, 5>" if mode == "chain" else "k_trace_element<ART_TORUS, false>"
-        tr = profiled_traffic(kname, n, args.mirrors, mode)
-        value = inter_per_step_rank * world * args.steps / dt
+        value = inter_per_step_job * args.steps / dt
         res = {
             "metric": "ray-surface intersections/s", "value": value, "unit": "intersections/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"relay{args.mirrors}: point source 20 mrad -> {args.mirrors} toroidal mirrors "
-                                   f"(f=600 mm, 80 deg, 200x30 mm) -> detector; {n} rays/GPU x {args.mirrors} mirrors "
-                                   f"= {inter_per_step_rank} intersections/GPU/step; full per-element history",
-                       "rays_per_gpu": n, "mirrors": args.mirrors, "trace_mode": mode,
+            "config": {"workload": f"{label}; {n} rays/GPU x {n_elems} elements x {n_chains} chain(s) = "
+                                   f"{inter_per_step_rank} intersections/step on rank 0, {inter_per_step_job} on all "
+                                   f"{world} rank(s); full per-element history",
+                       "name": cfg, "rays_per_gpu": n, "elements": n_elems, "chains": n_chains,
+                       "trace_mode": "scene (one launch for all chains)" if program is not None else mode,
+                       "hip_graph": bool(use_graph), "world_size_seen": world,
                        "step": "RayTracingCalculation + Detector.readout"
-                               + (" + ONE RCCL all-gather of the 24 statistics of every shard, folded on the device"
-                                  if use_dist else "")
-                               + (f" (it also carries a {sample_k * world}-ray sample of the read-out)" if sample_each_step else "")
-                               + (" + RCCL gather of the per-ray read-out to rank 0 (overlapped)" if gather_each_step else "")},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None if tr is None else tr[0],
-                         "traffic_source": None if tr is None else tr[1] + " (rocprofv3 PMC, bytes per launch)",
-                         "kernel": kname,
-                         "kernel_ms": kernel_ms, "intersections_per_launch": inter_per_launch,
-                         "algorithmic_bytes_per_intersection": ALGO_BYTES_PER_INTERSECTION,
-                         # what the memory system really delivers: counted bytes / live kernel time.  `frac` above is
-                         # on the ALGORITHMIC 128 B per intersection and can exceed 1 for the fused
-                         # kernel, which reads a ray once per chain instead of once per element.
-                         "hbm_real_GBps": None if tr is None else tr[0] / (kernel_ms * 1e-3) / 1e9,
-                         "hbm_real_frac": None if tr is None else tr[0] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "trace_only_intersections_per_s": inter_per_step_rank / (trace_ms * 1e-3),
+                               + (f" + ONE RCCL all-gather of every shard's 24 statistics and a {sample_k * world}-ray sample "
+                                  f"of the read-out, folded on the device" if use_dist else ""),
+                       "step_full_gather": None if not use_dist else
+                       "the same + ONE RCCL gather of every ray's read-out (X, Y, optical path, alive; 25 B/ray) to rank 0 in "
+                       "every step, double-buffered behind the next step's tracing (value_full_gather)"},
+            "value_full_gather": None if dt_full is None else inter_per_step_job * args.steps / dt_full,
+            "ms_per_step_full_gather": None if dt_full is None else dt_full / args.steps * 1e3,
             "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
-            "gather_to_rank0_ms": gather_ms,
-            "gather_note": None if gather_ms is None else
-            f"one gather of the {n * world}-ray read-out (25 B/ray) to rank 0, run after the timed steps; "
-            f"{'inside' if gather_each_step else 'not inside'} the timed step"
-            + (f"; every timed step all-gathers the statistics and a {sample_k * world}-ray sample (32 B/ray) in one "
-               f"collective" if sample_each_step else ""),
         }
-        if world == 1 and args.cpu_sample > 0:
-            v, inter, secs, oracle_result = cpu_baseline(chain, Rr, args.cpu_sample)
-            res["parity"] = parity_against(oracle_result, chain, args.cpu_sample, be, mode)
+        if on_gpu:
+            inter_per_launch = inter_per_step_rank / launches
+            defects = any(len(getattr(oe.type, "DeformationList", [])) > 0 for els in element_lists for oe in els)
+            kprefix = ("k_trace_scene<" if program is not None else
+                       ("k_trace_chain<" if mode == "chain" else "k_trace_element<"))
+            if program is not None or mode == "chain":
+                kprefix += "true" if defects else "false"
+            tr = profiled_traffic(cfg, kprefix, n)
+            algo = ALGO_BYTES_PER_INTERSECTION * inter_per_launch / (kernel_ms * 1e-3) / 1e9
+            # what the kernel moves by construction: every chain reads its source once (57 B/slot) and writes 65 B per
+            # slot and element (dead slots: only the alive byte) -- the PMC counters agree with it to 0.1 % on relay4
+            counted = None if tr is None else tr[0] / (kernel_ms * 1e-3) / 1e9
+            res["roofline"] = {
+                "bound": "hbm", "kernel": tr[2] if tr else kprefix + "...>",
+                # `achieved`/`frac`: COUNTED HBM bytes (rocprofv3 PMC, committed profile) / live kernel time / peak -- what
+                # the memory system really delivers.  The fused kernel reads a ray once per chain, so it moves fewer
+                # bytes than the 128 B/intersection of SURVEY 8(d): that algorithmic figure is kept beside it.
+                "achieved": counted, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": None if counted is None else counted / HBM_PEAK_GBS,
+                "traffic": None if tr is None else tr[0],
+                "traffic_source": None if tr is None else tr[1] + " (rocprofv3 PMC, bytes per launch)",
+                "achieved_algorithmic": algo, "frac_algorithmic": algo / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_intersection": ALGO_BYTES_PER_INTERSECTION,
+                "kernel_ms": kernel_ms, "launches_per_step": launches, "intersections_per_launch": inter_per_launch,
+                "frac_of_achievable_6300": None if counted is None else counted / 6300.0,
+            }
+            rays_ro = n
+            tro = profiled_traffic(cfg, "k_detector_readout", n)
+            algo_ro = ALGO_BYTES_READOUT * rays_ro / (readout_ms * 1e-3) / 1e9
+            counted_ro = None if tro is None else tro[0] / (readout_ms * 1e-3) / 1e9
+            res["roofline_readout"] = {
+                "bound": "hbm", "kernel": "k_detector_readout (+ k_readout_final)", "achieved": counted_ro,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if counted_ro is None else counted_ro / HBM_PEAK_GBS,
+                "traffic": None if tro is None else tro[0],
+                "traffic_source": None if tro is None else tro[1] + " (rocprofv3 PMC, bytes per launch)",
+                "achieved_algorithmic": algo_ro, "frac_algorithmic": algo_ro / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_ray": ALGO_BYTES_READOUT, "kernel_ms": readout_ms, "launches_per_step": n_chains,
+            }
+            res["trace_only_intersections_per_s"] = inter_per_step_rank / (kernel_ms * launches * 1e-3)
+        if world == 1 and args.cpu_sample > 0 and on_gpu:
+            v, inter, secs, oracle_result = cpu_baseline(element_lists[-1], src_kind, det_dist, args.cpu_sample, ignore_defects)
+            res["parity"] = parity_against(oracle_result, element_lists[-1], be, mode, ignore_defects)
             res["cpu_baseline"] = {"value": v, "unit": "intersections/s", "cores": 1, "kind": "port",
                                    "sample": f"oracle/art_oracle.py (NumPy, batched LAPACK eigvals; single thread) on "
-                                             f"{args.cpu_sample} rays x {args.mirrors} mirrors + detector = {inter} "
+                                             f"{args.cpu_sample} rays x {n_elems} elements of one chain + detector = {inter} "
                                              f"intersections in {secs:.1f} s; host has {os.cpu_count()} cores"}
             try:
-                v2, inter2, secs2, thr = cpu_twin_allcores(chain, min(args.cpu_sample, 4_000_000))
+                v2, inter2, secs2, thr = cpu_twin_allcores(element_lists[-1], src_kind, min(args.cpu_sample, 4_000_000),
+                                                           ignore_defects)
                 res["cpu_twin_allcores"] = {"value": v2, "unit": "intersections/s", "cores": thr,
                                             "note": f"oracle/twin: the kernels' per-ray code built by g++ -O2 -fopenmp, "
                                                     f"{inter2} intersections in {secs2:.2f} s (best of 3); for scale only"}
@@ -389,7 +625,29 @@ def main():
         os.dup2(2, 1)
     if use_dist:
         dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="relay4", choices=CONFIGS, help="BASELINE.json configuration (default: the headline)")
+    ap.add_argument("--rays", type=int, default=0, help="rays per GPU (0 = the configuration's own size)")
+    ap.add_argument("--mirrors", type=int, default=4, help="relay4 only: number of toroidal mirrors")
+    ap.add_argument("--mode", default=None, choices=[None, "chain", "element"])
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the step from a HIP graph (auto: for the multi-chain configurations)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="rays of the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args(argv)
+    if args.cpu_sample < 0:
+        args.cpu_sample = {"relay4": 2_000_000, "C2": 1_000_000, "C3": 1_000_000, "C4": 400_000, "C5": 150_000}[args.config]
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_workers(args.gpus, argv)      # nothing above or in there touches the GPU
+    return worker(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

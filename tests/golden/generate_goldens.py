@@ -12,7 +12,10 @@ packages the reference imports; they are replaced by the stand-ins in `tests/gol
   * `quaternion` (numpy-quaternion): a 60-line Hamilton-algebra class of ours.  Consequence: the
     rotation arithmetic inside `RotationAroundAxis` (ART/ModuleGeometry.py:321-329) is the
     stand-in's, everything else (np.roots solvers, acceptance rules, reflection, masks, detector,
-    Zernike recurrences) is executed reference code + NumPy/SciPy.
+    Zernike recurrences) is executed reference code + NumPy/SciPy.  The stand-in is pinned independently:
+    tests/test_quaternion_standin.py runs that call sequence on it against SciPy's Rotation.from_rotvec and an
+    80-bit Rodrigues formula (<= 4 ulp (1 + |angle|) from the truth, as accurate as SciPy itself), and main()
+    the __main__ block below refuses to generate fixtures if a spot check of the same comparison fails.
   * `pyvista`, `pyvistaqt`, `colorcet`: empty modules (only used inside plot functions).
 Tier-A fixtures (`zernike_*.npz`) come from reference modules that import with NO stand-in
 (`ART/recursive_zernike_generator.py`, `ART/ModuleDefects.py`).
@@ -510,7 +513,20 @@ def scene_autofocus():
                extra={"autofocus": res, "NA": float(na), "Airy": float(mp.ReturnAiryRadius(50e-6, na))})
 
 
+def check_standin_rotations():
+    """Spot check before anything is generated: the reference's RotationAroundAxis (ART/ModuleGeometry.py:321-329),
+    running on the stand-in quaternion class, against SciPy (the full comparison: tests/test_quaternion_standin.py)."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(7)
+    for ang in list(rng.uniform(-np.pi, np.pi, 200)) + [0.0, 1e-12, np.pi, np.pi - 1e-12]:
+        axis, v = rng.normal(size=3), rng.normal(size=3)
+        got = mgeo.RotationAroundAxis(axis, ang, v)
+        ref = Rotation.from_rotvec(ang * axis / np.linalg.norm(axis)).apply(v)
+        assert np.abs(got - ref).max() <= 6 * np.finfo(float).eps * (1 + abs(ang)) * np.linalg.norm(v), (ang, got, ref)
+
+
 if __name__ == "__main__":
+    check_standin_rotations()
     np.random.seed(12345)
     t0 = time.perf_counter()
     scene_zernike_tierA()

@@ -1,0 +1,63 @@
+"""CPU: `bench.py --gpus N` as the driver calls it (no torchrun, no WORLD_SIZE) must start N ranks by itself, run the
+N > 1 step on every rank and report the world size the process group really had.  The ranks here are CPU processes over
+gloo with the test-only twin backend installed through bench.py's test hook; the launcher, the rendezvous, the
+per-step all-gather, the full read-out gather and the JSON contract are the code the GPU run executes."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ART_DIST_BACKEND="gloo", ART_BENCH_BACKEND_HOOK="twin_backend:install", OMP_NUM_THREADS="2",
+               PYTHONPATH=os.path.join(ROOT, "tests") + os.pathsep + env.get("PYTHONPATH", ""))
+    env.update(extra)
+    return env
+
+
+def _run(args, **extra):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=_env(**extra), capture_output=True,
+                          text=True, timeout=600)
+
+
+def test_bench_gpus_2_spawns_two_ranks():
+    p = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--rays", "5000", "--cpu-sample", "0"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["world_size_seen"] == 2 and j["scaling"] == "weak"
+    assert j["steps"] == 3 and j["warmup"] == 1 and j["unit"] == "intersections/s"
+    # both N > 1 numbers are on the line: the statistics + sample step and the full-gather step
+    assert j["value"] > 0 and j["value_full_gather"] > 0 and j["ms_per_step_full_gather"] > 0
+    assert "all-gather" in j["config"]["step"] and "gather" in j["config"]["step_full_gather"]
+    # whole-job aggregate: 2 ranks x 5000 rays x 4 mirrors per step
+    inter = 2 * 5000 * 4
+    assert abs(j["value"] - inter * 3 / (j["ms_per_step"] * 3e-3)) <= 1e-6 * j["value"]
+
+
+def test_bench_multichain_config_two_ranks():
+    """A loop-list configuration (C2: 11 chains in one scene-table launch) through the same launcher."""
+    p = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "C2", "--rays", "2000", "--cpu-sample", "0"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    j = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    assert j["n_gpus"] == 2 and j["config"]["chains"] == 11 and j["config"]["name"] == "C2"
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus():
+    # as a torchrun worker (WORLD_SIZE set) whose group has 1 rank while --gpus says 2: must fail, not report n_gpus 1
+    p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--rays", "1000", "--cpu-sample", "0"],
+             WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert "process group has 1 rank" in p.stderr
+
+
+def test_bench_single_rank_line_on_cpu_twin():
+    p = _run(["--steps", "2", "--warmup", "1", "--rays", "4000", "--cpu-sample", "0"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    j = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    assert j["n_gpus"] == 1 and j["value_full_gather"] is None and j["config"]["name"] == "relay4"

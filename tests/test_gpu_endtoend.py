@@ -1,0 +1,165 @@
+"""GPU (-m gpu): SURVEY 8 rows f4 and the end-to-end path on the HIP backend.
+  * archives: save_compressed / load_compressed (ART/ModuleProcessing.py:612-633) of DEVICE bundles -- bit-equal
+    arrays, lazy re-upload, usable for further tracing;
+  * plot adaptors fed from device bundles (SpotDiagram, DelayGraph, MirrorProjection; ART/ModuleAnalysisAndPlots.py:
+    62-129, :133-673): the data inside the figures against the oracle;
+  * ARTmain.run_ART / ARTmain.main (ART/ARTmain.py:248-342) on fixture-built chains against the fixtures'
+    ETransmission / SpotSizeSD / DurationSD, with and without autofocus, single chain and loop list."""
+import matplotlib
+matplotlib.use("Agg")
+import numpy as np
+import pytest
+
+from conftest import load_golden, report
+import parity_common as pc
+import test_plots as tp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    import __graft_entry__
+    from attosecondraytracing_amd import _lib
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    __graft_entry__.ensure_built()
+    _lib._BACKEND = None
+    be = _lib.get_backend()
+    assert be.name == "hip"
+    return be
+
+
+@pytest.fixture(scope="module")
+def scene(hip):
+    sc = tp.build_plot_scene()
+    assert sc["last"].data.is_cuda          # the figures below are fed from device-resident bundles
+    return sc
+
+
+def test_gpu_spot_diagram_shows_the_reference_points(scene):
+    tp.test_spot_diagram_shows_the_reference_points(scene)
+
+
+def test_gpu_spot_diagram_key_press_moves_the_detector(scene):
+    tp.test_spot_diagram_key_press_moves_the_detector(scene)
+
+
+def test_gpu_delay_graph_and_mirror_projection(scene):
+    tp.test_delay_graph_and_mirror_projection(scene)
+
+
+def test_gpu_large_bundles_are_down_sampled(scene, monkeypatch):
+    tp.test_large_bundles_are_down_sampled(scene, monkeypatch)
+
+
+def test_gpu_archive_round_trip_of_device_bundles(hip, tmp_path, monkeypatch):
+    import torch
+    import ART.ModuleProcessing as mp
+    import ART.ModuleOpticalChain as moc
+    import ART.ModuleDetector as mdet
+    monkeypatch.chdir(tmp_path)
+    scene, a = load_golden("c2_fxf_chain05")
+    chain = moc.OpticalChain(pc.source_bundle(a, scene), pc.build_elements(scene, a), "archive me")
+    out = chain.get_output_rays()
+    assert out[-1].data.is_cuda
+    d = scene["detector"]
+    D = mdet.Detector(np.array(d["refpoint"]), np.array(d["centre"]), np.array(d["normal"]))
+    mp.save_compressed({"OpticalChain": [chain], "Detector": [D], "x": 1.5}, "kept")
+    back = mp.load_compressed("kept_0")
+    ch = back["OpticalChain"][0]
+    assert back["x"] == 1.5 and ch.description == "archive me"
+    for o2, o in zip(ch._output_rays, out):
+        assert not o2.data.is_cuda and o2._backend is None                 # archived as host arrays ...
+        assert np.array_equal(o2.data.numpy(), o.data.cpu().numpy(), equal_nan=True)     # ... bit for bit
+        assert np.array_equal(o2.alive.numpy(), o.alive.cpu().numpy())
+    last2 = ch._output_rays[-1]
+    assert len(last2) == len(out[-1]) == 490                              # first use moves it back to the device
+    assert last2.data.is_cuda and last2.backend is hip
+    assert np.array_equal(last2.points(), out[-1].points())
+    assert np.array_equal(last2.path_segments(), out[-1].path_segments())
+    assert [r.number for r in last2[:3]] == [r.number for r in out[-1][:3]]
+    # the restored chain is a working chain: its cache is still valid, a modified copy re-traces on the device
+    pc.check_outputs(ch.get_output_rays(), a, scene)
+    D2 = back["Detector"][0]
+    assert np.abs(D2.get_Delays(last2) - a["det_delays"]).max() <= 1e-10 * np.mean(D2.get_OpticalPaths(last2)) / mdet.LightSpeed * 1e15
+    again = mp.RayTracingCalculation(ch.source_rays, ch.optical_elements)
+    assert torch.equal(again[-1].alive, out[-1].alive)
+    m = out[-1].alive.bool()
+    assert torch.equal(again[-1].data[:, m], out[-1].data[:, m])
+
+
+_ANA = {"verbose": False, "plot_Render": False, "plot_SpotDiagram": False, "plot_DelaySpotDiagram": False,
+        "plot_IntensitySpotDiagram": False, "plot_IncidenceSpotDiagram": False, "plot_DelayGraph": False,
+        "plot_IntensityGraph": False, "plot_IncidenceGraph": False, "plot_DelayMirrorProjection": False,
+        "plot_IntensityMirrorProjection": False, "plot_IncidenceMirrorProjection": False, "DrawAiryAndFourier": True,
+        "save_results": False}
+
+
+def _options(scene, auto):
+    SP = {"Divergence": 0.025, "SourceSize": 0, "Wavelength": scene["wavelength"], "DeltaFT": 0.5,
+          "NumberRays": scene["n_source"]}
+    det = {"ReflectionNumber": -1, "ManualDetector": False, "DistanceDetector": scene["detector"]["distance"],
+           "AutoDetectorDistance": auto, "OptFor": "intensity"}
+    return SP, det, dict(_ANA)
+
+
+@pytest.mark.parametrize("name", ["c3_twisted_chain00", "c3_twisted_chain04", "c3_twisted_chain09", "c2_fxf_chain05"])
+def test_gpu_run_art_matches_fixture_summary(hip, name):
+    """ARTmain.run_ART on the HIP backend (ART/ARTmain.py:248-300): trace, energy transmission, automatic detector
+    placement, result summary -- against what the reference printed for the same chain."""
+    import ARTmain
+    import ART.ModuleOpticalChain as moc
+    import ART.ModuleDetector as mdet
+    scene, a = load_golden(name)
+    chain = moc.OpticalChain(pc.source_bundle(a, scene), pc.build_elements(scene, a), scene["description"])
+    SP, det, ana = ARTmain.complete_defaults(*_options(scene, False))
+    ch, D, ET, spot, dur = ARTmain.run_ART(chain, SP, det, ana)
+    assert ch is chain and ch.get_output_rays()[-1].data.is_cuda
+    d = scene["detector"]
+    scale = max(1.0, np.abs(np.array(d["centre"])).max())
+    assert np.abs(D.centre - d["centre"]).max() <= 1e-10 * scale and np.abs(D.normal - d["normal"]).max() <= 1e-10
+    mean_t_fs = np.mean(D.get_OpticalPaths(ch.get_output_rays()[-1])) / mdet.LightSpeed * 1e15
+    e = (abs(ET - scene["ETransmission"]), abs(spot - scene["SpotSizeSD"]) / scale, abs(dur - scene["DurationSD"]) / mean_t_fs)
+    report(f"[run_ART {name}] |dETransmission| {e[0]:.1e} %  spot {e[1]:.1e} of scene  duration {e[2]:.1e} of travel time")
+    assert e[0] <= 1e-9 and e[1] <= 1e-10 and e[2] <= 1e-10, e
+
+
+def test_gpu_run_art_with_autofocus(hip):
+    """AutoDetectorDistance=True (ARTmain.py:273-283 -> FindOptimalDistance, ART/ModuleProcessing.py:369-460): all rays,
+    intensity-weighted, on the device; against the reference's optimum for the same rays (fixture autofocus_c3)."""
+    import ARTmain
+    import ART.ModuleOpticalChain as moc
+    scene, a = load_golden("autofocus_c3")
+    chain = moc.OpticalChain(pc.source_bundle(a, scene), pc.build_elements(scene, a))
+    SP, det, ana = ARTmain.complete_defaults(*_options(scene, True))
+    _, D, ET, spot, dur = ARTmain.run_ART(chain, SP, det, ana)
+    ref = scene["autofocus"]["intensity_1"]             # [distance, spot SD, duration SD], intensity-weighted
+    assert abs(D.get_distance() - ref[0]) <= 2e-3       # the scan's last step is 1e-3 mm
+    assert abs(spot - ref[1]) <= 1e-6 and abs(dur - ref[2]) <= 1e-4
+    assert abs(ET - scene["ETransmission"]) <= 1e-9
+
+
+def test_gpu_artmain_main_over_a_loop_list(hip):
+    """ARTmain.main on a list of chains (ARTmain.py:304-342): the loop list is traced by ONE scene-table launch
+    (moc.trace_chain_list), then analysed chain by chain; kept_data against the three C3 fixtures."""
+    import ARTmain
+    import ART.ModuleOpticalChain as moc
+    import ART.ModuleProcessing as mp
+    names = ("c3_twisted_chain00", "c3_twisted_chain04", "c3_twisted_chain09")
+    scenes = [load_golden(n) for n in names]
+    chains = [moc.OpticalChain(pc.source_bundle(a, s), pc.build_elements(s, a), s["description"],
+                               "twist", float(s["loop_variable_value"])) for s, a in scenes]
+    calls = []
+    real = mp.RayTracingCalculation
+    mp.RayTracingCalculation = lambda *x, **k: calls.append(1) or real(*x, **k)
+    try:
+        kept = ARTmain.main(chains, *_options(scenes[0][0], False))
+    finally:
+        mp.RayTracingCalculation = real
+    assert not calls, "the loop list must go through the batched launch"
+    for k, (s, a) in enumerate(scenes):
+        assert abs(kept["ETransmission"][k] - s["ETransmission"]) <= 1e-9
+        assert abs(kept["SpotSizeSD"][k] - s["SpotSizeSD"]) <= 1e-10 * 2000
+        assert abs(kept["DurationSD"][k] - s["DurationSD"]) <= 1e-10 * 1e7
+        pc.check_outputs(kept["OpticalChain"][k].get_output_rays(), a, s)

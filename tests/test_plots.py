@@ -22,6 +22,12 @@ def twin():
 
 @pytest.fixture(scope="module")
 def scene(twin):
+    return build_plot_scene()
+
+
+def build_plot_scene():
+    """Golden chain c3_twisted_chain04 traced by whatever backend is active + the oracle's view of the same scene
+    (shared with the GPU suite, tests/test_gpu_endtoend.py)."""
     import ART.ModuleProcessing as mp
     import ART.ModuleDetector as mdet
     import ART.ModuleOpticalChain as moc

@@ -101,6 +101,22 @@ def _worker(rank, world, port, n_total, q):
         if rank == 0:
             off = sizes[0]
             assert torch.equal(smp[1][:, 0:3], XYO[:, off + ex.slots].T)    # the other rank's sample, global order
+        # the north_star's gather as ONE collective (what bench.py times as value_full_gather): equal shards, two
+        # buffer sets used alternately
+        nmin = min(sizes)
+        rg = sharding.ReadoutGather(nmin, world, rank, torch.device("cpu"), dst=0, buffers=2)
+        for b in (0, 1, 0):
+            rg.start(b, r["X"][:nmin], r["Y"][:nmin], r["opl"][:nmin], last.alive[:nmin])
+        rg.drain()
+        got, galive = rg.result(0)
+        if rank == 0:
+            assert got.shape == (world, 3, nmin) and galive.shape == (world, nmin)
+            off = 0
+            for kk in range(world):
+                assert torch.equal(got[kk], XYO[:, off:off + nmin]) and torch.equal(galive[kk], alive[off:off + nmin])
+                off += sizes[kk]
+        else:
+            assert got is None and galive is None
         if rank == 0:
             q.put((stats.numpy(), XYO.numpy(), alive.numpy()))
         else:
@@ -153,3 +169,26 @@ def test_shard_ranges_partition():
             assert edges[0][0] == 0 and edges[-1][1] == n
             assert all(edges[i][1] == edges[i + 1][0] for i in range(w - 1))
             assert max(b - a for a, b in edges) - min(b - a for a, b in edges) <= 1
+
+
+def test_sample_slots_are_exact_integers():
+    """Evenly spaced sample slots for shards above 2^24 slots: a float32 linspace rounds n-1 up to n there (reading
+    one element past the arrays in art_exchange_pack); the integer form never does."""
+    from attosecondraytracing_amd.sharding import sample_slots
+    dev = torch.device("cpu")
+    for n in (20_000_000, 40_000_000, 2 ** 25, 2 ** 25 + 3, 2 ** 24 + 1, 10 ** 8 + 7, 20001):
+        for k in (2, 2500, 20000):
+            s = sample_slots(n, k, dev)
+            assert s.dtype == torch.int64 and s.numel() == k
+            assert int(s[0]) == 0 and int(s[-1]) == n - 1 and int(s.max()) < n
+            assert bool((s[1:] > s[:-1]).all())
+    assert torch.equal(sample_slots(5, 10, dev), torch.arange(5))
+    assert torch.equal(sample_slots(7, 1, dev), torch.zeros(1, dtype=torch.int64))
+
+
+def test_exchange_refuses_out_of_range_slots():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from twin_backend import TwinBackend
+    from attosecondraytracing_amd import sharding
+    ex = sharding.Exchange(TwinBackend(), 2 ** 25 + 3, sample=20000)
+    assert int(ex.slots.max()) == 2 ** 25 + 2

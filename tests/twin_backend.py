@@ -262,3 +262,10 @@ class TwinBackend:
         s = (C.c_double * 3)(*[float(v) for v in np.asarray(S).reshape(3)])
         assert self.lib.art_cpu_make_extended_source(float(radius), float(divergence), int(n_points), int(per), r, s,
                                                      first, n, C.byref(view)) == 0
+
+
+def install():
+    """Make the twin the process-wide backend (tests; also the target of bench.py's ART_BENCH_BACKEND_HOOK test hook)."""
+    from attosecondraytracing_amd import _lib
+    _lib._BACKEND = TwinBackend()
+    return _lib._BACKEND
