@@ -61,11 +61,12 @@ __device__ __forceinline__ int64_t tile_of(const unsigned b, const unsigned nb, 
   return (int64_t)(((b >> span_sh) << span_sh) + ((r & 7u) << sh) + (r >> 3));
 }
 
-// ART_XCD_MAP: "0" identity, "-1" eighths, "k" runs of 2^(k-1) tiles per XCD (default below)
+// ART_XCD_MAP: "0" identity (default: no mapping measured faster than run-to-run noise), "-1" eighths, "k" runs of
+// 2^(k-1) tiles per XCD
 inline int xcd_map() {
   static const int v = [] {
     const char* e = getenv("ART_XCD_MAP");
-    const int x = e ? atoi(e) : -1;
+    const int x = e ? atoi(e) : 0;
     return (x < -1 || x > 16) ? 0 : x;
   }();
   return v;
@@ -917,11 +918,8 @@ inline int chain_waves() {
   const char* wv = getenv("ART_CHAIN_WAVES");
   return wv ? atoi(wv) : 5;
 }
-// the fused kernel WITH defects: 4 waves (126 VGPRs, no spills) or 5 (96 VGPRs, 25 spilled dwords); ART_DEFECT_WAVES
-inline int defect_waves() {
-  const char* wv = getenv("ART_DEFECT_WAVES");
-  return wv ? atoi(wv) : 4;
-}
+// (the fused kernel WITH defects stays at 4 waves: 126 VGPRs without spills; at 5 waves it spills 25 dwords and
+// measured 0.40 instead of 0.23 ms per 1e7 rays on the C5 surface)
 }  // namespace
 
 int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundleView* in, const ArtBundleView* outs,
@@ -937,6 +935,9 @@ int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundl
   for (int k = 0; k < n_elems; ++k)
     if (outs[k].alive != nullptr && !view_ok(&outs[k])) return fail(ART_ERR_BAD_ARG, "history view partially NULL");
   if (!view_ok(&outs[n_elems - 1])) return fail(ART_ERR_BAD_ARG, "the last output view is mandatory");
+  // a chain of ONE element is the per-element kernel's job: compiled for the optic's kind, it needs fewer registers
+  // than the fused kernel's run-time dispatch (5 instead of 4 waves per SIMD with defects) -- same results
+  if (n_elems == 1) return art_trace_element(&elems[0], in, &outs[0], n, stream);
   hipStream_t s = (hipStream_t)stream;
   for (int k0 = 0; k0 < n_elems; k0 += kChainMax) {
     const int m = (n_elems - k0 < kChainMax) ? n_elems - k0 : kChainMax;
@@ -967,10 +968,7 @@ int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundl
 #endif
       const int xm = xcd_map();
       const dim3 g(grid_stream_mapped(cnt, xm)), b(kBlock);
-      if ((a.flags & 1) && defect_waves() == 5)
-        hipLaunchKernelGGL((k_trace_chain<true, 5>), dim3(kDefectLoop ? grid_for(cnt) : grid_stream_mapped(cnt, xm)), b, lds,
-                           s, a, cnt, kDefectLoop ? 0 : xm);
-      else if (a.flags & 1)
+      if (a.flags & 1)
         hipLaunchKernelGGL((k_trace_chain<true, 4>), dim3(kDefectLoop ? grid_for(cnt) : grid_stream_mapped(cnt, xm)), b, lds,
                            s, a, cnt, kDefectLoop ? 0 : xm);
       else if (waves == 4)
@@ -1017,9 +1015,7 @@ int art_trace_scene(const void* image_dev, int32_t n_chains, int32_t n_elems, in
     const dim3 g(grid_stream_mapped(cnt, xm), n_chains), b(kBlock);
     for (int sg = 0; sg < S; ++sg) {
       const ChainArgs* seg = tab + (int64_t)sg * n_chains;
-      if ((flags & 1) && defect_waves() == 5)
-        hipLaunchKernelGGL((k_trace_scene<true, 5>), g, b, 0, s, seg, off, cnt, xm);
-      else if (flags & 1)
+      if (flags & 1)
         hipLaunchKernelGGL((k_trace_scene<true, 4>), g, b, 0, s, seg, off, cnt, xm);
       else if (waves == 4)
         hipLaunchKernelGGL((k_trace_scene<false, 4>), g, b, 0, s, seg, off, cnt, xm);

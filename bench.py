@@ -44,6 +44,10 @@ ALGO_BYTES_PER_INTERSECTION = 128.0   # read 48+8+4, write 48+8+
 ALGO_BYTES_READOUT = 88.0             # read 48+8+4, write 8+8+8+4
 HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6300 GB/s is what a copy achieves)
 CONFIGS = ("relay4", "C2", "C3", "C4", "C5")
+# Timed steps whose launches are bracketed by HIP events (roofline.kernel_ms).  Every timing event is an extra barrier
+# packet in the stream's queue; bracketing all of a 100-step run fills the queue and makes the host enqueue in lockstep
+# with the GPU (measured: host_enqueue_ms_per_step 0.83 instead of 0.15 at 60 queued steps).
+EVENT_STEPS = int(os.environ.get("ART_BENCH_EVENT_STEPS", "20"))
 
 
 def log(*a):
@@ -489,10 +493,14 @@ def worker(args):
             gather.drain()
         barrier()
         sync()
+        ev = None
         if collect_events:
             be.trace_events, be.readout_events = [], []
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for k in range(steps):
+            if collect_events and k == EVENT_STEPS:
+                ev = (be.trace_events, be.readout_events)      # HIP events bracket the launches of the first
+                be.trace_events, be.readout_events = None, None  # EVENT_STEPS timed steps only (see EVENT_STEPS)
             o, r = step(full_gather)
         t_enq = time.perf_counter() - t0     # host time to enqueue all steps (diagnostic: host-bound if ~ dt)
         if gather:
@@ -504,8 +512,8 @@ def worker(args):
             t = torch.tensor([dt], dtype=torch.float64, device=be.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        ev = (be.trace_events, be.readout_events) if collect_events else None
-        if collect_events:
+        if collect_events and be.trace_events is not None:
+            ev = (be.trace_events, be.readout_events)
             be.trace_events, be.readout_events = None, None
         return dt, t_enq, o, r, ev
 
@@ -568,10 +576,12 @@ def worker(args):
         if on_gpu:
             inter_per_launch = inter_per_step_rank / launches
             defects = any(len(getattr(oe.type, "DeformationList", [])) > 0 for els in element_lists for oe in els)
-            kprefix = ("k_trace_scene<" if program is not None else
-                       ("k_trace_chain<" if mode == "chain" else "k_trace_element<"))
-            if program is not None or mode == "chain":
-                kprefix += "true" if defects else "false"
+            if program is not None:
+                kprefix = "k_trace_scene<" + ("true" if defects else "false")
+            elif mode == "chain" and n_elems > 1:
+                kprefix = "k_trace_chain<" + ("true" if defects else "false")
+            else:                       # per-element launches; a one-element chain is the per-element kernel too
+                kprefix = "k_trace_element<"
             tr = profiled_traffic(cfg, kprefix, n)
             algo = ALGO_BYTES_PER_INTERSECTION * inter_per_launch / (kernel_ms * 1e-3) / 1e9
             # what the kernel moves by construction: every chain reads its source once (57 B/slot) and writes 65 B per

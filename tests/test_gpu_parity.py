@@ -270,6 +270,30 @@ def test_gpu_exchange_kernels(hip):
     assert torch.equal(out.cpu(), want)
     with pytest.raises(RuntimeError):
         be.exchange_fold(recv, 0, stride, out)
+    # a shard above 2^24 slots (a float32 linspace of sample slots rounds n-1 up to n there): the last sampled slot is
+    # n-1, and the packed sample is exactly those slots
+    del X, Y, O, alive
+    n = 2 ** 25 + 3
+    X = torch.arange(n, dtype=torch.float64, device=be.device)
+    alive = torch.ones(n, dtype=torch.uint8, device=be.device)
+    ex = sharding.Exchange(be, n, sample=20000)
+    assert int(ex.slots[-1]) == n - 1 and int(ex.slots.max()) < n and ex.k == 20000
+    st, smp = ex(stats, X, X, X, alive)
+    assert torch.equal(smp[0][:, 0], ex.slots.to(torch.float64)) and bool((smp[0][:, 3] == 1).all())
+    # empty and all-dead shards give the reduction identities, which fold away
+    import ART.ModuleDetector as mdet
+    from attosecondraytracing_amd.bundle import RayBundle
+    D = mdet.Detector(np.zeros(3), np.array([0.0, 0.0, 10.0]), np.array([0.0, 0.0, -1.0]))
+    dead = RayBundle.allocate(1000, backend=be)
+    dead.data.zero_()
+    dead.alive.zero_()
+    for B in (dead, RayBundle.allocate(0, backend=be)):
+        s = D.readout(B)["stats"]
+        assert s[0] == 0 and s[1] == 0 and s[2] == np.inf and s[3] == -np.inf and s[12] == np.inf and s[13] == -np.inf
+    both = torch.cat([torch.as_tensor(s, device=be.device), stats])
+    be.exchange_fold(both, 2, 24, out)
+    want = stats.clone()
+    assert torch.equal(out[[2, 3, 4, 5, 12, 13]], want[[2, 3, 4, 5, 12, 13]]) and out[0] == want[0]
 
 
 def test_gpu_plain_c_consumer_of_the_abi(hip, tmp_path):

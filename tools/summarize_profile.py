@@ -65,10 +65,10 @@ def main():
     if "--steps" in extra.split():
         steps = int(extra.split()[extra.split().index("--steps") + 1])
     for k, v in byk.items():
-        if k.startswith("k_trace_chain") or k.startswith("k_trace_element"):
+        if k.startswith(("k_trace_chain", "k_trace_element", "k_trace_scene")):
             g = max(x[0] for x in v)
             big = [x[1] for x in v if x[0] == g]
-            per_step = 1 if k.startswith("k_trace_chain") else max(1, len(big) // (steps + 6))
+            per_step = 1 if k.startswith(("k_trace_chain", "k_trace_scene")) else max(1, len(big) // (steps + 6))
             last = big[-steps * per_step:]
             if len(last) >= steps and sum(big) > 1e6:
                 out.append(f"`{k}`: average over the last {len(last)} launches (the timed steps) = {sum(last)/len(last)/1e3:.1f} us")
