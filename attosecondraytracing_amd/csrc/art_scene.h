@@ -25,9 +25,16 @@ struct ChainArgs {
   ArtElementDesc e[kChainMax];
   ArtBundleView out[kChainMax];  // out[k].alive == NULL: no history for element k
   ArtBundleView in;
+  ArtChainReadout ro;            // fused detector read-out of the last bundle (flags bit 1)
   int32_t n_elems;
-  int32_t flags;                 // bit 0: some element carries Zernike or gridded defects
+  int32_t flags;                 // bit 0: some element carries Zernike or gridded defects; bit 1: `ro` is set
 };
+constexpr int kFlagDefects = 1, kFlagReadout = 2;
+
+inline bool readout_ok(const ArtChainReadout& r) {
+  const int outs = (r.X != nullptr) + (r.Y != nullptr) + (r.opl != nullptr);
+  return r.scratch && r.out24 && (outs == 0 || outs == 3);
+}
 
 constexpr uint32_t kSceneMagic = 0x41525453u;  // "ARTS"
 struct SceneHeader {                           // first 64 bytes of an image
@@ -52,7 +59,7 @@ inline bool scene_view_ok(const ArtBundleView& v) {
 // Returns flags (>= 0) or a negative ART_ERR_* code with a message in `err`.
 // elems[c * n_elems + k], outs[c * n_elems + k], ins[c]; segment s of chain c sits at table[s * n_chains + c].
 inline int scene_pack(const ArtElementDesc* elems, int n_chains, int n_elems, const ArtBundleView* ins,
-                      const ArtBundleView* outs, void* image, const char** err) {
+                      const ArtBundleView* outs, const ArtChainReadout* ros, void* image, const char** err) {
   static const char* none = "";
   *err = none;
   if (!elems || !ins || !outs || !image) { *err = "NULL argument"; return ART_ERR_BAD_ARG; }
@@ -83,10 +90,16 @@ inline int scene_pack(const ArtElementDesc* elems, int n_chains, int n_elems, co
         if ((e.n_defects > 0 && !e.zern) || (e.n_grid > 0 && !e.grid)) { *err = "defect count > 0 but its table is NULL"; return ART_ERR_BAD_ARG; }
         a.e[k] = e;
         prepare_element(a.e[k]);
-        if (e.n_defects > 0 || e.n_grid > 0) { a.flags |= 1; h.flags |= 1; }
+        if (e.n_defects > 0 || e.n_grid > 0) { a.flags |= kFlagDefects; h.flags |= kFlagDefects; }
         const ArtBundleView& o = outs[(int64_t)c * n_elems + k0 + k];
         if (o.alive != nullptr && !scene_view_ok(o)) { *err = "history view partially NULL"; return ART_ERR_BAD_ARG; }
         a.out[k] = o;
+      }
+      if (ros && s == S - 1) {   // the read-out rides on the chain's last segment
+        if (!readout_ok(ros[c])) { *err = "read-out: scratch/out24 missing or X/Y/opl partially NULL"; return ART_ERR_BAD_ARG; }
+        a.ro = ros[c];
+        a.flags |= kFlagReadout;
+        h.flags |= kFlagReadout;
       }
       // the segment's last bundle is the next segment's input (or the chain's result): it must exist
       if (!scene_view_ok(a.out[m - 1])) {

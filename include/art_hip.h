@@ -149,6 +149,27 @@ int art_trace_element(const ArtElementDesc* e, const ArtBundleView* in, const Ar
 int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundleView* in,
                     const ArtBundleView* outs, int64_t n, void* stream);
 
+/* The same launch with the detector read-out of the LAST bundle fused behind it (art_detector_readout's outputs and
+ * statistics, ART/ModuleDetector.py:191-279): the ray is still in registers when it reaches the detector, so the
+ * read-out costs its 24 B/ray of outputs instead of a second pass that re-reads 57 B/ray.  For a detector that is known
+ * before the trace (manual placement, a re-trace, a scan).  Per-workgroup partial statistics go to `scratch`
+ * (art_chain_readout_scratch_doubles(n) doubles, DEVICE) and are folded into out24 by a second tiny launch; the fold
+ * order differs from art_detector_readout's, so sums agree with it to rounding (minima, maxima and counts exactly).
+ * One launch's limit applies: n <= 2^28 (ART_ERR_UNSUPPORTED beyond; use the two separate calls).                   */
+typedef struct ArtChainReadout {
+  ArtDetectorDesc det;
+  const double* w;       /* DEVICE weights (Ray.intensity) or NULL (w = 1)                          */
+  double cx, cy, co;     /* provisional centres of the second moments, as in art_detector_readout   */
+  double* X;             /* DEVICE, n doubles each, or all three NULL (statistics only)              */
+  double* Y;
+  double* opl;
+  double* scratch;       /* DEVICE, art_chain_readout_scratch_doubles(n) doubles                    */
+  double* out24;         /* DEVICE, 24 doubles: slot layout of art_detector_readout                 */
+} ArtChainReadout;
+int64_t art_chain_readout_scratch_doubles(int64_t n);
+int art_trace_chain_readout(const ArtElementDesc* elems, int32_t n_elems, const ArtBundleView* in,
+                            const ArtBundleView* outs, const ArtChainReadout* readout, int64_t n, void* stream);
+
 /* MANY chains in ONE launch (ART/ModuleProcessing.py:203-239: OEPlacement with a list-valued argument returns 10-11
  * chains that differ only in poses, which ARTmain.py:304-342 traces one after the other; the misalignment loop lists of
  * ART/ModuleOpticalChain.py:371-657 likewise).  All chains have n_elems elements and bundles of n slots.  The
@@ -157,8 +178,10 @@ int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundl
  *   2. art_scene_pack(...)                     fills a HOST buffer of that size -- pure host code, no HIP call;
  *                                              elems[c * n_elems + k], ins[c], outs[c * n_elems + k] (rules of
  *                                              art_trace_chain: outs[..].alive == NULL skips that history bundle, the
- *                                              last view of a chain and every 8th are mandatory).  Returns flags >= 0
- *                                              to pass on to art_trace_scene, or a negative error code;
+ *                                              last view of a chain and every 8th are mandatory); readouts = NULL or
+ *                                              one ArtChainReadout per chain (fused read-out of each chain's last
+ *                                              bundle, see art_trace_chain_readout).  Returns flags >= 0 to pass on
+ *                                              to art_trace_scene, or a negative error code;
  *   3. the caller copies the image to DEVICE memory (its own allocation and memcpy);
  *   4. art_trace_scene(image_dev, ...)         ONE kernel launch per 8 elements: grid.y = chain, grid.x = 256-ray tile.
  * A launch reads nothing but the device image and the bundles: re-packing new poses into the same device buffer and
@@ -166,7 +189,7 @@ int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundl
  * art_trace_chain, bit for bit.                                                                                      */
 int64_t art_scene_bytes(int32_t n_chains, int32_t n_elems);
 int art_scene_pack(const ArtElementDesc* elems, int32_t n_chains, int32_t n_elems, const ArtBundleView* ins,
-                   const ArtBundleView* outs, void* image_host);
+                   const ArtBundleView* outs, const ArtChainReadout* readouts, void* image_host);
 int art_trace_scene(const void* image_dev, int32_t n_chains, int32_t n_elems, int32_t flags, int64_t n, void* stream);
 
 /* Bundle from array-of-structs input (the layout a caller holding ART Ray lists / (n,3) NumPy arrays has):
