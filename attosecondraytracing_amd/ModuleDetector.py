@@ -100,6 +100,10 @@ class Detector:
         d.rot[:] = cached[1]
         return d
 
+    def _readout_key(self, path_centre=0.0):
+        """What a read-out depends on besides the bundle: the detector plane and the provisional path centre."""
+        return (self._centre.tobytes(), self._normal.tobytes(), float(path_centre))
+
     def readout(self, RayList, points3d=False, sync=True, path_centre=0.0, store=True):
         """One fused pass on the device (art_detector_readout): per-slot tensors 'X', 'Y' (detector-plane coordinates
         about Detector.centre, ART/ModuleDetector.py:212-234), 'opl' (optical path to the detector, :272-275),
@@ -109,6 +113,14 @@ class Detector:
         store=False skips the per-ray outputs (statistics only)."""
         self._iscomplete()
         B = RayList if isinstance(RayList, RayBundle) else RayBundle.from_ray_list(RayList)
+        fused = getattr(B, "_fused_readout", None)
+        if fused is not None and not points3d and fused[0] == self._readout_key(path_centre) and fused[1] == B.version \
+                and (fused[2]["X"] is not None or not store):
+            # computed in the launch that traced this bundle (RayTracingCalculation(..., detector=self))
+            res = fused[2]
+            if sync and "stats" not in res:
+                res["stats"] = res["stats_dev"].cpu().numpy()
+            return res
         be = B.backend
         n = B.n_slots
         X = Y = opl = P3 = None

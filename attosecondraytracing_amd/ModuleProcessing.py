@@ -119,13 +119,26 @@ _CHAIN_MAX = 8          # elements per fused launch (kChainMax in csrc/art_scene
 
 
 # ------------------------------------------------------------------------------------------- the hot path
-def RayTracingCalculation(source_rays, optical_elements, IgnoreDefects=True, mode=None, history=True):
+def _attach_readout(bundle, detector, path_centre, res):
+    """Remember a read-out that was computed in the same launch as `bundle`: Detector.readout(bundle) returns it
+    instead of launching the read-out kernel, as long as the detector pose and the bundle are unchanged."""
+    res["bundle"] = bundle
+    bundle._fused_readout = (detector._readout_key(path_centre), bundle.version, res)
+
+
+def RayTracingCalculation(source_rays, optical_elements, IgnoreDefects=True, mode=None, history=True, detector=None,
+                          path_centre=0.0):
     """Propagate `source_rays` through `optical_elements` (ART/ModuleProcessing.py:250-313).
 
     Returns a list with one RayBundle per element: the rays *after* that element, in the lab frame.  Each
     bundle behaves like the reference's list of surviving Ray objects (len, indexing, iteration) and keeps
     the full SoA state on the device.  With history=False only the last bundle is materialised (the others
-    are None): an extension for callers that only analyse the final bundle."""
+    are None): an extension for callers that only analyse the final bundle.
+
+    detector: a placed `Detector` known BEFORE the trace (manual placement, a re-trace, a scan).  Its read-out of the
+    last bundle (ART/ModuleDetector.py:191-279) is then computed in the same launch, while every ray is still in
+    registers (art_trace_chain_readout): `detector.readout(outs[-1])` and the `get_*` methods find it ready instead of
+    re-reading the bundle.  Same values as the separate read-out (statistics to rounding: another summation order)."""
     src = _as_bundle(source_rays)
     be = src.backend
     n = src.n_slots
@@ -171,7 +184,13 @@ def RayTracingCalculation(source_rays, optical_elements, IgnoreDefects=True, mod
             for j, k in enumerate(range(_CHAIN_MAX - 1, m - 1, _CHAIN_MAX)):
                 views[k] = scratch[j % len(scratch)].view()
             outs[-1]._keepalive = (keep, scratch)
-        be.trace_chain(descs, src.view(), views, n)
+        ro = None
+        if detector is not None and 0 < n <= be.MAX_FUSED_READOUT_RAYS:
+            detector._iscomplete()
+            ro = be.new_chain_readout(detector._desc(), src.intensity, n, (0.0, 0.0, path_centre))
+        be.trace_chain(descs, src.view(), views, n, readout=ro)
+        if ro is not None:
+            _attach_readout(outs[-1], detector, path_centre, ro)
     elif mode == "element":
         if not history and m > 1:
             # ping-pong through one scratch bundle, in place
@@ -191,13 +210,15 @@ def RayTracingCalculation(source_rays, optical_elements, IgnoreDefects=True, mod
     return outs
 
 
-def RayTracingCalculationMany(source_rays_list, optical_elements_list, IgnoreDefects=True, history=True):
+def RayTracingCalculationMany(source_rays_list, optical_elements_list, IgnoreDefects=True, history=True,
+                              detectors=None):
     """`RayTracingCalculation` for a LIST of chains in ONE launch (art_trace_scene): what `OEPlacement` returns when one
     of its arguments is a list -- 10-11 chains that differ only in poses (ART/ModuleProcessing.py:203-239), which the
     reference's `ARTmain.main` traces one after the other (ARTmain.py:304-342).  The element descriptors of all chains
     travel as one device-resident scene table; blockIdx.y selects the chain.  Returns one list of bundles per chain,
     identical to separate calls.  Chains that cannot share a launch (different ray or element counts) are traced one
-    by one -- still on the device."""
+    by one -- still on the device.  `detectors`: one placed Detector per chain whose read-out is fused behind the
+    trace (see RayTracingCalculation)."""
     sources = [_as_bundle(s) for s in source_rays_list]
     c = len(sources)
     if c != len(optical_elements_list):
@@ -213,9 +234,11 @@ def RayTracingCalculationMany(source_rays_list, optical_elements_list, IgnoreDef
             keep.append(k)
     uniform = (m > 0 and n > 0 and all(len(els) == m for els in optical_elements_list)
                and all(s.n_slots == n and s.backend is be for s in sources) and not any(d.nonfinite for d in descs))
+    if detectors is not None and len(detectors) != c:
+        raise ValueError("need one detector per chain")
     if c == 1 or not uniform:
-        return [RayTracingCalculation(s, els, IgnoreDefects, None, history)
-                for s, els in zip(sources, optical_elements_list)]
+        return [RayTracingCalculation(s, els, IgnoreDefects, None, history, None if detectors is None else detectors[k])
+                for k, (s, els) in enumerate(zip(sources, optical_elements_list))]
     if history:
         grid = RayBundle.allocate_grid(n, c, m, sources, be)
     else:
@@ -234,12 +257,21 @@ def RayTracingCalculationMany(source_rays_list, optical_elements_list, IgnoreDef
                 b._keepalive = (keep, scratch)
                 prev = b
             views.append(b.view() if b is not None else _abi.ArtBundleView())
+    ros = None
+    if detectors is not None and n <= be.MAX_FUSED_READOUT_RAYS:
+        areas = be.chain_readout_scratch(n, c)
+        ros = []
+        for d, s_, area in zip(detectors, sources, areas):
+            d._iscomplete()
+            ros.append(be.new_chain_readout(d._desc(), s_.intensity, n, scratch=area))
     host, dev = be.scene_alloc(c, m)
-    flags = be.scene_pack(descs, [s.view() for s in sources], views, c, m, host)
+    flags = be.scene_pack(descs, [s.view() for s in sources], views, c, m, host, ros)
     be.scene_upload(host, dev)
     be.trace_scene(dev, c, m, flags, n)
-    for outs in grid:
+    for ci, outs in enumerate(grid):
         outs[-1]._keepalive = (keep, scratch, host, dev)
+        if ros is not None:
+            _attach_readout(outs[-1], detectors[ci], 0.0, ros[ci])
     return grid
 
 

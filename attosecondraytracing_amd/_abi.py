@@ -67,6 +67,17 @@ class ArtDetectorDesc(C.Structure):
     ]
 
 
+class ArtChainReadout(C.Structure):
+    _fields_ = [
+        ("det", ArtDetectorDesc),
+        ("w", C.c_void_p),
+        ("cx", C.c_double), ("cy", C.c_double), ("co", C.c_double),
+        ("X", C.c_void_p), ("Y", C.c_void_p), ("opl", C.c_void_p),
+        ("scratch", C.c_void_p),
+        ("out24", C.c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); the loader checks every symbol exists (tests/test_abi.py does too)
 PROTOTYPES = {
     "art_abi_version": (C.c_int, []),
@@ -77,8 +88,11 @@ PROTOTYPES = {
     "art_trace_chain": (C.c_int, [C.POINTER(ArtElementDesc), C.c_int32, C.POINTER(ArtBundleView),
                                   C.POINTER(ArtBundleView), C.c_int64, C.c_void_p]),
     "art_scene_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
+    "art_chain_readout_scratch_doubles": (C.c_int64, [C.c_int64]),
+    "art_trace_chain_readout": (C.c_int, [C.POINTER(ArtElementDesc), C.c_int32, C.POINTER(ArtBundleView),
+                                          C.POINTER(ArtBundleView), C.POINTER(ArtChainReadout), C.c_int64, C.c_void_p]),
     "art_scene_pack": (C.c_int, [C.POINTER(ArtElementDesc), C.c_int32, C.c_int32, C.POINTER(ArtBundleView),
-                                 C.POINTER(ArtBundleView), C.c_void_p]),
+                                 C.POINTER(ArtBundleView), C.POINTER(ArtChainReadout), C.c_void_p]),
     "art_trace_scene": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
     "art_pack_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(ArtBundleView), C.c_void_p]),
     "art_transform_bundle": (C.c_int, [c_double_p, c_double_p, C.c_int32, C.POINTER(ArtBundleView),

@@ -100,13 +100,45 @@ class HipBackend:
         self.check(self._timed(lambda: self.fn["art_trace_element"](C.byref(desc), C.byref(view_in),
                                                                     C.byref(view_out), n, sp)), "art_trace_element")
 
-    def trace_chain(self, descs, view_in, views_out, n):
+    def trace_chain(self, descs, view_in, views_out, n, readout=None):
+        """art_trace_chain, or art_trace_chain_readout when `readout` (from new_chain_readout) is given."""
         m = len(descs)
         darr = (_abi.ArtElementDesc * m)(*descs)
         varr = (_abi.ArtBundleView * m)(*views_out)
         sp = self.stream_ptr()
-        self.check(self._timed(lambda: self.fn["art_trace_chain"](darr, m, C.byref(view_in), varr, n, sp)),
-                   "art_trace_chain")
+        if readout is None:
+            self.check(self._timed(lambda: self.fn["art_trace_chain"](darr, m, C.byref(view_in), varr, n, sp)),
+                       "art_trace_chain")
+        else:
+            ro = readout["struct"]
+            self.check(self._timed(lambda: self.fn["art_trace_chain_readout"](darr, m, C.byref(view_in), varr,
+                                                                              C.byref(ro), n, sp)),
+                       "art_trace_chain_readout")
+
+    MAX_FUSED_READOUT_RAYS = 1 << 28     # one launch (art_trace_chain_readout)
+
+    def new_chain_readout(self, ddesc, w, n, centres=(0.0, 0.0, 0.0), store=True, scratch=None):
+        """Outputs + descriptor of a read-out fused behind a chain launch (ArtChainReadout): returns a dict with the
+        result tensors 'X', 'Y', 'opl' (None with store=False), 'stats_dev' and the ctypes 'struct'."""
+        X = Y = opl = None
+        if store:
+            X, Y, opl = self.empty(n), self.empty(n), self.empty(n)
+        out = self.empty(24)
+        if scratch is None:
+            scratch = self.scratch("chain_ro", self.fn["art_chain_readout_scratch_doubles"](n), torch.float64)
+        ro = _abi.ArtChainReadout()
+        ro.det = ddesc
+        ro.w = None if w is None else w.data_ptr()
+        ro.cx, ro.cy, ro.co = (float(v) for v in centres)
+        ro.X, ro.Y, ro.opl = (None, None, None) if not store else (X.data_ptr(), Y.data_ptr(), opl.data_ptr())
+        ro.scratch, ro.out24 = scratch.data_ptr(), out.data_ptr()
+        return {"struct": ro, "X": X, "Y": Y, "opl": opl, "P3": None, "stats_dev": out, "_keep": (w, scratch)}
+
+    def chain_readout_scratch(self, n, count):
+        """`count` scratch areas for fused read-outs of `count` chains in one scene launch."""
+        per = int(self.fn["art_chain_readout_scratch_doubles"](n))
+        t = torch.empty(per * count, dtype=torch.float64, device=self.device)
+        return [t[k * per:(k + 1) * per] for k in range(count)]
 
     # scene table (include/art_hip.h: art_scene_bytes / art_scene_pack / art_trace_scene): many chains, one launch
     def scene_alloc(self, n_chains, n_elems):
@@ -117,12 +149,14 @@ class HipBackend:
         return (torch.empty(nb, dtype=torch.uint8, pin_memory=True),
                 torch.empty(nb, dtype=torch.uint8, device=self.device))
 
-    def scene_pack(self, descs, views_in, views_out, n_chains, n_elems, host_image):
-        """Pack descriptors (flat, chain-major) and views into the host image; returns the scene flags."""
+    def scene_pack(self, descs, views_in, views_out, n_chains, n_elems, host_image, readouts=None):
+        """Pack descriptors (flat, chain-major), views and optional per-chain fused read-outs (new_chain_readout
+        dicts) into the host image; returns the scene flags."""
         darr = (_abi.ArtElementDesc * (n_chains * n_elems))(*descs)
         iarr = (_abi.ArtBundleView * n_chains)(*views_in)
         oarr = (_abi.ArtBundleView * (n_chains * n_elems))(*views_out)
-        rc = self.fn["art_scene_pack"](darr, n_chains, n_elems, iarr, oarr, host_image.data_ptr())
+        rarr = None if readouts is None else (_abi.ArtChainReadout * n_chains)(*[r["struct"] for r in readouts])
+        rc = self.fn["art_scene_pack"](darr, n_chains, n_elems, iarr, oarr, rarr, host_image.data_ptr())
         if rc < 0:
             self.check(rc, "art_scene_pack")
         return rc

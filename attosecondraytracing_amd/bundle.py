@@ -38,6 +38,7 @@ class RayBundle:
         # host array [n, k] or None: the path segments rays already carried when a bundle WITHOUT parent was built
         # from Ray objects whose `path` tuples had k > 1 entries (the device keeps only their sum)
         self.path_head = None
+        self._fused_readout = None    # (detector key, version, result) of a read-out computed in the tracing launch
 
     # ------------------------------------------------------------------ backend / persistence
     @property
@@ -70,6 +71,7 @@ class RayBundle:
         self._backend = None
         self._index = None
         self._count = None
+        self._fused_readout = None
         self._serial = next(_SERIAL)
 
     # ------------------------------------------------------------------ construction

@@ -67,7 +67,7 @@ inline int xcd_map() {
   static const int v = [] {
     const char* e = getenv("ART_XCD_MAP");
     const int x = e ? atoi(e) : 0;
-    return (x < -1 || x > 16) ? 0 : x;
+    return (x < -1 || x > 8) ? 0 : x;     // runs of at most 128 tiles: the grid is rounded up by < 1024 workgroups
   }();
   return v;
 }
@@ -170,7 +170,9 @@ __device__ __forceinline__ void store_slot(const BundleRsrc& b, int64_t i, const
   st_f64(b.dx, o8, r.dx); st_f64(b.dy, o8, r.dy); st_f64(b.dz, o8, r.dz);
   st_f64(b.path, o8, r.path);
   st_f64(b.inc, o8, r.inc);
+#ifndef ART_DIAG_NOALIVE   // timing-only build without the 64-byte-per-wave alive stores (results are wrong)
   __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(ok ? 1 : 0), b.alive, (int)o1, 0, ART_ST_AUX);
+#endif
 }
 
 // plain-pointer access for the small kernels (detector, sources)
@@ -185,6 +187,79 @@ __device__ __forceinline__ void store_ray(const ArtBundleView& v, int64_t i, con
   v.path[i] = r.path;
   v.incidence[i] = r.inc;
 }
+
+// ------------------------------------------------------------------------------------------- reductions
+// Deterministic: fixed grid, each lane accumulates its grid-stride slice, wave shuffle tree, LDS across the
+// 4 waves, one partial per workgroup into `scratch`, then fold_slot(): one workgroup per statistic folds the
+// partials in a fixed order.
+constexpr int kRedBlocks = 1024;
+constexpr int kRedSlots = 16;
+constexpr int kReadoutSlots = 24;   // art_detector_readout / fused chain read-out statistics
+
+enum RedOp { RSUM = 0, RMIN = 1, RMAX = 2 };
+
+__device__ __forceinline__ double wave_reduce(double v, int op) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_down(v, off, 64);
+    v = (op == RSUM) ? v + o : (op == RMIN ? fmin(v, o) : fmax(v, o));
+  }
+  return v;
+}
+
+template <int NS>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[NS], const int (&ops)[NS], double* dst) {
+  __shared__ double s[kBlock / 64][NS];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const double v = wave_reduce(acc[k], ops[k]);
+    if (lane == 0) s[w][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NS) {
+    const int k = threadIdx.x;
+    double v = s[0][k];
+    for (int j = 1; j < kBlock / 64; ++j)
+      v = (ops[k] == RSUM) ? v + s[j][k] : (ops[k] == RMIN ? fmin(v, s[j][k]) : fmax(v, s[j][k]));
+    dst[k] = v;
+  }
+}
+
+// Final fold of per-block partials laid out [block][ns]: launched with ns blocks, block k folds slot k in a fixed
+// order (thread t takes partials t, t+256, ...; then the shuffle tree) — deterministic, and ns blocks work in
+// parallel instead of one block walking the whole table.
+__device__ __forceinline__ void fold_slot(const double* scratch, const int nblocks, const int ns, const int op_k,
+                                          double* out) {
+  const int k = blockIdx.x;
+  const int op[1] = {op_k};
+  double acc[1] = {(op_k == RSUM) ? 0.0 : (op_k == RMIN ? INFINITY : -INFINITY)};
+  for (int blk = threadIdx.x; blk < nblocks; blk += kBlock) {
+    const double v = scratch[(int64_t)blk * ns + k];
+    acc[0] = (op_k == RSUM) ? acc[0] + v : (op_k == RMIN ? fmin(acc[0], v) : fmax(acc[0], v));
+  }
+  block_reduce_store<1>(acc, op, out + k);
+}
+
+// The 24 read-out statistics (layout: art_hip.h, art_detector_readout) of one ray folded into `acc`; dead rays add the
+// reduction identities through selects (no divergent skip).
+__device__ __forceinline__ void readout_accumulate(double (&acc)[kReadoutSlots], const bool live, const double x,
+                                                   const double y, const double o, const double wi, const bool has_w,
+                                                   const double cx, const double cy, const double co) {
+  const double ww = live ? (has_w ? wi : 1.0) : 0.0, one = live ? 1.0 : 0.0;
+  const double xs = live ? x : 0.0, ys = live ? y : 0.0, os = live ? o : 0.0;
+  acc[0] += one; acc[1] += os;
+  acc[2] = fmin(acc[2], live ? x : INFINITY); acc[3] = fmax(acc[3], live ? x : -INFINITY);
+  acc[4] = fmin(acc[4], live ? y : INFINITY); acc[5] = fmax(acc[5], live ? y : -INFINITY);
+  acc[6] += xs; acc[7] += ys;
+  acc[8] += ww; acc[9] = fma(ww, xs, acc[9]); acc[10] = fma(ww, ys, acc[10]); acc[11] = fma(ww, os, acc[11]);
+  acc[12] = fmin(acc[12], live ? o : INFINITY); acc[13] = fmax(acc[13], live ? o : -INFINITY);
+  const double ex = live ? x - cx : 0.0, ey = live ? y - cy : 0.0, eo = live ? o - co : 0.0;
+  acc[16] = fma(ex, ex, acc[16]); acc[17] = fma(ey, ey, acc[17]); acc[18] = fma(eo, eo, acc[18]);
+  acc[19] = fma(ww * ex, ex, acc[19]); acc[20] = fma(ww * ey, ey, acc[20]); acc[21] = fma(ww * eo, eo, acc[21]);
+}
+#define ART_READOUT_OPS {RSUM, RSUM, RMIN, RMAX, RMIN, RMAX, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, \
+                         RMIN, RMAX, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM}
 
 // ------------------------------------------------------------------------------------------- trace kernels
 // The descriptor travels in a one-element array and is indexed with blockIdx.y (always 0): a dynamic index makes the
@@ -323,8 +398,37 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
       store_slot(make_rsrc(a.out[k], a.out[k].alive != nullptr ? n : 0, first), i, r, ok);
 #endif
     }
+    if (a.flags & art::kFlagReadout) {
+      // Fused detector read-out of the last bundle (art_trace_chain_readout): the ray is still in registers.  X, Y, opl
+      // of dead rays are dropped by the range check; every workgroup leaves one 24-slot partial in ro.scratch.
+      const int ops[kReadoutSlots] = ART_READOUT_OPS;
+      double acc[kReadoutSlots];
+#pragma unroll
+      for (int k = 0; k < kReadoutSlots; ++k) acc[k] = (ops[k] == RSUM) ? 0.0 : (ops[k] == RMIN ? INFINITY : -INFINITY);
+      double Ix, Iy, Iz, x = 0.0, y = 0.0, o = 0.0;
+      if (ok) art::detector_ray(a.ro.det, r, Ix, Iy, Iz, x, y, o);
+      const unsigned nb8 = (unsigned)(n * 8);
+      const unsigned o8 = ok ? (unsigned)i * 8u : kDropOffset;
+      st_f64(rsrc_of(a.ro.X + first, a.ro.X ? nb8 : 0u), o8, x);
+      st_f64(rsrc_of(a.ro.Y + first, a.ro.Y ? nb8 : 0u), o8, y);
+      st_f64(rsrc_of(a.ro.opl + first, a.ro.opl ? nb8 : 0u), o8, o);
+      const double wi = ld_f64(rsrc_of(const_cast<double*>(a.ro.w) + first, a.ro.w ? nb8 : 0u), (unsigned)i * 8u);
+      readout_accumulate(acc, ok, x, y, o, wi, a.ro.w != nullptr, a.ro.cx, a.ro.cy, a.ro.co);
+      block_reduce_store<kReadoutSlots>(acc, ops, a.ro.scratch + (int64_t)blockIdx.x * kReadoutSlots);
+    }
     i += stride;
   } while (DEFECT && kDefectLoop && i < n);
+}
+
+// fold of the fused read-out's partials: grid (24 slots, chains)
+__global__ __launch_bounds__(kBlock) void k_chain_readout_final(const ChainArgs* __restrict__ tab, const int nblocks) {
+  const int ops[kReadoutSlots] = ART_READOUT_OPS;
+  const ChainArgs& a = tab[blockIdx.y];
+  fold_slot(a.ro.scratch, nblocks, kReadoutSlots, ops[blockIdx.x], a.ro.out24);
+}
+__global__ __launch_bounds__(kBlock) void k_chain_readout_final1(const double* scratch, double* out24, const int nblocks) {
+  const int ops[kReadoutSlots] = ART_READOUT_OPS;
+  fold_slot(scratch, nblocks, kReadoutSlots, ops[blockIdx.x], out24);
 }
 
 template <bool DEFECT, int WAVES>
@@ -397,58 +501,6 @@ __global__ __launch_bounds__(kBlock) void k_detector(const ArtDetectorDesc d, co
   }
 }
 
-// ------------------------------------------------------------------------------------------- reductions
-// Deterministic: fixed grid, each lane accumulates its grid-stride slice, wave shuffle tree, LDS across the
-// 4 waves, one partial per workgroup into `scratch`, then fold_slot(): one workgroup per statistic folds the
-// partials in a fixed order.
-constexpr int kRedBlocks = 1024;
-constexpr int kRedSlots = 16;
-
-enum RedOp { RSUM = 0, RMIN = 1, RMAX = 2 };
-
-__device__ __forceinline__ double wave_reduce(double v, int op) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const double o = __shfl_down(v, off, 64);
-    v = (op == RSUM) ? v + o : (op == RMIN ? fmin(v, o) : fmax(v, o));
-  }
-  return v;
-}
-
-template <int NS>
-__device__ __forceinline__ void block_reduce_store(double (&acc)[NS], const int (&ops)[NS], double* dst) {
-  __shared__ double s[kBlock / 64][NS];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < NS; ++k) {
-    const double v = wave_reduce(acc[k], ops[k]);
-    if (lane == 0) s[w][k] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < NS) {
-    const int k = threadIdx.x;
-    double v = s[0][k];
-    for (int j = 1; j < kBlock / 64; ++j)
-      v = (ops[k] == RSUM) ? v + s[j][k] : (ops[k] == RMIN ? fmin(v, s[j][k]) : fmax(v, s[j][k]));
-    dst[k] = v;
-  }
-}
-
-// Final fold of per-block partials laid out [block][ns]: launched with ns blocks, block k folds slot k in a fixed
-// order (thread t takes partials t, t+256, ...; then the shuffle tree) — deterministic, and ns blocks work in
-// parallel instead of one block walking the whole table.
-__device__ __forceinline__ void fold_slot(const double* scratch, const int nblocks, const int ns, const int op_k,
-                                          double* out) {
-  const int k = blockIdx.x;
-  const int op[1] = {op_k};
-  double acc[1] = {(op_k == RSUM) ? 0.0 : (op_k == RMIN ? INFINITY : -INFINITY)};
-  for (int blk = threadIdx.x; blk < nblocks; blk += kBlock) {
-    const double v = scratch[(int64_t)blk * ns + k];
-    acc[0] = (op_k == RSUM) ? acc[0] + v : (op_k == RMIN ? fmin(acc[0], v) : fmax(acc[0], v));
-  }
-  block_reduce_store<1>(acc, op, out + k);
-}
-
 __global__ __launch_bounds__(kBlock) void k_stats_partial(const uint8_t* alive, const double* X, const double* Y,
                                                           const double* opl, const double* w, const int64_t n,
                                                           double* scratch) {
@@ -478,7 +530,6 @@ __global__ __launch_bounds__(kBlock) void k_stats_final(const double* scratch, c
 }
 
 constexpr int kSumSlots = 8;
-constexpr int kReadoutSlots = 24;
 
 // detector read-out fused with its reductions: one pass over the bundle, statistics accumulated in registers
 __global__ __launch_bounds__(kBlock) void k_detector_readout(const ArtDetectorDesc d, const ArtBundleView b,
@@ -522,18 +573,7 @@ __global__ __launch_bounds__(kBlock) void k_detector_readout(const ArtDetectorDe
       double x, y, o;
       art::detector_ray(d, r, p3[0][h], p3[1][h], p3[2][h], x, y, o);
       xo[h] = x; yo[h] = y; oo[h] = o;
-      const double wi = h ? wv.b : wv.a;
-      const double ww = live ? (w ? wi : 1.0) : 0.0, one = live ? 1.0 : 0.0;
-      const double xs = live ? x : 0.0, ys = live ? y : 0.0, os = live ? o : 0.0;
-      acc[0] += one; acc[1] += os;
-      acc[2] = fmin(acc[2], live ? x : INFINITY); acc[3] = fmax(acc[3], live ? x : -INFINITY);
-      acc[4] = fmin(acc[4], live ? y : INFINITY); acc[5] = fmax(acc[5], live ? y : -INFINITY);
-      acc[6] += xs; acc[7] += ys;
-      acc[8] += ww; acc[9] = fma(ww, xs, acc[9]); acc[10] = fma(ww, ys, acc[10]); acc[11] = fma(ww, os, acc[11]);
-      acc[12] = fmin(acc[12], live ? o : INFINITY); acc[13] = fmax(acc[13], live ? o : -INFINITY);
-      const double ex = live ? x - cx : 0.0, ey = live ? y - cy : 0.0, eo = live ? o - co : 0.0;
-      acc[16] = fma(ex, ex, acc[16]); acc[17] = fma(ey, ey, acc[17]); acc[18] = fma(eo, eo, acc[18]);
-      acc[19] = fma(ww * ex, ex, acc[19]); acc[20] = fma(ww * ey, ey, acc[20]); acc[21] = fma(ww * eo, eo, acc[21]);
+      readout_accumulate(acc, live, x, y, o, h ? wv.b : wv.a, w != nullptr, cx, cy, co);
     }
     st_2f64(r3x, o16, p3[0][0], p3[0][1]); st_2f64(r3y, o16, p3[1][0], p3[1][1]); st_2f64(r3z, o16, p3[2][0], p3[2][1]);
     st_2f64(rX, o16, xo[0], xo[1]); st_2f64(rY, o16, yo[0], yo[1]); st_2f64(rO, o16, oo[0], oo[1]);
@@ -922,23 +962,37 @@ inline int chain_waves() {
 // measured 0.40 instead of 0.23 ms per 1e7 rays on the C5 surface)
 }  // namespace
 
-int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundleView* in, const ArtBundleView* outs,
-                    int64_t n, void* stream) {
+static int trace_chain_impl(const ArtElementDesc* elems, int32_t n_elems, const ArtBundleView* in,
+                            const ArtBundleView* outs, const ArtChainReadout* ro, int64_t n, void* stream) {
   if (!elems || !outs || n_elems <= 0) return fail(ART_ERR_BAD_ARG, "empty chain");
   if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
   for (int k = 0; k < n_elems; ++k) {
     int rc = check_elem(&elems[k]);
     if (rc) return rc;
   }
-  if (n == 0) return ART_OK;  // an empty bundle has no arrays to point to
+  hipStream_t s = (hipStream_t)stream;
+  if (ro) {
+    if (!art::readout_ok(*ro)) return fail(ART_ERR_BAD_ARG, "read-out: scratch/out24 missing or X/Y/opl partially NULL");
+    if (n > max_rays_per_launch()) return fail(ART_ERR_UNSUPPORTED, "fused read-out: more rays than one launch covers");
+#ifdef ART_ZERN_LDS
+    return fail(ART_ERR_UNSUPPORTED, "ART_ZERN_LDS comparison build: no fused read-out");
+#endif
+  }
+  if (n == 0) {
+    if (ro) {   // nothing to trace: the statistics are the reduction identities
+      hipLaunchKernelGGL(k_chain_readout_final1, dim3(kReadoutSlots), dim3(kBlock), 0, s, ro->scratch, ro->out24, 0);
+      hipError_t e0 = hipGetLastError();
+      if (e0 != hipSuccess) return fail_hip(e0, "art_trace_chain_readout launch");
+    }
+    return ART_OK;  // an empty bundle has no arrays to point to
+  }
   if (!view_ok(in)) return fail(ART_ERR_BAD_ARG, "input bundle view has a NULL array");
   for (int k = 0; k < n_elems; ++k)
     if (outs[k].alive != nullptr && !view_ok(&outs[k])) return fail(ART_ERR_BAD_ARG, "history view partially NULL");
   if (!view_ok(&outs[n_elems - 1])) return fail(ART_ERR_BAD_ARG, "the last output view is mandatory");
   // a chain of ONE element is the per-element kernel's job: compiled for the optic's kind, it needs fewer registers
   // than the fused kernel's run-time dispatch (5 instead of 4 waves per SIMD with defects) -- same results
-  if (n_elems == 1) return art_trace_element(&elems[0], in, &outs[0], n, stream);
-  hipStream_t s = (hipStream_t)stream;
+  if (n_elems == 1 && !ro) return art_trace_element(&elems[0], in, &outs[0], n, stream);
   for (int k0 = 0; k0 < n_elems; k0 += kChainMax) {
     const int m = (n_elems - k0 < kChainMax) ? n_elems - k0 : kChainMax;
     // the chunk's last bundle is the next chunk's input: it must exist
@@ -959,7 +1013,12 @@ int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundl
         a.e[k] = elems[k0 + k];
         art::prepare_element(a.e[k]);
         a.out[k] = view_at(outs[k0 + k], off);
-        if (a.e[k].n_defects > 0 || a.e[k].n_grid > 0) a.flags |= 1;
+        if (a.e[k].n_defects > 0 || a.e[k].n_grid > 0) a.flags |= art::kFlagDefects;
+      }
+      const bool tail = ro && k0 + m == n_elems;       // the read-out rides on the chain's last fused launch
+      if (tail) {
+        a.ro = *ro;
+        a.flags |= art::kFlagReadout;
       }
       size_t lds = 0;
 #ifdef ART_ZERN_LDS
@@ -968,13 +1027,15 @@ int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundl
 #endif
       const int xm = xcd_map();
       const dim3 g(grid_stream_mapped(cnt, xm)), b(kBlock);
-      if (a.flags & 1)
+      if (a.flags & art::kFlagDefects)
         hipLaunchKernelGGL((k_trace_chain<true, 4>), dim3(kDefectLoop ? grid_for(cnt) : grid_stream_mapped(cnt, xm)), b, lds,
                            s, a, cnt, kDefectLoop ? 0 : xm);
       else if (waves == 4)
         hipLaunchKernelGGL((k_trace_chain<false, 4>), g, b, 0, s, a, cnt, xm);
       else
         hipLaunchKernelGGL((k_trace_chain<false, 5>), g, b, 0, s, a, cnt, xm);
+      if (tail)
+        hipLaunchKernelGGL(k_chain_readout_final1, dim3(kReadoutSlots), dim3(kBlock), 0, s, ro->scratch, ro->out24, (int)g.x);
       cur = a.out[m - 1];
     }
   }
@@ -983,15 +1044,33 @@ int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundl
   return ART_OK;
 }
 
+int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundleView* in, const ArtBundleView* outs,
+                    int64_t n, void* stream) {
+  return trace_chain_impl(elems, n_elems, in, outs, nullptr, n, stream);
+}
+
+int64_t art_chain_readout_scratch_doubles(int64_t n) {
+  if (n < 0) n = 0;
+  if (n > kMaxRaysPerLaunchHw) n = kMaxRaysPerLaunchHw;
+  // one 24-slot partial per workgroup of the fused launch (its grid may be rounded up by the tile mapping)
+  return ((n + kBlock - 1) / kBlock + 1024) * kReadoutSlots;
+}
+
+int art_trace_chain_readout(const ArtElementDesc* elems, int32_t n_elems, const ArtBundleView* in,
+                            const ArtBundleView* outs, const ArtChainReadout* readout, int64_t n, void* stream) {
+  if (!readout) return fail(ART_ERR_BAD_ARG, "read-out descriptor is NULL");
+  return trace_chain_impl(elems, n_elems, in, outs, readout, n, stream);
+}
+
 int64_t art_scene_bytes(int32_t n_chains, int32_t n_elems) {
   if (n_chains <= 0 || n_elems <= 0) return 0;
   return art::scene_bytes(n_chains, n_elems);
 }
 
 int art_scene_pack(const ArtElementDesc* elems, int32_t n_chains, int32_t n_elems, const ArtBundleView* ins,
-                   const ArtBundleView* outs, void* image) {
+                   const ArtBundleView* outs, const ArtChainReadout* readouts, void* image) {
   const char* msg = "";
-  const int rc = art::scene_pack(elems, n_chains, n_elems, ins, outs, image, &msg);
+  const int rc = art::scene_pack(elems, n_chains, n_elems, ins, outs, readouts, image, &msg);
   if (rc < 0) return fail(rc, msg);
   return rc;
 }
@@ -1000,13 +1079,19 @@ int art_trace_scene(const void* image_dev, int32_t n_chains, int32_t n_elems, in
   if (!image_dev) return fail(ART_ERR_BAD_ARG, "scene image is NULL");
   if (n_chains <= 0 || n_chains > 65535 || n_elems <= 0) return fail(ART_ERR_BAD_ARG, "bad chain or element count");
   if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
-  if (n == 0) return ART_OK;
 #ifdef ART_ZERN_LDS
   if (flags & 1) return fail(ART_ERR_UNSUPPORTED, "ART_ZERN_LDS build: scenes with defects go through art_trace_chain");
 #endif
+  if ((flags & art::kFlagReadout) && n > max_rays_per_launch())
+    return fail(ART_ERR_UNSUPPORTED, "fused read-out: more rays than one launch covers");
   hipStream_t s = (hipStream_t)stream;
   const ChainArgs* tab = art::scene_table(image_dev);
   const int S = art::scene_segments(n_elems);
+  if (n == 0) {
+    if (flags & art::kFlagReadout)
+      hipLaunchKernelGGL(k_chain_readout_final, dim3(kReadoutSlots, n_chains), dim3(kBlock), 0, s, tab + (int64_t)(S - 1) * n_chains, 0);
+    return ART_OK;
+  }
   const int waves = chain_waves();
   const int64_t chunk = max_rays_per_launch();
   for (int64_t off = 0; off < n; off += chunk) {
@@ -1021,6 +1106,8 @@ int art_trace_scene(const void* image_dev, int32_t n_chains, int32_t n_elems, in
         hipLaunchKernelGGL((k_trace_scene<false, 4>), g, b, 0, s, seg, off, cnt, xm);
       else
         hipLaunchKernelGGL((k_trace_scene<false, 5>), g, b, 0, s, seg, off, cnt, xm);
+      if ((flags & art::kFlagReadout) && sg == S - 1)
+        hipLaunchKernelGGL(k_chain_readout_final, dim3(kReadoutSlots, n_chains), dim3(kBlock), 0, s, seg, (int)g.x);
     }
   }
   hipError_t err = hipGetLastError();

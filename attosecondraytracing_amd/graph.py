@@ -48,12 +48,14 @@ class SceneProgram:
     host-to-device copy and one graph launch -- no descriptor marshalling, no allocation, no per-launch Python.  This is
     what a pose scan (the misalignment loop lists of ART/ModuleOpticalChain.py:371-657, an alignment optimiser) or a
     repeated trace of small bundles (1e4-1e6 rays, where an eager launch is host-bound) should use.  To trace other
-    rays, overwrite the source bundles' tensors in place.  `post`: optional callable `post(outputs)` captured right
-    behind the trace (e.g. a `Detector.readout(..., sync=False)`); its return value is `self.post_result`.
+    rays, overwrite the source bundles' tensors in place.  `detectors`: one placed Detector per chain whose read-out
+    of the chain's last bundle is fused behind the trace (art_trace_chain_readout; results in `self.readouts`, and
+    `detector.readout(outputs[c][-1])` returns them).  `post`: optional callable `post(outputs)` captured right behind
+    the trace; its return value is `self.post_result`.
 
     Results are bit-identical to `RayTracingCalculation`; the returned bundles are overwritten by the next `run()`."""
 
-    def __init__(self, sources, element_lists, IgnoreDefects=True, post=None, capture=True):
+    def __init__(self, sources, element_lists, IgnoreDefects=True, post=None, capture=True, detectors=None):
         from . import ModuleProcessing as mp
         from . import _abi
         from .bundle import RayBundle
@@ -75,6 +77,12 @@ class SceneProgram:
                 prev = b
         self._views_in = [s.view() for s in self.sources]
         self._views_out = [b.view() for outs in self.outputs for b in outs]
+        self.detectors, self.readouts = None, None
+        if detectors is not None and self.n <= self.be.MAX_FUSED_READOUT_RAYS:
+            if len(detectors) != self.c:
+                raise ValueError("need one detector per chain")
+            self._ro_scratch = self.be.chain_readout_scratch(self.n, self.c)
+            self.set_detectors(detectors)
         self.host, self.dev = self.be.scene_alloc(self.c, self.m)
         self._uploaded = None
         self._signature = None
@@ -91,6 +99,23 @@ class SceneProgram:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self._launch()
+
+    def set_detectors(self, detectors):
+        """(Re)place the fused read-outs' detectors; takes effect with the next update().  Only for a program that was
+        built with detectors (whether the launch carries a read-out is part of the captured graph)."""
+        if self.readouts is None and getattr(self, "_signature", None) is not None:
+            raise ValueError("this SceneProgram was built without detectors")
+        self.detectors = list(detectors)
+        if self.readouts is None:
+            self.readouts = []
+            for d, s, area in zip(self.detectors, self.sources, self._ro_scratch):
+                d._iscomplete()
+                self.readouts.append(self.be.new_chain_readout(d._desc(), s.intensity, self.n, scratch=area))
+        else:
+            for d, ro in zip(self.detectors, self.readouts):
+                d._iscomplete()
+                ro["struct"].det = d._desc()
+                ro.pop("stats", None)
 
     def _structure(self, element_lists, descs):
         """What a captured launch has baked in: counts, optic kinds and whether defects are present."""
@@ -125,24 +150,32 @@ class SceneProgram:
         self._signature = sig
         if self._uploaded is not None:
             self._uploaded.synchronize()       # the previous copy has read the pinned image
-        self.flags = self.be.scene_pack(descs, self._views_in, self._views_out, self.c, self.m, self.host)
+        self.flags = self.be.scene_pack(descs, self._views_in, self._views_out, self.c, self.m, self.host, self.readouts)
         self._uploaded = self.be.scene_upload(self.host, self.dev)
         self._keep = keep
         for outs in self.outputs:
             for b in outs:
                 b.touch()
 
+    def _mark(self):
+        """The output arrays have new contents: drop cached survivor lists, re-attach the fused read-outs."""
+        for ci, outs in enumerate(self.outputs):
+            for b in outs:
+                b.touch()
+            if self.readouts is not None:
+                self.readouts[ci].pop("stats", None)
+                self._mp._attach_readout(outs[-1], self.detectors[ci], 0.0, self.readouts[ci])
+
     def _launch(self):
         self.be.trace_scene(self.dev, self.c, self.m, self.flags, self.n)
+        self._mark()
         if self.post is not None:
             self.post_result = self.post(self.outputs)
 
     def run(self):
         if self.graph is not None:
             self.graph.replay()
+            self._mark()
         else:
             self._launch()
-        for outs in self.outputs:
-            for b in outs:
-                b.touch()
         return self.outputs

@@ -44,10 +44,7 @@ ALGO_BYTES_PER_INTERSECTION = 128.0   # read 48+8+4, write 48+8+
 ALGO_BYTES_READOUT = 88.0             # read 48+8+4, write 8+8+8+4
 HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6300 GB/s is what a copy achieves)
 CONFIGS = ("relay4", "C2", "C3", "C4", "C5")
-# Timed steps whose launches are bracketed by HIP events (roofline.kernel_ms).  Every timing event is an extra barrier
-# packet in the stream's queue; bracketing all of a 100-step run fills the queue and makes the host enqueue in lockstep
-# with the GPU (measured: host_enqueue_ms_per_step 0.83 instead of 0.15 at 60 queued steps).
-EVENT_STEPS = int(os.environ.get("ART_BENCH_EVENT_STEPS", "20"))
+EVENT_STEPS = 20    # passes whose launches are bracketed by HIP events for roofline.kernel_ms (see worker())
 
 
 def log(*a):
@@ -456,16 +453,21 @@ def worker(args):
     def readouts(outs):
         return [d.readout(o[-1], sync=False) for d, o in zip(dets, outs)]
 
+    # the detectors are in place before the timed region, so their read-out rides on the tracing launch (the ray is
+    # still in registers: 24 B/ray of outputs instead of a second pass that re-reads 57 B/ray); --readout separate
+    # launches art_detector_readout on the last bundle instead
+    fuse = args.readout == "fused" and mode == "chain"
     program = None
     if batched or use_graph:
         program = SceneProgram([src] * n_chains, element_lists, IgnoreDefects=ignore_defects,
-                               post=readouts, capture=use_graph)
+                               post=readouts, capture=use_graph, detectors=dets if fuse else None)
 
     def trace_and_readout():
         if program is not None:
             o = program.run()
             return o, program.post_result
-        o = [mp.RayTracingCalculation(src, element_lists[0], IgnoreDefects=ignore_defects, mode=mode)]
+        o = [mp.RayTracingCalculation(src, element_lists[0], IgnoreDefects=ignore_defects, mode=mode,
+                                      detector=dets[0] if fuse else None)]
         return o, readouts(o)
 
     # ------------------------------------------------------------------ N > 1 exchanges
@@ -486,21 +488,15 @@ def worker(args):
                 state["step"] += 1
         return o, r
 
-    def timed(full_gather, steps, collect_events):
+    def timed(full_gather, steps):
         for _ in range(args.warmup):
             step(full_gather)
         if gather:
             gather.drain()
         barrier()
         sync()
-        ev = None
-        if collect_events:
-            be.trace_events, be.readout_events = [], []
         t0 = time.perf_counter()
         for k in range(steps):
-            if collect_events and k == EVENT_STEPS:
-                ev = (be.trace_events, be.readout_events)      # HIP events bracket the launches of the first
-                be.trace_events, be.readout_events = None, None  # EVENT_STEPS timed steps only (see EVENT_STEPS)
             o, r = step(full_gather)
         t_enq = time.perf_counter() - t0     # host time to enqueue all steps (diagnostic: host-bound if ~ dt)
         if gather:
@@ -512,44 +508,46 @@ def worker(args):
             t = torch.tensor([dt], dtype=torch.float64, device=be.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        if collect_events and be.trace_events is not None:
-            ev = (be.trace_events, be.readout_events)
-            be.trace_events, be.readout_events = None, None
-        return dt, t_enq, o, r, ev
+        return dt, t_enq, o, r
 
-    dt, t_enq, o, r, ev = timed(False, args.steps, on_gpu and program is None)
+    dt, t_enq, o, r = timed(False, args.steps)
     dt_full = None
     if use_dist:
-        dt_full, _, o, r, _ = timed(True, args.steps, False)
+        dt_full, _, o, r = timed(True, args.steps)
         if rank == 0:
             XYO, alv = gather.result((state["step"] - 1) % 2)
             assert XYO.shape == (world, 3, n) and int(alv.sum().item()) > 0
-            assert torch.equal(XYO[0], torch.stack([r[-1]["X"], r[-1]["Y"], r[-1]["opl"]]))   # rank 0's own shard
+            # rank 0's own shard arrived bit for bit (compared as integers: the slots of dead rays hold whatever was
+            # in the freshly allocated arrays, NaNs included)
+            assert torch.equal(XYO[0].view(torch.int64), torch.stack([r[-1]["X"], r[-1]["Y"], r[-1]["opl"]]).view(torch.int64))
             S = state["sample"]
             assert S.shape == (world, sample_k, 4)
             own = torch.stack([r[-1]["X"], r[-1]["Y"], r[-1]["opl"]]).index_select(1, exchange.slots).T
-            assert torch.equal(S[0][:, 0:3], own)              # rank 0's own part of the last step's sample
+            assert torch.equal(S[0][:, 0:3].contiguous().view(torch.int64), own.contiguous().view(torch.int64))   # own part of the sample
     stats_host = (state["stats"] if use_dist else r[-1]["stats_dev"]).cpu().numpy()
     assert stats_host[0] == surv_last_job and np.isfinite(stats_host[1]), (stats_host[0], surv_last_job)
 
     # ------------------------------------------------------------------ kernel durations (HIP events on the launch stream)
+    # Right after the timed region, on the same resident data: EVENT_STEPS more passes of trace + read-out with every
+    # launch bracketed by HIP events recorded on the launch stream.  They are NOT inside the timed region because every
+    # timing event is a barrier packet that keeps the next kernel from overlapping the previous one's tail: bracketing
+    # the timed steps themselves costs 0.09 ms per 0.75-ms step (measured).
     kernel_ms = readout_ms = None
     launches = 1
     if on_gpu:
-        if ev is None:
-            # graph-replayed steps cannot carry events inside the graph: the same launches, eager, right after the timed
-            # region (same resident data)
-            be.trace_events, be.readout_events = [], []
-            for _ in range(min(args.steps, 20)):
+        be.trace_events, be.readout_events = [], []
+        for _ in range(EVENT_STEPS):
+            if program is not None:
                 program._launch()
-            sync()
-            ev = (be.trace_events, be.readout_events)
-            be.trace_events, be.readout_events = None, None
-        tr_ev, ro_ev = ev
-        steps_ev = len(ro_ev) // n_chains
-        launches = max(1, len(tr_ev) // max(steps_ev, 1))
+            else:
+                trace_and_readout()
+        sync()
+        tr_ev, ro_ev = be.trace_events, be.readout_events
+        be.trace_events, be.readout_events = None, None
+        launches = max(1, len(tr_ev) // EVENT_STEPS)
         kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in tr_ev]))       # average duration of one trace launch
-        readout_ms = float(np.mean([a.elapsed_time(b) for a, b in ro_ev]))      # one read-out (kernel + 24-slot fold)
+        if ro_ev:
+            readout_ms = float(np.mean([a.elapsed_time(b) for a, b in ro_ev]))  # one read-out (kernel + 24-slot fold)
 
     if rank == 0:
         value = inter_per_step_job * args.steps / dt
@@ -563,6 +561,7 @@ def worker(args):
                        "name": cfg, "rays_per_gpu": n, "elements": n_elems, "chains": n_chains,
                        "trace_mode": "scene (one launch for all chains)" if program is not None else mode,
                        "hip_graph": bool(use_graph), "world_size_seen": world,
+                       "readout": "fused into the tracing launch" if fuse else "separate launch",
                        "step": "RayTracingCalculation + Detector.readout"
                                + (f" + ONE RCCL all-gather of every shard's 24 statistics and a {sample_k * world}-ray sample "
                                   f"of the read-out, folded on the device" if use_dist else ""),
@@ -582,7 +581,7 @@ def worker(args):
                 kprefix = "k_trace_chain<" + ("true" if defects else "false")
             else:                       # per-element launches; a one-element chain is the per-element kernel too
                 kprefix = "k_trace_element<"
-            tr = profiled_traffic(cfg, kprefix, n)
+            tr = profiled_traffic(cfg if fuse else cfg + "_separate", kprefix, n)
             algo = ALGO_BYTES_PER_INTERSECTION * inter_per_launch / (kernel_ms * 1e-3) / 1e9
             # what the kernel moves by construction: every chain reads its source once (57 B/slot) and writes 65 B per
             # slot and element (dead slots: only the alive byte) -- the PMC counters agree with it to 0.1 % on relay4
@@ -601,18 +600,23 @@ def worker(args):
                 "kernel_ms": kernel_ms, "launches_per_step": launches, "intersections_per_launch": inter_per_launch,
                 "frac_of_achievable_6300": None if counted is None else counted / 6300.0,
             }
-            rays_ro = n
-            tro = profiled_traffic(cfg, "k_detector_readout", n)
-            algo_ro = ALGO_BYTES_READOUT * rays_ro / (readout_ms * 1e-3) / 1e9
-            counted_ro = None if tro is None else tro[0] / (readout_ms * 1e-3) / 1e9
-            res["roofline_readout"] = {
-                "bound": "hbm", "kernel": "k_detector_readout (+ k_readout_final)", "achieved": counted_ro,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if counted_ro is None else counted_ro / HBM_PEAK_GBS,
-                "traffic": None if tro is None else tro[0],
-                "traffic_source": None if tro is None else tro[1] + " (rocprofv3 PMC, bytes per launch)",
-                "achieved_algorithmic": algo_ro, "frac_algorithmic": algo_ro / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_ray": ALGO_BYTES_READOUT, "kernel_ms": readout_ms, "launches_per_step": n_chains,
-            }
+            if readout_ms is None:
+                res["roofline_readout"] = {
+                    "fused": True, "kernel": res["roofline"]["kernel"],
+                    "note": "the read-out rides on the tracing launch (art_trace_chain_readout / scene read-outs): its "
+                            "24 B/ray of outputs and the per-workgroup partial statistics are part of that kernel's "
+                            "traffic and time; `--readout separate` launches k_detector_readout instead"}
+            else:
+                tro = profiled_traffic(cfg + "_separate", "k_detector_readout", n) or profiled_traffic(cfg, "k_detector_readout", n)
+                algo_ro = ALGO_BYTES_READOUT * n / (readout_ms * 1e-3) / 1e9
+                counted_ro = None if tro is None else tro[0] / (readout_ms * 1e-3) / 1e9
+                res["roofline_readout"] = {
+                    "fused": False, "bound": "hbm", "kernel": "k_detector_readout (+ k_readout_final)", "achieved": counted_ro,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if counted_ro is None else counted_ro / HBM_PEAK_GBS,
+                    "traffic": None if tro is None else tro[0],
+                    "traffic_source": None if tro is None else tro[1] + " (rocprofv3 PMC, bytes per launch)",
+                    "achieved_algorithmic": algo_ro, "frac_algorithmic": algo_ro / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_ray": ALGO_BYTES_READOUT, "kernel_ms": readout_ms, "launches_per_step": n_chains}
             res["trace_only_intersections_per_s"] = inter_per_step_rank / (kernel_ms * launches * 1e-3)
         if world == 1 and args.cpu_sample > 0 and on_gpu:
             v, inter, secs, oracle_result = cpu_baseline(element_lists[-1], src_kind, det_dist, args.cpu_sample, ignore_defects)
@@ -650,6 +654,8 @@ def main(argv=None):
     ap.add_argument("--mode", default=None, choices=[None, "chain", "element"])
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step from a HIP graph (auto: for the multi-chain configurations)")
+    ap.add_argument("--readout", default="fused", choices=["fused", "separate"],
+                    help="fused: the detector read-out rides on the tracing launch; separate: its own kernel afterwards")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="rays of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args(argv)
     if args.cpu_sample < 0:

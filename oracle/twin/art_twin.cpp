@@ -72,9 +72,22 @@ int64_t art_cpu_scene_bytes(int32_t n_chains, int32_t n_elems) {
 }
 
 int art_cpu_scene_pack(const ArtElementDesc* elems, int32_t n_chains, int32_t n_elems, const ArtBundleView* ins,
-                       const ArtBundleView* outs, void* image) {
+                       const ArtBundleView* outs, const ArtChainReadout* ros, void* image) {
   const char* msg = "";
-  return art::scene_pack(elems, n_chains, n_elems, ins, outs, image, &msg);
+  return art::scene_pack(elems, n_chains, n_elems, ins, outs, ros, image, &msg);
+}
+
+// fused read-out of a chain's last bundle: per-ray outputs here, the statistics are left to the caller (the test
+// backend reduces them with NumPy, as it does for the separate read-out)
+static void readout_tail(const ArtChainReadout& ro, const ArtBundleView& last, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) {
+    if (last.alive[i] == 0) continue;
+    art::Ray r;
+    load_ray(last, i, r);
+    double Ix, Iy, Iz, x, y, o;
+    art::detector_ray(ro.det, r, Ix, Iy, Iz, x, y, o);
+    if (ro.X) { ro.X[i] = x; ro.Y[i] = y; ro.opl[i] = o; }
+  }
 }
 
 int art_cpu_trace_scene(const void* image, int32_t n_chains, int32_t n_elems, int32_t flags, int64_t n) {
@@ -96,8 +109,14 @@ int art_cpu_trace_scene(const void* image, int32_t n_chains, int32_t n_elems, in
           }
         }
       }
+      if (a.flags & art::kFlagReadout) readout_tail(a.ro, a.out[a.n_elems - 1], n);
     }
   }
+  return 0;
+}
+
+int art_cpu_chain_readout_tail(const ArtChainReadout* ro, const ArtBundleView* last, int64_t n) {
+  readout_tail(*ro, *last, n);
   return 0;
 }
 

@@ -142,3 +142,84 @@ def run_chain_list_cache():
     assert not calls, "the loop list must be traced by the batched launch, not chain by chain"
     for (s, a), o in zip(scenes, outs):
         pc.check_outputs(o, a, s)
+
+
+def run_fused_readout():
+    """The detector read-out fused behind the trace (art_trace_chain_readout / scene read-outs): same per-ray values
+    as the separate read-out bit for bit, statistics to rounding, and `Detector.readout` / `get_*` reuse it."""
+    import ART.ModuleProcessing as mp
+    import ART.ModuleDetector as mdet
+    from attosecondraytracing_amd.graph import SceneProgram
+    names = ("c3_twisted_chain00", "c3_twisted_chain04", "c3_twisted_chain09")
+    scenes = [load_golden(n) for n in names]
+    srcs = [pc.source_bundle(a, s) for s, a in scenes]
+    els = [pc.build_elements(s, a) for s, a in scenes]
+    dets = [mdet.Detector(np.array(s["detector"]["refpoint"]), np.array(s["detector"]["centre"]), np.array(s["detector"]["normal"]))
+            for s, a in scenes]
+
+    def same_readout(fused, plain, alive):
+        m = alive.cpu().numpy().astype(bool)
+        for key in ("X", "Y", "opl"):
+            assert np.array_equal(fused[key].cpu().numpy()[m], plain[key].cpu().numpy()[m]), key
+        fs, ps = fused["stats_dev"].cpu().numpy(), plain["stats_dev"].cpu().numpy()
+        for k in (0, 2, 3, 4, 5, 12, 13):
+            assert fs[k] == ps[k]                                        # count, minima, maxima: exact
+        for k in (1, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 20, 21):
+            assert abs(fs[k] - ps[k]) <= 1e-11 * max(abs(ps[k]), 1e-300), (k, fs[k], ps[k])
+
+    # single chain, through the public entry point
+    (s, a), src, e, D = scenes[1], srcs[1], els[1], dets[1]
+    plain_out = mp.RayTracingCalculation(src, e)
+    plain = D.readout(plain_out[-1], sync=False)
+    out = mp.RayTracingCalculation(src, e, detector=D)
+    for x, y in zip(out, plain_out):
+        _equal_bundles(x, y)
+    calls = []
+    be = src.backend
+    real = be.detector_readout
+    be.detector_readout = lambda *x, **k: calls.append(1) or real(*x, **k)
+    try:
+        fused = D.readout(out[-1], sync=False)
+        assert not calls, "Detector.readout must reuse the fused result"
+        same_readout(fused, plain, out[-1].alive)
+        # the reference API on top of it
+        scale = max(1.0, np.abs(a["det_points3d"]).max())
+        assert np.abs(D.get_PointList2D(out[-1]) - a["det_points2d"]).max() <= 1e-10 * scale
+        assert np.abs(D.get_PointList2DCentre(out[-1]) - a["det_points2dcentre"]).max() <= 1e-10 * scale
+        mean_t_fs = np.mean(D.get_OpticalPaths(out[-1])) / mdet.LightSpeed * 1e15
+        assert np.abs(D.get_Delays(out[-1]) - a["det_delays"]).max() <= 1e-10 * mean_t_fs
+        assert not calls
+        # a moved detector or 3-D points are not what was fused: a real read-out is launched
+        D2 = D.copy_detector()
+        D2.shiftByDistance(1.0)
+        D2.readout(out[-1])
+        D.get_PointList3D(out[-1])
+        assert len(calls) == 2
+    finally:
+        be.detector_readout = real
+    # history=False and a one-element chain keep the fused path
+    lo = mp.RayTracingCalculation(src, e, history=False, detector=D)
+    same_readout(D.readout(lo[-1], sync=False), plain, lo[-1].alive)
+    one = mp.RayTracingCalculation(src, e[:1], detector=D)
+    same_readout(D.readout(one[-1], sync=False), D.copy_detector().readout(mp.RayTracingCalculation(src, e[:1])[-1], sync=False),
+                 one[-1].alive)
+    # many chains in one launch, every chain with its own detector
+    many = mp.RayTracingCalculationMany(srcs, els, detectors=dets)
+    for o, src_, e_, D_ in zip(many, srcs, els, dets):
+        ref_out = mp.RayTracingCalculation(src_, e_)
+        same_readout(D_.readout(o[-1], sync=False), D_.copy_detector().readout(ref_out[-1], sync=False), o[-1].alive)
+    # a compiled program: replayed read-outs follow pose updates and detector moves
+    prog = SceneProgram([srcs[0]], [els[0]], detectors=[dets[0]])
+    for j in (0, 2, 1):
+        prog.set_detectors([dets[j]])
+        prog.update([els[j]])
+        o = prog.run()[0]
+        ref_out = mp.RayTracingCalculation(srcs[0], els[j])
+        same_readout(dets[j].readout(o[-1], sync=False), dets[j].copy_detector().readout(ref_out[-1], sync=False), o[-1].alive)
+        assert dets[j].readout(o[-1], sync=False) is prog.readouts[0]
+    # empty and all-dead bundles: reduction identities
+    from attosecondraytracing_amd.bundle import RayBundle
+    dead = src.copy()
+    dead.alive.zero_()
+    st = D.readout(mp.RayTracingCalculation(dead, e, detector=D)[-1])["stats"]
+    assert st[0] == 0 and st[2] == np.inf and st[3] == -np.inf and st[1] == 0

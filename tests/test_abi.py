@@ -38,9 +38,10 @@ def test_struct_layout_matches_header():
 #include <stddef.h>
 #include "art_hip.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(ArtElementDesc), offsetof(ArtElementDesc, fwd),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(ArtElementDesc), offsetof(ArtElementDesc, fwd),
          offsetof(ArtElementDesc, sp), offsetof(ArtElementDesc, zern), sizeof(ArtBundleView),
-         sizeof(ArtDetectorDesc), (size_t)ART_ZERN_STRIDE);
+         sizeof(ArtDetectorDesc), (size_t)ART_ZERN_STRIDE, sizeof(ArtChainReadout), offsetof(ArtChainReadout, w),
+         offsetof(ArtChainReadout, X), offsetof(ArtChainReadout, out24));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as td:
@@ -50,8 +51,10 @@ int main(void) {
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", exe, c])
         vals = [int(v) for v in subprocess.check_output([exe]).split()]
     E = _abi.ArtElementDesc
+    R = _abi.ArtChainReadout
     assert vals == [C.sizeof(E), E.fwd.offset, E.sp.offset, E.zern.offset, C.sizeof(_abi.ArtBundleView),
-                    C.sizeof(_abi.ArtDetectorDesc), _abi.ART_ZERN_STRIDE]
+                    C.sizeof(_abi.ArtDetectorDesc), _abi.ART_ZERN_STRIDE, C.sizeof(R), R.w.offset, R.X.offset,
+                    R.out24.offset]
 
 
 def test_no_cpu_fallback():

@@ -555,6 +555,40 @@ def test_gpu_scene_program_replays(hip):
     scene_cases.run_chain_list_cache()
 
 
+def test_gpu_fused_readout(hip):
+    """The detector read-out fused behind the tracing launch (art_trace_chain_readout, scene read-outs): per-ray values
+    bit-identical to the separate art_detector_readout, statistics to rounding, Detector.readout reuses it."""
+    import scene_cases
+    scene_cases.run_fused_readout()
+
+
+def test_gpu_fused_readout_full_size(hip):
+    """relay4 at the headline size (1e7 rays x 4 toroids): fused == separate read-out; and the chunked-launch limit."""
+    import torch
+    import bench
+    import ART.ModuleProcessing as mp
+    import ART.ModuleDetector as mdet
+    chain, _ = bench.build_scene(4)
+    els = chain.optical_elements
+    src = bench.device_source(10_000_000, 0, 10_000_000, hip)
+    plain = mp.RayTracingCalculation(src, els)
+    D = mdet.Detector(np.asarray(els[-1].position, dtype=float))
+    D.autoplace(plain[-1], 600.0)
+    want = D.readout(plain[-1], sync=False)
+    out = mp.RayTracingCalculation(src, els, detector=D)
+    got = D.readout(out[-1], sync=False)
+    assert got is out[-1]._fused_readout[2]
+    for x, y in zip(out, plain):
+        assert torch.equal(x.alive, y.alive) and torch.equal(x.data, y.data)
+    for k in ("X", "Y", "opl"):
+        assert torch.equal(got[k], want[k])
+    g, w = got["stats_dev"].cpu().numpy(), want["stats_dev"].cpu().numpy()
+    assert g[0] == w[0] == 10_000_000 and all(g[k] == w[k] for k in (2, 3, 4, 5, 12, 13))
+    rel = max(abs(g[k] - w[k]) / abs(w[k]) for k in (1, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 20, 21) if w[k] != 0)
+    report(f"[fused read-out relay4 1e7] statistics vs separate read-out: max rel diff {rel:.1e} (summation order)")
+    assert rel <= 1e-11
+
+
 def test_gpu_batched_full_size_c2(hip):
     """BASELINE C2 size: 11 chains x 1e6 rays in one launch == 11 single launches, bit for bit."""
     import torch

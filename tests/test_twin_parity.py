@@ -114,3 +114,8 @@ def test_twin_scene_program(twin):
     import scene_cases
     scene_cases.run_program_updates()
     scene_cases.run_chain_list_cache()
+
+
+def test_twin_fused_readout(twin):
+    import scene_cases
+    scene_cases.run_fused_readout()

@@ -66,7 +66,46 @@ class TwinBackend:
     def trace_element(self, desc, vin, vout, n):
         assert self.lib.art_cpu_trace_element(C.byref(desc), C.byref(vin), C.byref(vout), n) == 0
 
-    def trace_chain(self, descs, vin, vouts, n):
+    MAX_FUSED_READOUT_RAYS = 1 << 28
+
+    def new_chain_readout(self, ddesc, w, n, centres=(0.0, 0.0, 0.0), store=True, scratch=None):
+        X, Y, opl = (torch.empty(n, dtype=torch.float64) for _ in range(3))     # the twin always computes them
+        out = torch.empty(24, dtype=torch.float64)
+        ro = _abi.ArtChainReadout()
+        ro.det = ddesc
+        ro.w = None if w is None else w.data_ptr()
+        ro.cx, ro.cy, ro.co = (float(v) for v in centres)
+        ro.X, ro.Y, ro.opl = X.data_ptr(), Y.data_ptr(), opl.data_ptr()
+        ro.scratch, ro.out24 = out.data_ptr(), out.data_ptr()
+        return {"struct": ro, "X": X if store else None, "Y": Y if store else None, "opl": opl if store else None,
+                "P3": None, "stats_dev": out, "_keep": (w, X, Y, opl), "_w": w, "_centres": centres}
+
+    def chain_readout_scratch(self, n, count):
+        return [None] * count
+
+    def _finish_readout(self, ro, last_view, n):
+        """Statistics of a fused read-out (the twin's C side only fills X, Y, opl): same reduction as detector_readout."""
+        X, Y, O = ro["_keep"][1:4]
+        alive = torch.from_numpy(np.ctypeslib.as_array(C.cast(last_view.alive, C.POINTER(C.c_uint8)), shape=(max(n, 1),))[:n].copy())
+        w, c = ro["_w"], ro["_centres"]
+        out = np.zeros(24)
+        out[:16] = self.detector_stats(alive, X, Y, O, w, n)
+        a = alive.numpy().astype(bool)
+        ww = w.numpy()[a] if w is not None else np.ones(int(a.sum()))
+        ex, ey, eo = X.numpy()[a] - c[0], Y.numpy()[a] - c[1], O.numpy()[a] - c[2]
+        out[16:22] = [(ex ** 2).sum(), (ey ** 2).sum(), (eo ** 2).sum(), (ww * ex ** 2).sum(), (ww * ey ** 2).sum(),
+                      (ww * eo ** 2).sum()]
+        ro["stats_dev"].copy_(torch.from_numpy(out))
+
+    def trace_chain(self, descs, vin, vouts, n, readout=None):
+        self._trace_chain(descs, vin, vouts, n)
+        if readout is not None:
+            f = self.lib.art_cpu_chain_readout_tail
+            f.restype, f.argtypes = C.c_int, [C.POINTER(_abi.ArtChainReadout), C.POINTER(_abi.ArtBundleView), C.c_int64]
+            assert f(C.byref(readout["struct"]), C.byref(vouts[len(descs) - 1]), n) == 0
+            self._finish_readout(readout, vouts[len(descs) - 1], n)
+
+    def _trace_chain(self, descs, vin, vouts, n):
         m = len(descs)
         # the argument rules of art_trace_chain (csrc/art_kernels.hip), so that host-shell mistakes show up without a GPU:
         # the last view is mandatory, and a chain longer than one fused launch (8 elements) needs a view where one
@@ -87,16 +126,21 @@ class TwinBackend:
         img = torch.empty(int(f(n_chains, n_elems)), dtype=torch.uint8)
         return img, img
 
-    def scene_pack(self, descs, views_in, views_out, n_chains, n_elems, host_image):
+    def scene_pack(self, descs, views_in, views_out, n_chains, n_elems, host_image, readouts=None):
         f = self.lib.art_cpu_scene_pack
         f.restype = C.c_int
         f.argtypes = [C.POINTER(_abi.ArtElementDesc), C.c_int32, C.c_int32, C.POINTER(_abi.ArtBundleView),
-                      C.POINTER(_abi.ArtBundleView), C.c_void_p]
+                      C.POINTER(_abi.ArtBundleView), C.POINTER(_abi.ArtChainReadout), C.c_void_p]
         darr = (_abi.ArtElementDesc * (n_chains * n_elems))(*descs)
         iarr = (_abi.ArtBundleView * n_chains)(*views_in)
         oarr = (_abi.ArtBundleView * (n_chains * n_elems))(*views_out)
-        rc = f(darr, n_chains, n_elems, iarr, oarr, host_image.data_ptr())
+        rarr = None if readouts is None else (_abi.ArtChainReadout * n_chains)(*[r["struct"] for r in readouts])
+        rc = f(darr, n_chains, n_elems, iarr, oarr, rarr, host_image.data_ptr())
         assert rc >= 0, rc
+        # the statistics of fused read-outs are finished on the Python side after every trace_scene of this image
+        last = [views_out[c * n_elems + n_elems - 1] for c in range(n_chains)]
+        self._scene_ro = getattr(self, "_scene_ro", {})
+        self._scene_ro[host_image.data_ptr()] = None if readouts is None else list(zip(readouts, last))
         return rc
 
     def scene_upload(self, host_image, dev_image):
@@ -106,6 +150,8 @@ class TwinBackend:
         f = self.lib.art_cpu_trace_scene
         f.restype, f.argtypes = C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64]
         assert f(dev_image.data_ptr(), n_chains, n_elems, flags, n) == 0
+        for ro, last in (getattr(self, "_scene_ro", {}).get(dev_image.data_ptr()) or []):
+            self._finish_readout(ro, last, n)
 
     def pack_rays(self, points, vectors, path0, n, view):
         f = self.lib.art_cpu_pack_rays
