@@ -224,6 +224,7 @@ class RayBundle:
         cum = []
         b = self
         while b is not None:
+            b.backend                 # a bundle restored from an archive moves back to the device on first use
             cum.append(b.data[ROW_PATH].index_select(0, idx).cpu().numpy())
             b = b.parent
         cum = cum[::-1]
@@ -248,6 +249,7 @@ class RayBundle:
         cum = []
         b = self
         while b is not None:
+            b.backend                 # (restored parents may still be host-resident)
             cum.append(b.data[ROW_PATH].index_select(0, st).cpu().numpy())
             b = b.parent
         cum = cum[::-1]

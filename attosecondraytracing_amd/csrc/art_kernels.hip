@@ -122,7 +122,11 @@ __device__ __forceinline__ BundleRsrc make_rsrc(const ArtBundleView& v, int64_t 
   r.ox = rsrc_of(v.ox + first, b8); r.oy = rsrc_of(v.oy + first, b8); r.oz = rsrc_of(v.oz + first, b8);
   r.dx = rsrc_of(v.dx + first, b8); r.dy = rsrc_of(v.dy + first, b8); r.dz = rsrc_of(v.dz + first, b8);
   r.path = rsrc_of(v.path + first, b8); r.inc = rsrc_of(v.incidence + first, b8);
+#ifdef ART_DIAG_NOALIVE   // timing-only build: bundles above 4096 slots get no alive stores (their results are wrong)
+  r.alive = rsrc_of(v.alive + first, n > 4096 ? 0u : b1);
+#else
   r.alive = rsrc_of(v.alive + first, b1);
+#endif
   return r;
 }
 __device__ __forceinline__ double ld_f64(__amdgpu_buffer_rsrc_t rs, unsigned off) {
@@ -170,9 +174,7 @@ __device__ __forceinline__ void store_slot(const BundleRsrc& b, int64_t i, const
   st_f64(b.dx, o8, r.dx); st_f64(b.dy, o8, r.dy); st_f64(b.dz, o8, r.dz);
   st_f64(b.path, o8, r.path);
   st_f64(b.inc, o8, r.inc);
-#ifndef ART_DIAG_NOALIVE   // timing-only build without the 64-byte-per-wave alive stores (results are wrong)
   __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(ok ? 1 : 0), b.alive, (int)o1, 0, ART_ST_AUX);
-#endif
 }
 
 // plain-pointer access for the small kernels (detector, sources)
@@ -369,6 +371,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
 #ifdef ART_STORE_LDS4
   __shared__ __attribute__((aligned(16))) double s_out[8][kBlock];
 #endif
+  __shared__ double s_w[kBlock];   // per-lane parking slot (no barrier: a lane only reads what it wrote)
   const int64_t tile = tile_of(blockIdx.x, gridDim.x, xmap);
   const BundleRsrc bi = make_rsrc(a.in, n, first);
   const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -378,6 +381,11 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
     r.inc = 0.0;
     uint8_t al;
     load_slot(bi, i, r, al);
+    // Weight of the fused read-out: fetched with the ray (a zero-length descriptor without read-out or weights) and
+    // parked in LDS until the tail needs it -- held in registers across the chain it costs the 2 VGPRs that push the
+    // 5-wave build into scratch, and a scratch reload at the end is a VMEM load behind 36 stores (see the tail).
+    s_w[threadIdx.x] = ld_f64(rsrc_of(const_cast<double*>(a.ro.w) + first,
+                                      ((a.flags & art::kFlagReadout) && a.ro.w) ? (unsigned)(n * 8) : 0u), (unsigned)i * 8u);
     bool ok = al != 0;
     const double* zk = s_zern;
     for (int k = 0; k < a.n_elems; ++k) {
@@ -400,7 +408,10 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
     }
     if (a.flags & art::kFlagReadout) {
       // Fused detector read-out of the last bundle (art_trace_chain_readout): the ray is still in registers.  X, Y, opl
-      // of dead rays are dropped by the range check; every workgroup leaves one 24-slot partial in ro.scratch.
+      // of dead rays are dropped by the range check.  Statistics: one partial per WAVE (shuffle tree only), written
+      // slot-major into ro.scratch -- no LDS, no barrier and no load down here: a __syncthreads() or a trailing load
+      // would make every wave wait for the acknowledgement of its 36 outstanding stores (vmcnt counts loads and
+      // stores in one queue) instead of retiring as soon as they are issued, which cost 35 %.
       const int ops[kReadoutSlots] = ART_READOUT_OPS;
       double acc[kReadoutSlots];
 #pragma unroll
@@ -412,23 +423,39 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
       st_f64(rsrc_of(a.ro.X + first, a.ro.X ? nb8 : 0u), o8, x);
       st_f64(rsrc_of(a.ro.Y + first, a.ro.Y ? nb8 : 0u), o8, y);
       st_f64(rsrc_of(a.ro.opl + first, a.ro.opl ? nb8 : 0u), o8, o);
-      const double wi = ld_f64(rsrc_of(const_cast<double*>(a.ro.w) + first, a.ro.w ? nb8 : 0u), (unsigned)i * 8u);
-      readout_accumulate(acc, ok, x, y, o, wi, a.ro.w != nullptr, a.ro.cx, a.ro.cy, a.ro.co);
-      block_reduce_store<kReadoutSlots>(acc, ops, a.ro.scratch + (int64_t)blockIdx.x * kReadoutSlots);
+      asm volatile("" ::: "memory");   // the parked weight is re-read from LDS, not kept in (or spilled from) a register
+      readout_accumulate(acc, ok, x, y, o, s_w[threadIdx.x], a.ro.w != nullptr, a.ro.cx, a.ro.cy, a.ro.co);
+      const int64_t nparts = (int64_t)gridDim.x * (kBlock / 64);
+      const int64_t part = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+#pragma unroll
+      for (int k = 0; k < kReadoutSlots; ++k) {
+        const double v = wave_reduce(acc[k], ops[k]);
+        if ((threadIdx.x & 63) == 0) a.ro.scratch[(int64_t)k * nparts + part] = v;
+      }
     }
     i += stride;
   } while (DEFECT && kDefectLoop && i < n);
 }
 
-// fold of the fused read-out's partials: grid (24 slots, chains)
-__global__ __launch_bounds__(kBlock) void k_chain_readout_final(const ChainArgs* __restrict__ tab, const int nblocks) {
+// fold of the fused read-out's per-wave partials (slot-major: scratch[slot * nparts + part]): one workgroup per
+// statistic walks its contiguous row in a fixed order; grid (24 slots, chains)
+__device__ __forceinline__ void fold_row(const double* row, const int64_t nparts, const int op_k, double* out) {
+  const int op[1] = {op_k};
+  double acc[1] = {(op_k == RSUM) ? 0.0 : (op_k == RMIN ? INFINITY : -INFINITY)};
+  for (int64_t p = threadIdx.x; p < nparts; p += kBlock) {
+    const double v = row[p];
+    acc[0] = (op_k == RSUM) ? acc[0] + v : (op_k == RMIN ? fmin(acc[0], v) : fmax(acc[0], v));
+  }
+  block_reduce_store<1>(acc, op, out);
+}
+__global__ __launch_bounds__(kBlock) void k_chain_readout_final(const ChainArgs* __restrict__ tab, const int64_t nparts) {
   const int ops[kReadoutSlots] = ART_READOUT_OPS;
   const ChainArgs& a = tab[blockIdx.y];
-  fold_slot(a.ro.scratch, nblocks, kReadoutSlots, ops[blockIdx.x], a.ro.out24);
+  fold_row(a.ro.scratch + (int64_t)blockIdx.x * nparts, nparts, ops[blockIdx.x], a.ro.out24 + blockIdx.x);
 }
-__global__ __launch_bounds__(kBlock) void k_chain_readout_final1(const double* scratch, double* out24, const int nblocks) {
+__global__ __launch_bounds__(kBlock) void k_chain_readout_final1(const double* scratch, double* out24, const int64_t nparts) {
   const int ops[kReadoutSlots] = ART_READOUT_OPS;
-  fold_slot(scratch, nblocks, kReadoutSlots, ops[blockIdx.x], out24);
+  fold_row(scratch + (int64_t)blockIdx.x * nparts, nparts, ops[blockIdx.x], out24 + blockIdx.x);
 }
 
 template <bool DEFECT, int WAVES>
@@ -980,7 +1007,7 @@ static int trace_chain_impl(const ArtElementDesc* elems, int32_t n_elems, const 
   }
   if (n == 0) {
     if (ro) {   // nothing to trace: the statistics are the reduction identities
-      hipLaunchKernelGGL(k_chain_readout_final1, dim3(kReadoutSlots), dim3(kBlock), 0, s, ro->scratch, ro->out24, 0);
+      hipLaunchKernelGGL(k_chain_readout_final1, dim3(kReadoutSlots), dim3(kBlock), 0, s, ro->scratch, ro->out24, (int64_t)0);
       hipError_t e0 = hipGetLastError();
       if (e0 != hipSuccess) return fail_hip(e0, "art_trace_chain_readout launch");
     }
@@ -1035,7 +1062,8 @@ static int trace_chain_impl(const ArtElementDesc* elems, int32_t n_elems, const 
       else
         hipLaunchKernelGGL((k_trace_chain<false, 5>), g, b, 0, s, a, cnt, xm);
       if (tail)
-        hipLaunchKernelGGL(k_chain_readout_final1, dim3(kReadoutSlots), dim3(kBlock), 0, s, ro->scratch, ro->out24, (int)g.x);
+        hipLaunchKernelGGL(k_chain_readout_final1, dim3(kReadoutSlots), dim3(kBlock), 0, s, ro->scratch, ro->out24,
+                           (int64_t)g.x * (kBlock / 64));
       cur = a.out[m - 1];
     }
   }
@@ -1052,8 +1080,8 @@ int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundl
 int64_t art_chain_readout_scratch_doubles(int64_t n) {
   if (n < 0) n = 0;
   if (n > kMaxRaysPerLaunchHw) n = kMaxRaysPerLaunchHw;
-  // one 24-slot partial per workgroup of the fused launch (its grid may be rounded up by the tile mapping)
-  return ((n + kBlock - 1) / kBlock + 1024) * kReadoutSlots;
+  // one 24-slot partial per WAVE of the fused launch (its grid may be rounded up by the tile mapping)
+  return ((n + kBlock - 1) / kBlock + 1024) * (kBlock / 64) * kReadoutSlots;
 }
 
 int art_trace_chain_readout(const ArtElementDesc* elems, int32_t n_elems, const ArtBundleView* in,
@@ -1089,7 +1117,8 @@ int art_trace_scene(const void* image_dev, int32_t n_chains, int32_t n_elems, in
   const int S = art::scene_segments(n_elems);
   if (n == 0) {
     if (flags & art::kFlagReadout)
-      hipLaunchKernelGGL(k_chain_readout_final, dim3(kReadoutSlots, n_chains), dim3(kBlock), 0, s, tab + (int64_t)(S - 1) * n_chains, 0);
+      hipLaunchKernelGGL(k_chain_readout_final, dim3(kReadoutSlots, n_chains), dim3(kBlock), 0, s, tab + (int64_t)(S - 1) * n_chains,
+                         (int64_t)0);
     return ART_OK;
   }
   const int waves = chain_waves();
@@ -1107,7 +1136,8 @@ int art_trace_scene(const void* image_dev, int32_t n_chains, int32_t n_elems, in
       else
         hipLaunchKernelGGL((k_trace_scene<false, 5>), g, b, 0, s, seg, off, cnt, xm);
       if ((flags & art::kFlagReadout) && sg == S - 1)
-        hipLaunchKernelGGL(k_chain_readout_final, dim3(kReadoutSlots, n_chains), dim3(kBlock), 0, s, seg, (int)g.x);
+        hipLaunchKernelGGL(k_chain_readout_final, dim3(kReadoutSlots, n_chains), dim3(kBlock), 0, s, seg,
+                           (int64_t)g.x * (kBlock / 64));
     }
   }
   hipError_t err = hipGetLastError();
