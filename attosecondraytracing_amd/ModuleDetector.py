@@ -120,7 +120,7 @@ class Detector:
             res = fused[2]
             if sync and "stats" not in res:
                 res["stats"] = res["stats_dev"].cpu().numpy()
-            return res
+            return dict(res, bundle=B)
         be = B.backend
         n = B.n_slots
         X = Y = opl = P3 = None

@@ -121,8 +121,10 @@ _CHAIN_MAX = 8          # elements per fused launch (kChainMax in csrc/art_scene
 # ------------------------------------------------------------------------------------------- the hot path
 def _attach_readout(bundle, detector, path_centre, res):
     """Remember a read-out that was computed in the same launch as `bundle`: Detector.readout(bundle) returns it
-    instead of launching the read-out kernel, as long as the detector pose and the bundle are unchanged."""
-    res["bundle"] = bundle
+    instead of launching the read-out kernel, as long as the detector pose and the bundle are unchanged.
+    (`res` must not point back at the bundle: a reference cycle would keep every step's 2.6 GB of history alive until
+    the cyclic collector runs, and the caching allocator would hand out fresh, untouched memory for every trace.)"""
+    res.pop("bundle", None)
     bundle._fused_readout = (detector._readout_key(path_centre), bundle.version, res)
 
 

@@ -122,11 +122,7 @@ __device__ __forceinline__ BundleRsrc make_rsrc(const ArtBundleView& v, int64_t 
   r.ox = rsrc_of(v.ox + first, b8); r.oy = rsrc_of(v.oy + first, b8); r.oz = rsrc_of(v.oz + first, b8);
   r.dx = rsrc_of(v.dx + first, b8); r.dy = rsrc_of(v.dy + first, b8); r.dz = rsrc_of(v.dz + first, b8);
   r.path = rsrc_of(v.path + first, b8); r.inc = rsrc_of(v.incidence + first, b8);
-#ifdef ART_DIAG_NOALIVE   // timing-only build: bundles above 4096 slots get no alive stores (their results are wrong)
-  r.alive = rsrc_of(v.alive + first, n > 4096 ? 0u : b1);
-#else
   r.alive = rsrc_of(v.alive + first, b1);
-#endif
   return r;
 }
 __device__ __forceinline__ double ld_f64(__amdgpu_buffer_rsrc_t rs, unsigned off) {
@@ -174,7 +170,11 @@ __device__ __forceinline__ void store_slot(const BundleRsrc& b, int64_t i, const
   st_f64(b.dx, o8, r.dx); st_f64(b.dy, o8, r.dy); st_f64(b.dz, o8, r.dz);
   st_f64(b.path, o8, r.path);
   st_f64(b.inc, o8, r.inc);
+#ifdef ART_DIAG_NOALIVE   // timing-only build: slots >= 4096 get no alive store (results of large bundles are wrong)
+  __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(ok ? 1 : 0), b.alive, o1 < 4096u ? (int)o1 : (int)kDropOffset, 0, ART_ST_AUX);
+#else
   __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(ok ? 1 : 0), b.alive, (int)o1, 0, ART_ST_AUX);
+#endif
 }
 
 // plain-pointer access for the small kernels (detector, sources)
@@ -207,6 +207,68 @@ __device__ __forceinline__ double wave_reduce(double v, int op) {
     v = (op == RSUM) ? v + o : (op == RMIN ? fmin(v, o) : fmax(v, o));
   }
   return v;
+}
+
+// ---- 24 statistics x 64 lanes -> 24 wave totals, for the fused read-out tail (once per wave of 64 rays, so it has to
+// be cheap: 24 shuffle trees through ds_bpermute cost more than tracing the rays, 24 DPP prefix trees still +50 %).
+// Transpose through a wave-private LDS tile instead: in three passes of 8 statistics every lane parks its 8 values
+// ([stat][lane], conflict-free), then lane l folds 8 of the 64 values of statistic l/8 (stride-8 reads) and the 8
+// lanes of a statistic finish with a 3-step DPP butterfly (quad_perm xor 1, xor 2, row_half_mirror).  ~100
+// instructions per lane instead of ~900; no barrier (same-wave LDS operations are ordered), no VMEM.
+template <int CTRL>
+__device__ __forceinline__ double dpp_xchg(const double v) {
+  int2 s, r;
+  __builtin_memcpy(&s, &v, 8);
+  r.x = __builtin_amdgcn_update_dpp(s.x, s.x, CTRL, 0xf, 0xf, false);
+  r.y = __builtin_amdgcn_update_dpp(s.y, s.y, CTRL, 0xf, 0xf, false);
+  double d;
+  __builtin_memcpy(&d, &r, 8);
+  return d;
+}
+constexpr int kTileStride = 72;   // doubles per statistic row of the tile (64 + padding against bank conflicts)
+// Which statistic sits where: passes 0 and 1 carry the 16 sums, pass 2 the minima and -- negated, max(x) = -min(-x) --
+// the maxima, so that every pass folds with ONE compile-time operator (a per-lane operator compiles to branches).
+// Entries >= 24 are padding.
+constexpr int kPassSlot[3][8] = {{0, 1, 6, 7, 8, 9, 10, 11}, {16, 17, 18, 19, 20, 21, 14, 15},
+                                 {2, 4, 12, 3, 5, 13, 24, 24}};
+// kPassSlot[pass][j] for a run-time j as a select chain: a table in memory would put a load into the tail
+template <int PASS>
+__device__ __forceinline__ int pass_slot(const int j) {
+  int g = kPassSlot[PASS][0];
+#pragma unroll
+  for (int q = 1; q < 8; ++q) g = (j == q) ? kPassSlot[PASS][q] : g;
+  return g;
+}
+
+// tile: 8 * kTileStride doubles owned by this wave.  After the call, lanes with (lane & 7) == 0 hold in out[pass] the
+// wave total of statistic kPassSlot[pass][lane >> 3].
+__device__ __forceinline__ void wave_reduce24(const double (&acc)[kReadoutSlots], double* tile, double (&out)[3]) {
+  const int l = threadIdx.x & 63, stat = l >> 3, part = l & 7;
+#pragma unroll
+  for (int pass = 0; pass < 3; ++pass) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int g = kPassSlot[pass][j];
+      tile[j * kTileStride + l] = (g >= kReadoutSlots) ? INFINITY : ((pass == 2 && j >= 3) ? -acc[g] : acc[g]);
+    }
+    const double* row = tile + stat * kTileStride + part;
+    double v = row[0];
+    if (pass < 2) {
+#pragma unroll
+      for (int k = 1; k < 8; ++k) v += row[8 * k];
+      v += dpp_xchg<0xB1>(v);    // quad_perm:[1,0,3,2]  lane ^ 1
+      v += dpp_xchg<0x4E>(v);    // quad_perm:[2,3,0,1]  lane ^ 2
+      v += dpp_xchg<0x141>(v);   // row_half_mirror      lane i <-> 7 - i of its group of 8
+    } else {
+#pragma unroll
+      for (int k = 1; k < 8; ++k) v = fmin(v, row[8 * k]);
+      v = fmin(v, dpp_xchg<0xB1>(v));
+      v = fmin(v, dpp_xchg<0x4E>(v));
+      v = fmin(v, dpp_xchg<0x141>(v));
+      v = (stat >= 3) ? -v : v;  // the maxima were folded as minima of their negatives
+    }
+    out[pass] = v;
+  }
 }
 
 template <int NS>
@@ -372,6 +434,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
   __shared__ __attribute__((aligned(16))) double s_out[8][kBlock];
 #endif
   __shared__ double s_w[kBlock];   // per-lane parking slot (no barrier: a lane only reads what it wrote)
+  __shared__ double s_red[(kBlock / 64) * 8 * kTileStride];   // wave-private tiles of wave_reduce24 (18 KiB)
   const int64_t tile = tile_of(blockIdx.x, gridDim.x, xmap);
   const BundleRsrc bi = make_rsrc(a.in, n, first);
   const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -388,7 +451,11 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
                                       ((a.flags & art::kFlagReadout) && a.ro.w) ? (unsigned)(n * 8) : 0u), (unsigned)i * 8u);
     bool ok = al != 0;
     const double* zk = s_zern;
-    for (int k = 0; k < a.n_elems; ++k) {
+    // do-while (n_elems >= 1, checked on the host): with a zero-trip path the ray loads above would still be in
+    // flight where that path joins the tail, and the ONE wait the compiler then places at the join makes the main
+    // path wait for the acknowledgement of all its stores (vmcnt counts loads and stores in one in-order queue)
+    int k = 0;
+    do {
 #ifdef ART_DIAG_NOCOMPUTE
       r.path += a.e[k].mp[0];
 #else
@@ -405,7 +472,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
       // no history view for this element -> zero-length descriptors: every store is dropped by the range check
       store_slot(make_rsrc(a.out[k], a.out[k].alive != nullptr ? n : 0, first), i, r, ok);
 #endif
-    }
+    } while (++k < a.n_elems);
     if (a.flags & art::kFlagReadout) {
       // Fused detector read-out of the last bundle (art_trace_chain_readout): the ray is still in registers.  X, Y, opl
       // of dead rays are dropped by the range check.  Statistics: one partial per WAVE (shuffle tree only), written
@@ -420,17 +487,35 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
       if (ok) art::detector_ray(a.ro.det, r, Ix, Iy, Iz, x, y, o);
       const unsigned nb8 = (unsigned)(n * 8);
       const unsigned o8 = ok ? (unsigned)i * 8u : kDropOffset;
+#ifndef ART_DIAG_RO_NOXYO    // timing-only builds of the fused tail: without its per-ray outputs, ...
       st_f64(rsrc_of(a.ro.X + first, a.ro.X ? nb8 : 0u), o8, x);
       st_f64(rsrc_of(a.ro.Y + first, a.ro.Y ? nb8 : 0u), o8, y);
       st_f64(rsrc_of(a.ro.opl + first, a.ro.opl ? nb8 : 0u), o8, o);
-      asm volatile("" ::: "memory");   // the parked weight is re-read from LDS, not kept in (or spilled from) a register
-      readout_accumulate(acc, ok, x, y, o, s_w[threadIdx.x], a.ro.w != nullptr, a.ro.cx, a.ro.cy, a.ro.co);
+#endif
+      // re-read the parked weight through an index the compiler cannot prove equal to the one it was stored with
+      // (flags has no bit 30), so that the value is neither kept in a register nor spilled
+      readout_accumulate(acc, ok, x, y, o, s_w[threadIdx.x ^ ((unsigned)a.flags >> 30)], a.ro.w != nullptr, a.ro.cx,
+                         a.ro.cy, a.ro.co);
       const int64_t nparts = (int64_t)gridDim.x * (kBlock / 64);
       const int64_t part = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-#pragma unroll
-      for (int k = 0; k < kReadoutSlots; ++k) {
-        const double v = wave_reduce(acc[k], ops[k]);
-        if ((threadIdx.x & 63) == 0) a.ro.scratch[(int64_t)k * nparts + part] = v;
+      double tot[3];
+#ifdef ART_DIAG_RO_NOREDUCE  // ... without the wave reduction, ...
+      tot[0] = acc[0] + acc[1] + acc[6] + acc[7] + acc[8] + acc[9] + acc[10] + acc[11];
+      tot[1] = acc[16] + acc[17] + acc[18] + acc[19] + acc[20] + acc[21];
+      tot[2] = acc[2] + acc[3] + acc[4] + acc[5] + acc[12] + acc[13];
+#else
+      wave_reduce24(acc, s_red + (threadIdx.x >> 6) * (8 * kTileStride), tot);
+#endif
+#ifdef ART_DIAG_RO_NOSCRATCH  // ... without the partial-statistics stores
+      if (tot[0] + tot[1] + tot[2] == -1.2345e300) {
+#else
+      if ((threadIdx.x & 7) == 0) {
+#endif
+        const int stat = (threadIdx.x & 63) >> 3;
+        double* dst = a.ro.scratch + part;
+        dst[(int64_t)pass_slot<0>(stat) * nparts] = tot[0];
+        dst[(int64_t)pass_slot<1>(stat) * nparts] = tot[1];
+        if (stat < 6) dst[(int64_t)pass_slot<2>(stat) * nparts] = tot[2];
       }
     }
     i += stride;

@@ -456,7 +456,12 @@ def worker(args):
     # the detectors are in place before the timed region, so their read-out rides on the tracing launch (the ray is
     # still in registers: 24 B/ray of outputs instead of a second pass that re-reads 57 B/ray); --readout separate
     # launches art_detector_readout on the last bundle instead
-    fuse = args.readout == "fused" and mode == "chain"
+    # auto: fused for the loop-list configurations (C2, C3: many chains, a third to a half of the rays stopped by the
+    # mask -- the fused tail skips them and saves 10-11 small read-out launches: 0.48 vs 0.70 ms and 4.3 vs 5.2 ms per
+    # step); separate where every ray is alive in one long chain (relay4, C4, C5): there the tracing kernel is
+    # co-limited by its fp64 arithmetic and the extra 15 % of instructions cost what the saved re-read gains
+    # (0.85 vs 0.78 ms per step on relay4)
+    fuse = mode == "chain" and (args.readout == "fused" or (args.readout == "auto" and batched))
     program = None
     if batched or use_graph:
         program = SceneProgram([src] * n_chains, element_lists, IgnoreDefects=ignore_defects,
@@ -654,8 +659,9 @@ def main(argv=None):
     ap.add_argument("--mode", default=None, choices=[None, "chain", "element"])
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step from a HIP graph (auto: for the multi-chain configurations)")
-    ap.add_argument("--readout", default="fused", choices=["fused", "separate"],
-                    help="fused: the detector read-out rides on the tracing launch; separate: its own kernel afterwards")
+    ap.add_argument("--readout", default="auto", choices=["auto", "fused", "separate"],
+                    help="fused: the detector read-out rides on the tracing launch; separate: its own kernel afterwards; "
+                         "auto (default): fused for the multi-chain configurations, separate otherwise")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="rays of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args(argv)
     if args.cpu_sample < 0:

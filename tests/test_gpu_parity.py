@@ -577,7 +577,7 @@ def test_gpu_fused_readout_full_size(hip):
     want = D.readout(plain[-1], sync=False)
     out = mp.RayTracingCalculation(src, els, detector=D)
     got = D.readout(out[-1], sync=False)
-    assert got is out[-1]._fused_readout[2]
+    assert got["X"] is out[-1]._fused_readout[2]["X"]
     for x, y in zip(out, plain):
         assert torch.equal(x.alive, y.alive) and torch.equal(x.data, y.data)
     for k in ("X", "Y", "opl"):
