@@ -522,25 +522,61 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
   } while (DEFECT && kDefectLoop && i < n);
 }
 
-// fold of the fused read-out's per-wave partials (slot-major: scratch[slot * nparts + part]): one workgroup per
-// statistic walks its contiguous row in a fixed order; grid (24 slots, chains)
-__device__ __forceinline__ void fold_row(const double* row, const int64_t nparts, const int op_k, double* out) {
+// Fold of the fused read-out's per-wave partials (slot-major: scratch[slot * nparts + part], 1.6e5 parts per 1e7
+// rays) in two tiny launches, both in a fixed order: kFoldChunks workgroups per statistic each fold one contiguous
+// chunk of its row into mid[slot * kFoldChunks + chunk] (mid = the tail of the scratch area), then one workgroup per
+// statistic folds the chunks.  (A single workgroup per statistic walking the whole 1.25 MB row took 0.2 ms -- as long
+// as a third of the trace.)  Grids: (24, chunks, chains) and (24, 1, chains).
+constexpr int kFoldChunks = 64;
+__device__ __forceinline__ void fold_range(const double* row, const int64_t lo, const int64_t hi, const int op_k,
+                                           double* out) {
   const int op[1] = {op_k};
   double acc[1] = {(op_k == RSUM) ? 0.0 : (op_k == RMIN ? INFINITY : -INFINITY)};
-  for (int64_t p = threadIdx.x; p < nparts; p += kBlock) {
+  for (int64_t p = lo + threadIdx.x; p < hi; p += kBlock) {
     const double v = row[p];
     acc[0] = (op_k == RSUM) ? acc[0] + v : (op_k == RMIN ? fmin(acc[0], v) : fmax(acc[0], v));
   }
   block_reduce_store<1>(acc, op, out);
 }
-__global__ __launch_bounds__(kBlock) void k_chain_readout_final(const ChainArgs* __restrict__ tab, const int64_t nparts) {
-  const int ops[kReadoutSlots] = ART_READOUT_OPS;
-  const ChainArgs& a = tab[blockIdx.y];
-  fold_row(a.ro.scratch + (int64_t)blockIdx.x * nparts, nparts, ops[blockIdx.x], a.ro.out24 + blockIdx.x);
+__device__ __forceinline__ double* fold_mid(double* scratch, const int64_t nparts) {
+  return scratch + (int64_t)kReadoutSlots * nparts;
 }
-__global__ __launch_bounds__(kBlock) void k_chain_readout_final1(const double* scratch, double* out24, const int64_t nparts) {
+__device__ __forceinline__ void fold_stage1(double* scratch, const int64_t nparts) {
   const int ops[kReadoutSlots] = ART_READOUT_OPS;
-  fold_row(scratch + (int64_t)blockIdx.x * nparts, nparts, ops[blockIdx.x], out24 + blockIdx.x);
+  const int64_t per = (nparts + kFoldChunks - 1) / kFoldChunks;
+  const int64_t lo = (int64_t)blockIdx.y * per, hi = (lo + per < nparts) ? lo + per : nparts;
+  fold_range(scratch + (int64_t)blockIdx.x * nparts, lo, hi, ops[blockIdx.x],
+             fold_mid(scratch, nparts) + blockIdx.x * kFoldChunks + blockIdx.y);
+}
+__device__ __forceinline__ void fold_stage2(double* scratch, const int64_t nparts, double* out24) {
+  const int ops[kReadoutSlots] = ART_READOUT_OPS;
+  // nparts == 0 (an empty bundle): no chunk was written, the fold of nothing leaves the identities
+  fold_range(fold_mid(scratch, nparts) + blockIdx.x * kFoldChunks, 0, nparts > 0 ? kFoldChunks : 0, ops[blockIdx.x],
+             out24 + blockIdx.x);
+}
+__global__ __launch_bounds__(kBlock) void k_chain_readout_fold1(const ChainArgs* __restrict__ tab, const int64_t nparts) {
+  fold_stage1(tab[blockIdx.z].ro.scratch, nparts);
+}
+__global__ __launch_bounds__(kBlock) void k_chain_readout_fold2(const ChainArgs* __restrict__ tab, const int64_t nparts) {
+  fold_stage2(tab[blockIdx.z].ro.scratch, nparts, tab[blockIdx.z].ro.out24);
+}
+__global__ __launch_bounds__(kBlock) void k_chain_readout_fold1_one(double* scratch, const int64_t nparts) {
+  fold_stage1(scratch, nparts);
+}
+__global__ __launch_bounds__(kBlock) void k_chain_readout_fold2_one(double* scratch, double* out24, const int64_t nparts) {
+  fold_stage2(scratch, nparts, out24);
+}
+
+// launch both stages (host side)
+inline void launch_fold_one(double* scratch, double* out24, int64_t nparts, hipStream_t s) {
+  if (nparts > 0)
+    hipLaunchKernelGGL(k_chain_readout_fold1_one, dim3(kReadoutSlots, kFoldChunks), dim3(kBlock), 0, s, scratch, nparts);
+  hipLaunchKernelGGL(k_chain_readout_fold2_one, dim3(kReadoutSlots), dim3(kBlock), 0, s, scratch, out24, nparts);
+}
+inline void launch_fold_scene(const ChainArgs* seg, int n_chains, int64_t nparts, hipStream_t s) {
+  if (nparts > 0)
+    hipLaunchKernelGGL(k_chain_readout_fold1, dim3(kReadoutSlots, kFoldChunks, n_chains), dim3(kBlock), 0, s, seg, nparts);
+  hipLaunchKernelGGL(k_chain_readout_fold2, dim3(kReadoutSlots, 1, n_chains), dim3(kBlock), 0, s, seg, nparts);
 }
 
 template <bool DEFECT, int WAVES>
@@ -1092,7 +1128,7 @@ static int trace_chain_impl(const ArtElementDesc* elems, int32_t n_elems, const 
   }
   if (n == 0) {
     if (ro) {   // nothing to trace: the statistics are the reduction identities
-      hipLaunchKernelGGL(k_chain_readout_final1, dim3(kReadoutSlots), dim3(kBlock), 0, s, ro->scratch, ro->out24, (int64_t)0);
+      launch_fold_one(ro->scratch, ro->out24, 0, s);
       hipError_t e0 = hipGetLastError();
       if (e0 != hipSuccess) return fail_hip(e0, "art_trace_chain_readout launch");
     }
@@ -1147,8 +1183,7 @@ static int trace_chain_impl(const ArtElementDesc* elems, int32_t n_elems, const 
       else
         hipLaunchKernelGGL((k_trace_chain<false, 5>), g, b, 0, s, a, cnt, xm);
       if (tail)
-        hipLaunchKernelGGL(k_chain_readout_final1, dim3(kReadoutSlots), dim3(kBlock), 0, s, ro->scratch, ro->out24,
-                           (int64_t)g.x * (kBlock / 64));
+        launch_fold_one(ro->scratch, ro->out24, (int64_t)g.x * (kBlock / 64), s);
       cur = a.out[m - 1];
     }
   }
@@ -1165,8 +1200,9 @@ int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundl
 int64_t art_chain_readout_scratch_doubles(int64_t n) {
   if (n < 0) n = 0;
   if (n > kMaxRaysPerLaunchHw) n = kMaxRaysPerLaunchHw;
-  // one 24-slot partial per WAVE of the fused launch (its grid may be rounded up by the tile mapping)
-  return ((n + kBlock - 1) / kBlock + 1024) * (kBlock / 64) * kReadoutSlots;
+  // one 24-slot partial per WAVE of the fused launch (its grid may be rounded up by the tile mapping) + the chunk
+  // totals of the two-stage fold behind them
+  return (((n + kBlock - 1) / kBlock + 1024) * (kBlock / 64) + kFoldChunks) * kReadoutSlots;
 }
 
 int art_trace_chain_readout(const ArtElementDesc* elems, int32_t n_elems, const ArtBundleView* in,
@@ -1202,8 +1238,7 @@ int art_trace_scene(const void* image_dev, int32_t n_chains, int32_t n_elems, in
   const int S = art::scene_segments(n_elems);
   if (n == 0) {
     if (flags & art::kFlagReadout)
-      hipLaunchKernelGGL(k_chain_readout_final, dim3(kReadoutSlots, n_chains), dim3(kBlock), 0, s, tab + (int64_t)(S - 1) * n_chains,
-                         (int64_t)0);
+      launch_fold_scene(tab + (int64_t)(S - 1) * n_chains, n_chains, 0, s);
     return ART_OK;
   }
   const int waves = chain_waves();
@@ -1221,8 +1256,7 @@ int art_trace_scene(const void* image_dev, int32_t n_chains, int32_t n_elems, in
       else
         hipLaunchKernelGGL((k_trace_scene<false, 5>), g, b, 0, s, seg, off, cnt, xm);
       if ((flags & art::kFlagReadout) && sg == S - 1)
-        hipLaunchKernelGGL(k_chain_readout_final, dim3(kReadoutSlots, n_chains), dim3(kBlock), 0, s, seg,
-                           (int64_t)g.x * (kBlock / 64));
+        launch_fold_scene(seg, n_chains, (int64_t)g.x * (kBlock / 64), s);
     }
   }
   hipError_t err = hipGetLastError();

@@ -45,6 +45,7 @@ ALGO_BYTES_READOUT = 88.0             # read 48+8+4, write 8+8+8
 HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6300 GB/s is what a copy achieves)
 CONFIGS = ("relay4", "C2", "C3", "C4", "C5")
 EVENT_STEPS = 20    # passes whose launches are bracketed by HIP events for roofline.kernel_ms (see worker())
+IN_FLIGHT = 8       # the host enqueues at most 2 * IN_FLIGHT steps ahead of the GPU (see timed())
 
 
 def log(*a):
@@ -310,8 +311,7 @@ def profiled_traffic(config, kernel_prefix, rays):
     --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 read correction).  None when no matching profile exists."""
     import glob
     best = None
-    pats = [f"r*_{config}.json", f"r*_{config}_*.json"]
-    files = sorted({f for p in pats for f in glob.glob(os.path.join(ROOT, "profiles", p))})
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{config}.json")))    # newest round last
     for f in files:
         try:
             j = json.load(open(f))
@@ -501,7 +501,17 @@ def worker(args):
         barrier()
         sync()
         t0 = time.perf_counter()
+        marks = []
         for k in range(steps):
+            if on_gpu and k % IN_FLIGHT == 0:
+                # bounded run-ahead (a swap chain's "frames in flight"): the host stays IN_FLIGHT..2*IN_FLIGHT steps
+                # ahead of the GPU.  Unbounded, it runs into the HIP runtime's own back-pressure ~25-50 steps ahead,
+                # which blocks it for the ~40 ms the GPU needs to drain everything and then leaves the GPU idle until
+                # the queue is refilled (measured: one 40 ms stall per run, C4 2.1 instead of 1.6 ms per step)
+                if len(marks) >= 2:
+                    marks.pop(0).synchronize()
+                marks.append(torch.cuda.Event())
+                marks[-1].record()
             o, r = step(full_gather)
         t_enq = time.perf_counter() - t0     # host time to enqueue all steps (diagnostic: host-bound if ~ dt)
         if gather:
@@ -586,7 +596,10 @@ def worker(args):
                 kprefix = "k_trace_chain<" + ("true" if defects else "false")
             else:                       # per-element launches; a one-element chain is the per-element kernel too
                 kprefix = "k_trace_element<"
-            tr = profiled_traffic(cfg if fuse else cfg + "_separate", kprefix, n)
+            # profiles/r0N_<config>.json: the configuration as bench runs it by default; the other read-out mode is
+            # profiled as r0N_<config>_fused.json / _separate.json
+            pkey = cfg if fuse == batched else cfg + ("_fused" if fuse else "_separate")
+            tr = profiled_traffic(pkey, kprefix, n)
             algo = ALGO_BYTES_PER_INTERSECTION * inter_per_launch / (kernel_ms * 1e-3) / 1e9
             # what the kernel moves by construction: every chain reads its source once (57 B/slot) and writes 65 B per
             # slot and element (dead slots: only the alive byte) -- the PMC counters agree with it to 0.1 % on relay4
@@ -612,7 +625,7 @@ def worker(args):
                             "24 B/ray of outputs and the per-workgroup partial statistics are part of that kernel's "
                             "traffic and time; `--readout separate` launches k_detector_readout instead"}
             else:
-                tro = profiled_traffic(cfg + "_separate", "k_detector_readout", n) or profiled_traffic(cfg, "k_detector_readout", n)
+                tro = profiled_traffic(pkey, "k_detector_readout", n)
                 algo_ro = ALGO_BYTES_READOUT * n / (readout_ms * 1e-3) / 1e9
                 counted_ro = None if tro is None else tro[0] / (readout_ms * 1e-3) / 1e9
                 res["roofline_readout"] = {

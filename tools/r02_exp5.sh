@@ -26,13 +26,13 @@ PY
 step 900 pytest.log python -m pytest tests -m gpu -x -q -k "fused or scene_program or endtoend"
 tail -25 $OUT/pytest.log
 for rep in 1 2; do
-step 400 bench_20_$rep.log python bench.py --steps 20 --warmup 5 --cpu-sample 0;  short $OUT/bench_20_$rep.log
+step 400 bench_20_$rep.log python bench.py --steps 20 --warmup 5 --cpu-sample 0 --readout fused;  short $OUT/bench_20_$rep.log
 step 400 bench_20_sep_$rep.log python bench.py --steps 20 --warmup 5 --readout separate --cpu-sample 0; short $OUT/bench_20_sep_$rep.log
 done
-step 400 bench_100.log python bench.py --cpu-sample 0; short $OUT/bench_100.log
+step 400 bench_100.log python bench.py --cpu-sample 0 --readout fused; short $OUT/bench_100.log
 step 400 bench_100_sep.log python bench.py --readout separate --cpu-sample 0; short $OUT/bench_100_sep.log
 for c in C2 C3 C4 C5; do
-  step 400 bench_$c.log python bench.py --config $c --steps 20 --warmup 5 --cpu-sample 0; short $OUT/bench_$c.log
+  step 400 bench_$c.log python bench.py --config $c --steps 20 --warmup 5 --cpu-sample 0 --readout fused; short $OUT/bench_$c.log
   step 400 bench_${c}_sep.log python bench.py --config $c --steps 20 --warmup 5 --cpu-sample 0 --readout separate; short $OUT/bench_${c}_sep.log
 done
 V=$REPO/build/variants
