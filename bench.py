@@ -45,7 +45,6 @@ ALGO_BYTES_READOUT = 88.0             # read 48+8+4, write 8+8+8
 HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6300 GB/s is what a copy achieves)
 CONFIGS = ("relay4", "C2", "C3", "C4", "C5")
 EVENT_STEPS = 20    # passes whose launches are bracketed by HIP events for roofline.kernel_ms (see worker())
-IN_FLIGHT = 8       # the host enqueues at most 2 * IN_FLIGHT steps ahead of the GPU (see timed())
 
 
 def log(*a):
@@ -456,12 +455,11 @@ def worker(args):
     # the detectors are in place before the timed region, so their read-out rides on the tracing launch (the ray is
     # still in registers: 24 B/ray of outputs instead of a second pass that re-reads 57 B/ray); --readout separate
     # launches art_detector_readout on the last bundle instead
-    # auto: fused for the loop-list configurations (C2, C3: many chains, a third to a half of the rays stopped by the
-    # mask -- the fused tail skips them and saves 10-11 small read-out launches: 0.48 vs 0.70 ms and 4.3 vs 5.2 ms per
-    # step); separate where every ray is alive in one long chain (relay4, C4, C5): there the tracing kernel is
-    # co-limited by its fp64 arithmetic and the extra 15 % of instructions cost what the saved re-read gains
-    # (0.85 vs 0.78 ms per step on relay4)
-    fuse = mode == "chain" and (args.readout == "fused" or (args.readout == "auto" and batched))
+    # auto: fused, except for one long chain (>= 8 elements, C4).  Measured per step, fused vs separate:
+    # C2 0.47 vs 0.70 ms, C3 4.09 vs 5.25 ms (many chains, a third to a half of the rays stopped by the mask: the fused
+    # tail skips them and replaces 10-11 small read-out launches), relay4 0.71 vs 0.75 ms, C5 0.40 vs 0.42 ms; C4
+    # 1.64 vs 1.55 ms -- behind eight elements the tail's extra arithmetic costs more than the saved re-read gains.
+    fuse = mode == "chain" and (args.readout == "fused" or (args.readout == "auto" and (batched or n_elems < 8)))
     program = None
     if batched or use_graph:
         program = SceneProgram([src] * n_chains, element_lists, IgnoreDefects=ignore_defects,
@@ -493,6 +491,14 @@ def worker(args):
                 state["step"] += 1
         return o, r
 
+    # Python's cyclic collector: a full (generation-2) pass walks the ~1e6 objects that importing torch/numpy leaves
+    # behind and stops the host for ~40 ms -- once per run, at an arbitrary step; in a 20-step timed region of 0.8-ms
+    # steps that is the difference between 1.6 and 2.1 ms per step (tools/host_timing.py).  Everything alive now is
+    # moved to the permanent generation; the steps themselves create no reference cycles.
+    import gc
+    gc.collect()
+    gc.freeze()
+
     def timed(full_gather, steps):
         for _ in range(args.warmup):
             step(full_gather)
@@ -501,17 +507,7 @@ def worker(args):
         barrier()
         sync()
         t0 = time.perf_counter()
-        marks = []
         for k in range(steps):
-            if on_gpu and k % IN_FLIGHT == 0:
-                # bounded run-ahead (a swap chain's "frames in flight"): the host stays IN_FLIGHT..2*IN_FLIGHT steps
-                # ahead of the GPU.  Unbounded, it runs into the HIP runtime's own back-pressure ~25-50 steps ahead,
-                # which blocks it for the ~40 ms the GPU needs to drain everything and then leaves the GPU idle until
-                # the queue is refilled (measured: one 40 ms stall per run, C4 2.1 instead of 1.6 ms per step)
-                if len(marks) >= 2:
-                    marks.pop(0).synchronize()
-                marks.append(torch.cuda.Event())
-                marks[-1].record()
             o, r = step(full_gather)
         t_enq = time.perf_counter() - t0     # host time to enqueue all steps (diagnostic: host-bound if ~ dt)
         if gather:
@@ -598,7 +594,8 @@ def worker(args):
                 kprefix = "k_trace_element<"
             # profiles/r0N_<config>.json: the configuration as bench runs it by default; the other read-out mode is
             # profiled as r0N_<config>_fused.json / _separate.json
-            pkey = cfg if fuse == batched else cfg + ("_fused" if fuse else "_separate")
+            auto_fuse = batched or n_elems < 8
+            pkey = cfg if fuse == auto_fuse else cfg + ("_fused" if fuse else "_separate")
             tr = profiled_traffic(pkey, kprefix, n)
             algo = ALGO_BYTES_PER_INTERSECTION * inter_per_launch / (kernel_ms * 1e-3) / 1e9
             # what the kernel moves by construction: every chain reads its source once (57 B/slot) and writes 65 B per
@@ -674,7 +671,7 @@ def main(argv=None):
                     help="replay the step from a HIP graph (auto: for the multi-chain configurations)")
     ap.add_argument("--readout", default="auto", choices=["auto", "fused", "separate"],
                     help="fused: the detector read-out rides on the tracing launch; separate: its own kernel afterwards; "
-                         "auto (default): fused for the multi-chain configurations, separate otherwise")
+                         "auto (default): fused, except for a single chain of 8 or more elements")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="rays of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args(argv)
     if args.cpu_sample < 0:

@@ -33,9 +33,9 @@ for c in relay4 C2 C3 C4 C5; do
   step 120 sum_$c.log python tools/summarize_profile.py gpurun_out/prof_r02_$c gpurun_out/prof_r02_$c/r02_$c.md $n "--config $c --steps 20 --warmup 5"
   grep -h "^| k_trace\|^| k_detector_readout\|calibration" $OUT/sum_$c.log | head -8
 done
-step 900 prof_relay4_fused.log bash tools/prof.sh r02_relay4_fused --readout fused --steps 20 --warmup 5
-step 120 sum_relay4_fused.log python tools/summarize_profile.py gpurun_out/prof_r02_relay4_fused gpurun_out/prof_r02_relay4_fused/r02_relay4_fused.md 10000000 "--readout fused --steps 20 --warmup 5"
-grep -h "^| k_trace\|^| k_detector_readout" $OUT/sum_relay4_fused.log | head -4
+step 900 prof_relay4_separate.log bash tools/prof.sh r02_relay4_separate --readout separate --steps 20 --warmup 5
+step 120 sum_relay4_separate.log python tools/summarize_profile.py gpurun_out/prof_r02_relay4_separate gpurun_out/prof_r02_relay4_separate/r02_relay4_separate.md 10000000 "--readout separate --steps 20 --warmup 5"
+grep -h "^| k_trace\|^| k_detector_readout" $OUT/sum_relay4_separate.log | head -4
 step 900 prof_C3_separate.log bash tools/prof.sh r02_C3_separate --config C3 --readout separate --steps 20 --warmup 5
 step 120 sum_C3_separate.log python tools/summarize_profile.py gpurun_out/prof_r02_C3_separate gpurun_out/prof_r02_C3_separate/r02_C3_separate.md 10000000 "--config C3 --readout separate --steps 20 --warmup 5"
 grep -h "^| k_trace\|^| k_detector_readout" $OUT/sum_C3_separate.log | head -4
