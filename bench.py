@@ -588,9 +588,9 @@ def worker(args):
             defects = any(len(getattr(oe.type, "DeformationList", [])) > 0 for els in element_lists for oe in els)
             if program is not None:
                 kprefix = "k_trace_scene<" + ("true" if defects else "false")
-            elif mode == "chain" and n_elems > 1:
+            elif mode == "chain" and (n_elems > 1 or fuse):
                 kprefix = "k_trace_chain<" + ("true" if defects else "false")
-            else:                       # per-element launches; a one-element chain is the per-element kernel too
+            else:                       # per-element launches; a one-element chain without read-out is that kernel too
                 kprefix = "k_trace_element<"
             # profiles/r0N_<config>.json: the configuration as bench runs it by default; the other read-out mode is
             # profiled as r0N_<config>_fused.json / _separate.json
