@@ -195,6 +195,15 @@ def run_differential(seeds, modes=("chain", "element"), n_rays=1500):
                 for key, v in err.items():
                     assert v <= tols[key], f"{tag}, mode {mode}, element {k}: {key} error {v:.3e} > {tols[key]:.1e}"
                     worst[key] = max(worst[key], float(v))
+            if mode == "chain" and seed % 3 == 0:
+                # the scene-table launch (two copies of the chain in one launch) is the same per-ray code: bit-identical
+                many = mp.RayTracingCalculationMany([src, src], [els, els], IgnoreDefects=scene["IgnoreDefects"])
+                for o2 in many:
+                    for x, y in zip(o2, outs):
+                        al = y.alive.cpu().numpy()
+                        assert np.array_equal(x.alive.cpu().numpy(), al), f"{tag}: scene launch, survivors"
+                        m_ = al.astype(bool)
+                        assert np.array_equal(x.data.cpu().numpy()[:, m_], y.data.cpu().numpy()[:, m_]), f"{tag}: scene launch"
     return {"worst": worst, "scenes_with_hits": hits, "scenes": len(list(seeds))}
 
 
@@ -251,6 +260,20 @@ def run_detector_fuzz(seeds, n_rays=1200):
                 <= 1e-10 * sc * amp, tag
             mean_t_fs = np.mean(orc.optical_paths(Dq, last_o)) / orc.LightSpeed * 1e15
             assert np.abs(Dp.get_Delays(last) - orc.detector_delays(Dq, last_o)).max() <= 1e-10 * mean_t_fs * amp, tag
+            # the read-out fused behind the tracing launch: per-ray values bit-identical to the separate read-out,
+            # counts / minima / maxima exact, sums to rounding
+            sep = Dp.readout(last, sync=False)
+            fus_last = mp.RayTracingCalculation(src, els, IgnoreDefects=scene["IgnoreDefects"], detector=Dp)[-1]
+            fus = Dp.readout(fus_last, sync=False)
+            assert fus_last._fused_readout is not None and fus["X"] is fus_last._fused_readout[2]["X"], tag
+            m_ = last.alive.cpu().numpy().astype(bool)
+            for key in ("X", "Y", "opl"):
+                assert np.array_equal(fus[key].cpu().numpy()[m_], sep[key].cpu().numpy()[m_]), f"{tag}: fused {key}"
+            fs, ss = fus["stats_dev"].cpu().numpy(), sep["stats_dev"].cpu().numpy()
+            assert all(fs[k] == ss[k] for k in (0, 2, 3, 4, 5, 12, 13)), f"{tag}: fused statistics (exact slots)"
+            # second moments are about provisional centres (0, 0, 0): compare against the magnitude of the summands
+            mag = max(1.0, float(np.abs(ss).max()))
+            assert np.abs(fs - ss).max() <= 1e-11 * mag, f"{tag}: fused statistics (sums)"
             checked += 1
     return checked
 
