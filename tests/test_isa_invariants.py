@@ -1,0 +1,90 @@
+"""CPU (no GPU needed): performance-critical properties of the gfx950 device code, read off the compiler's assembly
+(hipcc cross-compiles here).  Each of them was worth 10-50 % when it was found:
+  * the fused chain kernel fits 5 waves per SIMD (<= 96 VGPRs) without scratch;
+  * after its first store the fused chain / scene kernel never waits on vmcnt again -- gfx9 counts loads and stores in
+    one in-order queue, so a late load, a fence or a scratch reload makes every wave wait for the acknowledgement of all
+    its outstanding stores instead of retiring;
+  * the scene kernel fetches its descriptors with scalar loads only (no vector loads of table data);
+  * the Zernike evaluators keep their coefficients scalar (no LDS traffic in the defect kernels; <= 128 VGPRs)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "attosecondraytracing_amd", "csrc", "art_kernels.hip")
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    out = str(tmp_path_factory.mktemp("isa") / "art.s")
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, SRC],
+                          stderr=subprocess.DEVNULL)
+    s = open(out).read()
+    meta = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", s, re.S):
+        g = lambda key: int(re.search(r"\.amdhsa_%s (\d+)" % key, m.group(2)).group(1))
+        meta[m.group(1)] = {"vgpr": g("next_free_vgpr"), "lds": g("group_segment_fixed_size"),
+                            "scratch": g("private_segment_fixed_size")}
+    parts = re.split(r"\n(_Z\w+):[^\n]*\n", s)
+    res = {}
+    for name, body in zip(parts[1::2], parts[2::2]):
+        if name in meta:
+            dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
+            dem = dem.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+            res[dem] = dict(meta[name], code=body[:body.rfind("s_endpgm") + 8].splitlines())
+    return res
+
+
+def _after_first_store(code, pattern):
+    first = next(i for i, l in enumerate(code) if "buffer_store" in l)
+    return [l.strip() for l in code[first:] if re.search(pattern, l)]
+
+
+def test_fused_chain_kernel_occupancy(kernels):
+    for name in ("k_trace_chain<false, 5>", "k_trace_scene<false, 5>"):
+        k = kernels[name]
+        assert k["vgpr"] <= 96, (name, k["vgpr"])        # 5 waves per SIMD
+        assert k["scratch"] == 0, (name, k["scratch"])    # a scratch reload is a VMEM load behind the stores
+        assert k["lds"] <= 32 * 1024, (name, k["lds"])    # 5 workgroups per CU fit 160 KiB
+    for name in ("k_trace_chain<true, 4>", "k_trace_scene<true, 4>"):
+        k = kernels[name]
+        assert k["vgpr"] <= 128, (name, k["vgpr"])
+        # (the compiler may reserve a few bytes of private segment without using them: what counts is that no spill
+        # or reload instruction exists)
+        assert not [l for l in k["code"] if re.search(r"scratch_(load|store)|Folded (Spill|Reload)", l)], name
+
+
+def test_no_wait_for_store_acknowledgements(kernels):
+    for name in ("k_trace_chain<false, 5>", "k_trace_chain<false, 4>", "k_trace_scene<false, 5>", "k_trace_scene<false, 4>"):
+        waits = _after_first_store(kernels[name]["code"], r"s_waitcnt.*vmcnt")
+        assert not waits, (name, waits[:5])
+        # nothing that needs such a wait either: loads of any kind, barriers
+        late = _after_first_store(kernels[name]["code"], r"\b(buffer_load|global_load|flat_load|scratch_load|s_barrier)\b")
+        assert not late, (name, late[:5])
+
+
+def test_scene_descriptors_are_scalar_loads(kernels):
+    for name in ("k_trace_scene<false, 5>", "k_trace_scene<true, 4>"):
+        code = kernels[name]["code"]
+        assert sum("s_load" in l for l in code) > 100, name
+        assert not [l for l in code if re.search(r"\b(global_load|flat_load)\b", l) and "grid" in name], name
+    # without gridded defects there is no vector load besides the ray's own 9 streams
+    code = kernels["k_trace_scene<false, 5>"]["code"]
+    assert not [l for l in code if re.search(r"\b(global_load|flat_load)\b", l)]
+    assert sum("buffer_load" in l for l in code) == 9
+
+
+def test_zernike_coefficients_stay_scalar(kernels):
+    for kind in range(6):
+        k = kernels[f"k_trace_element<{kind}, true>"]
+        assert k["vgpr"] <= 104 and k["lds"] == 0 and k["scratch"] == 0, (kind, k["vgpr"], k["lds"], k["scratch"])
+        code = k["code"]
+        # coefficients arrive through s_load and are consumed as the scalar operand of v_fma_f64 ...
+        assert sum(bool(re.search(r"v_fma_f64 v\[\d+:\d+\], v\[\d+:\d+\], v\[\d+:\d+\], s\[\d+:\d+\]", l)) for l in code) > 300, kind
+        # ... not copied into VGPRs first (the compiler's two-address v_fmac form needs 2 v_mov per coefficient)
+        assert sum("v_mov_b32" in l for l in code) < 400, kind
