@@ -541,7 +541,9 @@ __device__ __forceinline__ void fold_range(const double* row, const int64_t lo, 
 __device__ __forceinline__ double* fold_mid(double* scratch, const int64_t nparts) {
   return scratch + (int64_t)kReadoutSlots * nparts;
 }
+constexpr int kUsedSlots = 22;   // slots 22, 23 of the statistics are reserved (always 0): the tail writes no partials for them
 __device__ __forceinline__ void fold_stage1(double* scratch, const int64_t nparts) {
+  if (blockIdx.x >= kUsedSlots) return;
   const int ops[kReadoutSlots] = ART_READOUT_OPS;
   const int64_t per = (nparts + kFoldChunks - 1) / kFoldChunks;
   const int64_t lo = (int64_t)blockIdx.y * per, hi = (lo + per < nparts) ? lo + per : nparts;
@@ -549,6 +551,10 @@ __device__ __forceinline__ void fold_stage1(double* scratch, const int64_t npart
              fold_mid(scratch, nparts) + blockIdx.x * kFoldChunks + blockIdx.y);
 }
 __device__ __forceinline__ void fold_stage2(double* scratch, const int64_t nparts, double* out24) {
+  if (blockIdx.x >= kUsedSlots) {
+    if (threadIdx.x == 0) out24[blockIdx.x] = 0.0;
+    return;
+  }
   const int ops[kReadoutSlots] = ART_READOUT_OPS;
   // nparts == 0 (an empty bundle): no chunk was written, the fold of nothing leaves the identities
   fold_range(fold_mid(scratch, nparts) + blockIdx.x * kFoldChunks, 0, nparts > 0 ? kFoldChunks : 0, ops[blockIdx.x],

@@ -196,14 +196,25 @@ def run_differential(seeds, modes=("chain", "element"), n_rays=1500):
                     assert v <= tols[key], f"{tag}, mode {mode}, element {k}: {key} error {v:.3e} > {tols[key]:.1e}"
                     worst[key] = max(worst[key], float(v))
             if mode == "chain" and seed % 3 == 0:
-                # the scene-table launch (two copies of the chain in one launch) is the same per-ray code: bit-identical
+                # The scene-table launch (two copies of the chain in one launch) runs the fused kernel's per-ray code:
+                # bit-identical to the single launch when that is the same kernel body (>= 2 elements, no defects); a
+                # one-element chain is dispatched to the kind-specialised kernel and chains with defects go through the
+                # run-time-dispatch body -- other instruction orders, so agreement to rounding there.
                 many = mp.RayTracingCalculationMany([src, src], [els, els], IgnoreDefects=scene["IgnoreDefects"])
+                same_body = len(els) >= 2 and not any(e.get("defects") for e in scene["elements"])
                 for o2 in many:
                     for x, y in zip(o2, outs):
                         al = y.alive.cpu().numpy()
                         assert np.array_equal(x.alive.cpu().numpy(), al), f"{tag}: scene launch, survivors"
                         m_ = al.astype(bool)
-                        assert np.array_equal(x.data.cpu().numpy()[:, m_], y.data.cpu().numpy()[:, m_]), f"{tag}: scene launch"
+                        xd, yd = x.data.cpu().numpy()[:, m_], y.data.cpu().numpy()[:, m_]
+                        if same_body:
+                            assert np.array_equal(xd, yd), f"{tag}: scene launch"
+                        elif m_.any():
+                            # the incidence angle of a near-normal ray amplifies rounding: 1e-9 rad as everywhere
+                            assert np.abs(xd[0:3] - yd[0:3]).max() <= 1e-12 * scale and np.abs(xd[3:6] - yd[3:6]).max() <= 1e-12 \
+                                and np.abs(xd[6] - yd[6]).max() <= 1e-12 * max(scale, np.abs(yd[6]).max()) \
+                                and np.abs(xd[7] - yd[7]).max() <= 1e-9, f"{tag}: scene launch (rounding)"
     return {"worst": worst, "scenes_with_hits": hits, "scenes": len(list(seeds))}
 
 
@@ -262,11 +273,16 @@ def run_detector_fuzz(seeds, n_rays=1200):
             assert np.abs(Dp.get_Delays(last) - orc.detector_delays(Dq, last_o)).max() <= 1e-10 * mean_t_fs * amp, tag
             # the read-out fused behind the tracing launch: per-ray values bit-identical to the separate read-out,
             # counts / minima / maxima exact, sums to rounding
-            sep = Dp.readout(last, sync=False)
             fus_last = mp.RayTracingCalculation(src, els, IgnoreDefects=scene["IgnoreDefects"], detector=Dp)[-1]
             fus = Dp.readout(fus_last, sync=False)
             assert fus_last._fused_readout is not None and fus["X"] is fus_last._fused_readout[2]["X"], tag
-            m_ = last.alive.cpu().numpy().astype(bool)
+            # ... of the SAME bundle (a one-element or defect chain is traced by another kernel body with the read-out
+            # fused than without: equal to rounding, not bit for bit)
+            fus_last._fused_readout = None
+            sep = Dp.readout(fus_last, sync=False)
+            assert sep["X"] is not fus["X"], tag
+            m_ = fus_last.alive.cpu().numpy().astype(bool)
+            assert np.array_equal(m_, last.alive.cpu().numpy().astype(bool)), tag
             for key in ("X", "Y", "opl"):
                 assert np.array_equal(fus[key].cpu().numpy()[m_], sep[key].cpu().numpy()[m_]), f"{tag}: fused {key}"
             fs, ss = fus["stats_dev"].cpu().numpy(), sep["stats_dev"].cpu().numpy()
