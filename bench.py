@@ -565,7 +565,8 @@ def worker(args):
         res = {
             "metric": "ray-surface intersections/s", "value": value, "unit": "intersections/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic" if on_gpu else f"synthetic -- TEST HOOK {hook}: CPU ranks, NOT a measurement",
             "config": {"workload": f"{label}; {n} rays/GPU x {n_elems} elements x {n_chains} chain(s) = "
                                    f"{inter_per_step_rank} intersections/step on rank 0, {inter_per_step_job} on all "
                                    f"{world} rank(s); full per-element history",
