@@ -218,7 +218,6 @@ def run_fused_readout():
         same_readout(dets[j].readout(o[-1], sync=False), dets[j].copy_detector().readout(ref_out[-1], sync=False), o[-1].alive)
         assert dets[j].readout(o[-1], sync=False)["X"] is prog.readouts[0]["X"]
     # empty and all-dead bundles: reduction identities
-    from attosecondraytracing_amd.bundle import RayBundle
     dead = src.copy()
     dead.alive.zero_()
     st = D.readout(mp.RayTracingCalculation(dead, e, detector=D)[-1])["stats"]

@@ -12,7 +12,6 @@ element written; the PMC counters agree with this count to 0.1 %, profiles/).  W
 import os
 import sys
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
