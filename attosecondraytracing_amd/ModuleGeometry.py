@@ -107,6 +107,13 @@ def IncludeDisk(R, Point):
 
 
 # ------------------------------------------------------------------------------------------------- rotations
+def _cross3(a, b):
+    """np.cross for two 3-vectors, component by component (the same products and differences, so the same bits):
+    np.cross spends ~40 us per call on axis bookkeeping, and building the frame maps of one optical element needs 28
+    cross products -- that was 0.3 ms per element, i.e. the whole host cost of tracing a loop list."""
+    return np.array([a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]])
+
+
 def RotationAroundAxis(Axis, Angle, Vector):
     """Rotate Vector by Angle (rad) about Axis (ART/ModuleGeometry.py:321-329, there via a unit quaternion).
     Written as the equivalent Rodrigues sum with half-angle terms: v + 2w(a x v) + 2 a x (a x v),
@@ -115,8 +122,8 @@ def RotationAroundAxis(Axis, Angle, Vector):
     v = np.asarray(Vector, dtype=float)
     a = np.sin(0.5 * Angle) * k
     w = np.cos(0.5 * Angle)
-    av = np.cross(a, v)
-    return v + 2.0 * (w * av + np.cross(a, av))
+    av = _cross3(a, v)
+    return v + 2.0 * (w * av + _cross3(a, av))
 
 
 def rotation_matrix(Axis1, Axis2):
@@ -127,7 +134,7 @@ def rotation_matrix(Axis1, Axis2):
         return np.eye(3)
     if abs(ang - np.pi) < 1e-10:
         return -np.eye(3)
-    N = np.cross(Axis1, Axis2)
+    N = _cross3(np.asarray(Axis1, dtype=float), np.asarray(Axis2, dtype=float))
     return np.stack([RotationAroundAxis(N, ang, e) for e in np.eye(3)], axis=1)
 
 

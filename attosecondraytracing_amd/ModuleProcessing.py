@@ -266,12 +266,12 @@ def RayTracingCalculationMany(source_rays_list, optical_elements_list, IgnoreDef
         for d, s_, area in zip(detectors, sources, areas):
             d._iscomplete()
             ros.append(be.new_chain_readout(d._desc(), s_.intensity, n, scratch=area))
-    host, dev = be.scene_alloc(c, m)
+    host, dev = be.scene_alloc(c, m, transient=True)
     flags = be.scene_pack(descs, [s.view() for s in sources], views, c, m, host, ros)
     be.scene_upload(host, dev)
     be.trace_scene(dev, c, m, flags, n)
     for ci, outs in enumerate(grid):
-        outs[-1]._keepalive = (keep, scratch, host, dev)
+        outs[-1]._keepalive = (keep, scratch)
         if ros is not None:
             _attach_readout(outs[-1], detectors[ci], 0.0, ros[ci])
     return grid

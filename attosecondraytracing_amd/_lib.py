@@ -46,6 +46,7 @@ class HipBackend:
                                % (n, self.last_error()))
         self.device = torch.device("cuda", torch.cuda.current_device())
         self._scratch = {}
+        self._scene_pool, self._scene_uploads = {}, {}
         self.trace_events = None   # set to a list to collect (start, end) HIP events around each trace launch
         self.readout_events = None  # likewise around each fused read-out (kernel + final fold)
 
@@ -141,11 +142,24 @@ class HipBackend:
         return [t[k * per:(k + 1) * per] for k in range(count)]
 
     # scene table (include/art_hip.h: art_scene_bytes / art_scene_pack / art_trace_scene): many chains, one launch
-    def scene_alloc(self, n_chains, n_elems):
-        """(pinned host image, device image) uint8 tensors of art_scene_bytes(n_chains, n_elems)."""
+    def scene_alloc(self, n_chains, n_elems, transient=False):
+        """(pinned host image, device image) uint8 tensors of art_scene_bytes(n_chains, n_elems).
+        transient=True (one-shot launches, RayTracingCalculationMany): the pair comes from a per-size pool instead of
+        being allocated -- pinning host memory costs milliseconds.  A pooled pair is reused by the next call of the
+        same size: the device image is only read by launches that were enqueued before the next upload on the same
+        stream, and the pinned image is re-packed only after its last upload has completed (scene_pack waits)."""
         nb = int(self.fn["art_scene_bytes"](n_chains, n_elems))
         if nb <= 0:
             raise ArtError("art_scene_bytes: bad chain or element count")
+        if transient:
+            pair = self._scene_pool.get(nb)
+            if pair is None:
+                pair = self._scene_pool[nb] = (torch.empty(nb, dtype=torch.uint8, pin_memory=True),
+                                               torch.empty(nb, dtype=torch.uint8, device=self.device))
+            ev = self._scene_uploads.pop(pair[0].data_ptr(), None)
+            if ev is not None:
+                ev.synchronize()
+            return pair
         return (torch.empty(nb, dtype=torch.uint8, pin_memory=True),
                 torch.empty(nb, dtype=torch.uint8, device=self.device))
 
@@ -166,6 +180,7 @@ class HipBackend:
         dev_image.copy_(host_image, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
+        self._scene_uploads[host_image.data_ptr()] = ev
         return ev
 
     def trace_scene(self, dev_image, n_chains, n_elems, flags, n):

@@ -120,7 +120,7 @@ class TwinBackend:
         assert self.lib.art_cpu_trace_chain(darr, m, C.byref(vin), varr, n) == 0
 
     # scene table: the same packer (csrc/art_scene.h) compiled into the twin, "device" image = the host image
-    def scene_alloc(self, n_chains, n_elems):
+    def scene_alloc(self, n_chains, n_elems, transient=False):
         f = self.lib.art_cpu_scene_bytes
         f.restype, f.argtypes = C.c_int64, [C.c_int32, C.c_int32]
         img = torch.empty(int(f(n_chains, n_elems)), dtype=torch.uint8)
