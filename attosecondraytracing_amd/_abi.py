@@ -119,6 +119,8 @@ PROTOTYPES = {
     "art_compact": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "art_make_source": (C.c_int, [C.c_int32, C.c_double, c_double_p, c_double_p, C.c_int64, C.c_int64, C.c_int64,
                                   C.POINTER(ArtBundleView), C.c_void_p]),
+    "art_make_source_strided": (C.c_int, [C.c_int32, C.c_double, c_double_p, c_double_p, C.c_int64, C.c_int64, C.c_int64,
+                                          C.c_int64, C.POINTER(ArtBundleView), C.c_void_p]),
     "art_exchange_pack": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_void_p, C.c_void_p]),
     "art_exchange_fold": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "art_make_extended_source": (C.c_int, [C.c_double, C.c_double, C.c_int64, C.c_int64, c_double_p, c_double_p,

@@ -295,11 +295,12 @@ class HipBackend:
         c = int(cnt.cpu().item())
         return idx[:c], c
 
-    def make_source(self, kind, size, rot, S, first, n, n_total, view):
+    def make_source(self, kind, size, rot, S, first, n, n_total, view, step=1):
+        """Slots 0..n-1 = global rays first, first + step, ... of an n_total-ray source (art_make_source_strided)."""
         r = (C.c_double * 9)(*[float(v) for v in np.asarray(rot).reshape(9)])
         s = (C.c_double * 3)(*[float(v) for v in np.asarray(S).reshape(3)])
-        self.check(self.fn["art_make_source"](kind, float(size), r, s, first, n, n_total, C.byref(view),
-                                              self.stream_ptr()), "art_make_source")
+        self.check(self.fn["art_make_source_strided"](kind, float(size), r, s, first, int(step), n, n_total, C.byref(view),
+                                                      self.stream_ptr()), "art_make_source_strided")
 
     def exchange_pack(self, stats, X, Y, opl, alive, slots, send):
         """stats[24] + (X, Y, opl, alive) of the sampled slots -> send[24 + 4k] (art_exchange_pack)."""

@@ -943,13 +943,14 @@ __global__ __launch_bounds__(kBlock) void k_compact_scatter(const uint8_t* alive
 
 // ------------------------------------------------------------------------------------------- sources
 __global__ __launch_bounds__(kBlock) void k_make_source(const int32_t kind, const double size, const ArtDetectorDesc rs,
-                                                        const int64_t first, const int64_t n, const int64_t n_total,
-                                                        const ArtBundleView out) {
-  // rs.rot = rotation ez -> axis, rs.centre = S (ArtDetectorDesc reused as a POD carrier)
+                                                        const int64_t first, const int64_t step, const int64_t n,
+                                                        const int64_t n_total, const ArtBundleView out) {
+  // rs.rot = rotation ez -> axis, rs.centre = S (ArtDetectorDesc reused as a POD carrier); slot i = global ray
+  // first + i * step (step 1: a contiguous shard; step = world size: a strided one)
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
     art::Ray r;
-    art::source_ray(kind, size, rs.rot, rs.centre, first + i, n_total, r);
+    art::source_ray(kind, size, rs.rot, rs.centre, first + i * step, n_total, r);
     store_ray(out, i, r);
     out.alive[i] = 1;
   }
@@ -1492,16 +1493,22 @@ int art_compact(const uint8_t* alive, int64_t n, int32_t* block_counts, int64_t*
 
 int art_make_source(int32_t kind, double size, const double rot[9], const double S[3], int64_t first, int64_t n,
                     int64_t n_total, const ArtBundleView* out, void* stream) {
+  return art_make_source_strided(kind, size, rot, S, first, 1, n, n_total, out, stream);
+}
+
+int art_make_source_strided(int32_t kind, double size, const double rot[9], const double S[3], int64_t first,
+                            int64_t step, int64_t n, int64_t n_total, const ArtBundleView* out, void* stream) {
   if (kind != 0 && kind != 1) return fail(ART_ERR_BAD_ARG, "source kind must be 0 (point) or 1 (plane-wave disk)");
   if (!rot || !S || !view_ok(out)) return fail(ART_ERR_BAD_ARG, "NULL argument");
-  if (n < 0 || first < 0 || n_total <= 0 || first + n > n_total) return fail(ART_ERR_BAD_ARG, "bad index range");
+  if (n < 0 || first < 0 || step < 1 || n_total <= 0 || (n > 0 && first + (n - 1) * step >= n_total))
+    return fail(ART_ERR_BAD_ARG, "bad index range");
   if (n == 0) return ART_OK;
   ArtDetectorDesc rs;
   memset(&rs, 0, sizeof(rs));
   memcpy(rs.rot, rot, 9 * sizeof(double));
   memcpy(rs.centre, S, 3 * sizeof(double));
-  hipLaunchKernelGGL(k_make_source, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, kind, size, rs, first, n,
-                     n_total, *out);
+  hipLaunchKernelGGL(k_make_source, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, kind, size, rs, first, step,
+                     n, n_total, *out);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_make_source launch");
   return ART_OK;

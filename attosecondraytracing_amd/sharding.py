@@ -18,6 +18,29 @@ def shard_range(n_total, rank, world):
     return (n_total * rank) // world, (n_total * (rank + 1)) // world
 
 
+def shard_spec(n_total, rank, world, layout="blocks"):
+    """(first, step, n) of `rank`'s shard: slot i holds global ray first + i * step.
+    "blocks": contiguous index ranges (shard_range; rank order = global ray order).
+    "strided": rank r holds rays r, r + world, r + 2 world, ... -- every rank samples the whole aperture of a Vogel
+    spiral (which orders rays by radius), so masks and overfilled apertures cost every rank the same share of its rays;
+    the global order is restored by interleaving (assemble)."""
+    if layout == "blocks":
+        lo, hi = shard_range(n_total, rank, world)
+        return lo, 1, hi - lo
+    if layout == "strided":
+        return rank, world, (n_total - rank + world - 1) // world if n_total > rank else 0
+    raise ValueError("layout must be 'blocks' or 'strided'")
+
+
+def assemble(per_rank, layout="blocks"):
+    """Global-order array from equal-length per-rank results [world, ..., n] (e.g. ReadoutGather.result):
+    concatenation for "blocks", interleaving for "strided" -> [..., world * n]."""
+    world, n = per_rank.shape[0], per_rank.shape[-1]
+    if layout == "blocks":
+        return torch.cat(list(per_rank), dim=-1)
+    return torch.stack(list(per_rank), dim=-1).reshape(per_rank.shape[1:-1] + (n * world,))
+
+
 class PendingStats:
     """Handle of an in-flight statistics exchange (allreduce_stats(..., async_op=True)): `.result()` waits for the
     collective (on the caller's stream, not the host) and folds the per-rank vectors."""

@@ -157,8 +157,9 @@ def scene_c5():
     return [ch.optical_elements], ("plane", 20.0), 25.4
 
 
-def device_source(n, first, n_total, be, kind=("point", 0.02), wavelength=50e-6):
-    """Shard [first, first+n) of an n_total-ray source (point: half-angle; plane: disk radius), generated on the device."""
+def device_source(n, first, n_total, be, kind=("point", 0.02), wavelength=50e-6, step=1):
+    """Rays first, first + step, ... (n of them) of an n_total-ray source (point: half-angle; plane: disk radius),
+    generated on the device."""
     import numpy as np
     import torch
     from attosecondraytracing_amd.bundle import RayBundle
@@ -166,7 +167,7 @@ def device_source(n, first, n_total, be, kind=("point", 0.02), wavelength=50e-6)
     b = RayBundle.allocate(n, backend=be)
     b.wavelength = wavelength
     rot = mgeo.rotation_matrix(np.array([0.0, 0.0, 1.0]), np.array([1.0, 0.0, 0.0]))
-    be.make_source(0 if kind[0] == "point" else 1, kind[1], rot, np.zeros(3), first, n, n_total, b.view())
+    be.make_source(0 if kind[0] == "point" else 1, kind[1], rot, np.zeros(3), first, n, n_total, b.view(), step=step)
     b.intensity = torch.ones(n, dtype=torch.float64, device=be.device)
     return b
 
@@ -412,11 +413,13 @@ def worker(args):
         label = "C5 CONFIG_deformed geometry: parabola f=25.4 mm + 6th-order Zernike defect, perturbed normals -> detector"
     n_chains, n_elems = len(element_lists), len(element_lists[0])
     n_total = n * world
-    lo, hi = sharding.shard_range(n_total, rank, world)
-    assert hi - lo == n
+    # --shard blocks (default): contiguous index ranges; strided: rank r traces rays r, r + N, ... -- balanced
+    # where a mask or an overfilled aperture stops the outer rays of the Vogel spiral (C2, C3)
+    first, stride, n_shard = sharding.shard_spec(n_total, rank, world, args.shard)
+    assert n_shard == n
     wl = 800e-6 if cfg == "C5" else 50e-6
     # one resident source shard shared by all chains (OEPlacement gives every chain of a loop list the same source)
-    src = device_source(n, lo, n_total, be, src_kind, wl)
+    src = device_source(n, first, n_total, be, src_kind, wl, step=stride)
     batched = n_chains > 1
     # small bundles are launch-bound: replay the whole step (trace + read-outs) from a HIP graph
     use_graph = on_gpu and (args.graph == "on" or (args.graph == "auto" and batched))
@@ -586,7 +589,7 @@ def worker(args):
                                    f"{world} rank(s); full per-element history",
                        "name": cfg, "rays_per_gpu": n, "elements": n_elems, "chains": n_chains,
                        "trace_mode": "scene (one launch for all chains)" if program is not None else mode,
-                       "hip_graph": bool(use_graph), "world_size_seen": world,
+                       "hip_graph": bool(use_graph), "world_size_seen": world, "shard_layout": args.shard,
                        "readout": "fused into the tracing launch" if fuse else "separate launch",
                        "step": "RayTracingCalculation + Detector.readout"
                                + (f" + ONE RCCL all-gather of every shard's 24 statistics and a {sample_k * world}-ray sample "
@@ -689,6 +692,8 @@ def main(argv=None):
     ap.add_argument("--mode", default=None, choices=[None, "chain", "element"])
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step from a HIP graph (auto: for the multi-chain configurations)")
+    ap.add_argument("--shard", default="blocks", choices=["blocks", "strided"],
+                    help="N > 1: contiguous index ranges per rank (default) or rank r traces rays r, r + N, ...")
     ap.add_argument("--readout", default="auto", choices=["auto", "fused", "separate"],
                     help="fused: the detector read-out rides on the tracing launch; separate: its own kernel afterwards; "
                          "auto (default): fused, except for a single chain of 8 or more elements")

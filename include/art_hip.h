@@ -287,6 +287,11 @@ int art_compact(const uint8_t* alive, int64_t n, int32_t* block_counts, int64_t*
  * Writes origin, direction, path = 0, incidence = NaN, alive = 1.                                        */
 int art_make_source(int32_t kind, double size, const double rot[9], const double S[3], int64_t first,
                     int64_t n, int64_t n_total, const ArtBundleView* out, void* stream);
+/* The same for the global indices first, first + step, ..., first + (n-1)*step: the STRIDED shard of rank `first` among
+ * `step` ranks.  The Vogel spiral orders rays by radius, so contiguous shards of a masked or overfilled scene lose very
+ * different numbers of rays; strided shards are balanced (every rank samples the whole aperture).                    */
+int art_make_source_strided(int32_t kind, double size, const double rot[9], const double S[3], int64_t first,
+                            int64_t step, int64_t n, int64_t n_total, const ArtBundleView* out, void* stream);
 
 /* ExtendedSource (ART/ModuleSource.py:85-131): n_points point sources on a Vogel disk of radius `radius` (mm), each
  * emitting the same Vogel cone of rays_per_point rays with half-angle `divergence` (rad).  Global ray index

@@ -182,11 +182,11 @@ int art_cpu_pack_rays(const double* points, const double* vectors, const double*
   return 0;
 }
 
-int art_cpu_make_source(int32_t kind, double size, const double* rot, const double* S, int64_t first, int64_t n,
-                        int64_t n_total, const ArtBundleView* out) {
+int art_cpu_make_source(int32_t kind, double size, const double* rot, const double* S, int64_t first, int64_t step,
+                        int64_t n, int64_t n_total, const ArtBundleView* out) {
   for (int64_t i = 0; i < n; ++i) {
     art::Ray r;
-    art::source_ray(kind, size, rot, S, first + i, n_total, r);
+    art::source_ray(kind, size, rot, S, first + i * step, n_total, r);
     store_ray(*out, i, r);
     out->alive[i] = 1;
   }

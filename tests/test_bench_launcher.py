@@ -47,6 +47,22 @@ def test_bench_multichain_config_two_ranks():
     assert j["n_gpus"] == 2 and j["config"]["chains"] == 11 and j["config"]["name"] == "C2"
 
 
+def test_bench_strided_shards_balance_a_masked_scene():
+    """C2 on two ranks: with contiguous shards rank 1 (the outer half of the Vogel spiral) is stopped by the mask almost
+    entirely; with strided shards both ranks carry the same load."""
+    import re
+    share = {}
+    for layout in ("blocks", "strided"):
+        p = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "C2", "--rays", "2000", "--cpu-sample", "0",
+                  "--shard", layout])
+        assert p.returncode == 0, p.stderr[-3000:]
+        j = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+        assert j["config"]["shard_layout"] == layout
+        m = re.search(r"= (\d+) intersections/step on rank 0, (\d+) on all", j["config"]["workload"])
+        share[layout] = int(m.group(1)) / int(m.group(2))
+    assert abs(share["strided"] - 0.5) < 0.01 and share["blocks"] > 0.6, share
+
+
 def test_bench_refuses_a_world_size_that_differs_from_gpus():
     # as a torchrun worker (WORLD_SIZE set) whose group has 1 rank while --gpus says 2: must fail, not report n_gpus 1
     p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--rays", "1000", "--cpu-sample", "0"],

@@ -214,6 +214,25 @@ def test_gpu_sources_match_oracle(hip):
     assert np.abs(b.intensities() - q.intensity).max() <= 1e-10
 
 
+def test_gpu_strided_source_shards(hip):
+    """art_make_source_strided: rank r's strided shard of a source is every world-th ray of the full source, bit for bit."""
+    import torch
+    from attosecondraytracing_amd.bundle import RayBundle
+    from attosecondraytracing_amd import sharding, ModuleGeometry as mgeo
+    n_total, world = 1_000_003, 4
+    rot = mgeo.rotation_matrix(np.array([0.0, 0.0, 1.0]), np.array([0.3, -0.5, 0.8]))
+    for kind, size in ((0, 0.03), (1, 12.0)):
+        full = RayBundle.allocate(n_total, backend=hip)
+        hip.make_source(kind, size, rot, np.array([1.0, 2.0, 3.0]), 0, n_total, n_total, full.view())
+        for rk in range(world):
+            first, step, n = sharding.shard_spec(n_total, rk, world, "strided")
+            part = RayBundle.allocate(n, backend=hip)
+            hip.make_source(kind, size, rot, np.array([1.0, 2.0, 3.0]), first, n, n_total, part.view(), step=step)
+            assert torch.equal(part.data[0:7], full.data[0:7, rk::world]) and bool(part.alive.all())
+    with pytest.raises(RuntimeError):
+        hip.make_source(0, 0.03, rot, np.zeros(3), 3, 10, 40, RayBundle.allocate(10, backend=hip).view(), step=4)   # 3 + 9*4 >= 40
+
+
 def test_gpu_extended_source_matches_reference(hip):
     """ExtendedSource on the device (art_make_extended_source) against the reference's list, numbering included."""
     import ART.ModuleSource as msource

@@ -44,7 +44,7 @@ class TwinBackend:
                                                    C.c_int64, C.c_double] + [C.c_void_p] * 7
         self.lib.art_cpu_make_source.restype = C.c_int
         self.lib.art_cpu_make_source.argtypes = [C.c_int32, C.c_double, _abi.c_double_p, _abi.c_double_p, C.c_int64,
-                                                 C.c_int64, C.c_int64, C.POINTER(_abi.ArtBundleView)]
+                                                 C.c_int64, C.c_int64, C.c_int64, C.POINTER(_abi.ArtBundleView)]
         self.lib.art_cpu_make_extended_source.restype = C.c_int
         self.lib.art_cpu_make_extended_source.argtypes = [C.c_double, C.c_double, C.c_int64, C.c_int64,
                                                           _abi.c_double_p, _abi.c_double_p, C.c_int64, C.c_int64,
@@ -283,10 +283,10 @@ class TwinBackend:
         idx = torch.nonzero(alive, as_tuple=False).reshape(-1)
         return idx, int(idx.numel())
 
-    def make_source(self, kind, size, rot, S, first, n, n_total, view):
+    def make_source(self, kind, size, rot, S, first, n, n_total, view, step=1):
         r = (C.c_double * 9)(*[float(v) for v in np.asarray(rot).reshape(9)])
         s = (C.c_double * 3)(*[float(v) for v in np.asarray(S).reshape(3)])
-        assert self.lib.art_cpu_make_source(kind, float(size), r, s, first, n, n_total, C.byref(view)) == 0
+        assert self.lib.art_cpu_make_source(kind, float(size), r, s, first, int(step), n, n_total, C.byref(view)) == 0
 
     def exchange_pack(self, stats, X, Y, opl, alive, slots, send):
         k = int(slots.numel())
