@@ -230,7 +230,7 @@ def test_gpu_strided_source_shards(hip):
             hip.make_source(kind, size, rot, np.array([1.0, 2.0, 3.0]), first, n, n_total, part.view(), step=step)
             assert torch.equal(part.data[0:7], full.data[0:7, rk::world]) and bool(part.alive.all())
     with pytest.raises(RuntimeError):
-        hip.make_source(0, 0.03, rot, np.zeros(3), 3, 10, 40, RayBundle.allocate(10, backend=hip).view(), step=4)   # 3 + 9*4 >= 40
+        hip.make_source(0, 0.03, rot, np.zeros(3), 3, 10, 39, RayBundle.allocate(10, backend=hip).view(), step=4)   # 3 + 9*4 = 39 is not < 39
 
 
 def test_gpu_extended_source_matches_reference(hip):
