@@ -620,7 +620,9 @@ def worker(args):
             auto_fuse = batched or n_elems < 8
             pkey = cfg if fuse == auto_fuse else cfg + ("_fused" if fuse else "_separate")
             tr = profiled_traffic(pkey, kprefix, n)
-            algo = ALGO_BYTES_PER_INTERSECTION * inter_per_launch / (kernel_ms * 1e-3) / 1e9
+            # 128 B per intersection, + 88 B per ray of read-out when that rides on the same launch
+            algo_bytes = ALGO_BYTES_PER_INTERSECTION * inter_per_launch + (ALGO_BYTES_READOUT * n * n_chains / launches if fuse else 0.0)
+            algo = algo_bytes / (kernel_ms * 1e-3) / 1e9
             # what the kernel moves by construction: every chain reads its source once (57 B/slot) and writes 65 B per
             # slot and element (dead slots: only the alive byte) -- the PMC counters agree with it to 0.1 % on relay4
             counted = None if tr is None else tr[0] / (kernel_ms * 1e-3) / 1e9
@@ -635,9 +637,15 @@ def worker(args):
                 "traffic_source": None if tr is None else tr[1] + " (rocprofv3 PMC, bytes per launch)",
                 "achieved_algorithmic": algo, "frac_algorithmic": algo / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_intersection": ALGO_BYTES_PER_INTERSECTION,
+                "algorithmic_bytes_per_read_out_ray": ALGO_BYTES_READOUT if fuse else None,
+                "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_ms": kernel_ms, "launches_per_step": launches, "intersections_per_launch": inter_per_launch,
                 "frac_of_achievable_6300": None if counted is None else counted / 6300.0,
             }
+            sq = os.path.join(ROOT, "profiles", "r02_relay4_sq.json")
+            if cfg == "relay4" and fuse and n == 10_000_000 and args.mirrors == 4 and os.path.exists(sq):
+                # the kernel's OTHER roof: SQ counters of this very workload (tools/prof_sq.sh), committed
+                res["roofline"]["second_bound"] = dict(json.load(open(sq)), source="profiles/r02_relay4_sq.md")
             if readout_ms is None:
                 res["roofline_readout"] = {
                     "fused": True, "kernel": res["roofline"]["kernel"],
