@@ -21,12 +21,7 @@ def trace_chain_list(chains, **kwargs):
     ART/ARTmain.py:304-342) find their result ready.  A list as `OEPlacement` returns it -- chains that differ only in
     poses -- shares one scene table; anything else falls back to one launch per chain."""
     stale = [ch for ch in chains if ch._cache_key(kwargs) != ch._last_key and getattr(ch, "_program", None) is None]
-    # One launch pays off where single launches are latency-bound (<= ~1e6 rays per chain); with 1e7-ray chains the
-    # kernels fill the GPU either way and one 20-GB allocation for all histories is slower to obtain than ten 2-GB
-    # ones (measured, tools/e2e_time.py: 10 chains x 1e7 rays 7.3 ms batched vs 4.6 ms chain by chain; 1e5-1e6 rays
-    # 3.9-4.0 ms both ways, host-bound by descriptor building).  The explicit mp.RayTracingCalculationMany always batches.
-    history_bytes = sum(ch.source_rays.n_slots * len(ch.optical_elements) * 65 for ch in stale)
-    if len(stale) > 1 and history_bytes <= 4e9:
+    if len(stale) > 1:
         outs = mp.RayTracingCalculationMany([ch.source_rays for ch in stale], [ch.optical_elements for ch in stale],
                                             **kwargs)
         for ch, o in zip(stale, outs):

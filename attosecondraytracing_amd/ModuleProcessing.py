@@ -218,8 +218,9 @@ def RayTracingCalculationMany(source_rays_list, optical_elements_list, IgnoreDef
     of its arguments is a list -- 10-11 chains that differ only in poses (ART/ModuleProcessing.py:203-239), which the
     reference's `ARTmain.main` traces one after the other (ARTmain.py:304-342).  The element descriptors of all chains
     travel as one device-resident scene table; blockIdx.y selects the chain.  Returns one list of bundles per chain,
-    identical to separate calls.  Chains that cannot share a launch (different ray or element counts) are traced one
-    by one -- still on the device.  `detectors`: one placed Detector per chain whose read-out is fused behind the
+    identical to separate calls.  Chains that cannot share a launch (different ray or element counts) or whose
+    histories together exceed 4 GB are traced one by one -- still on the device; chains with equal sources share the
+    trace of their common prefix (below).  `detectors`: one placed Detector per chain whose read-out is fused behind the
     trace (see RayTracingCalculation)."""
     sources = [_as_bundle(s) for s in source_rays_list]
     c = len(sources)
@@ -238,7 +239,29 @@ def RayTracingCalculationMany(source_rays_list, optical_elements_list, IgnoreDef
                and all(s.n_slots == n and s.backend is be for s in sources) and not any(d.nonfinite for d in descs))
     if detectors is not None and len(detectors) != c:
         raise ValueError("need one detector per chain")
-    if c == 1 or not uniform:
+    # Common prefix: a loop list varies ONE entry of one list (OEPlacement), so its chains start from equal sources and
+    # share every element before the varied one -- C2 / C3: the mask and the first toroid, two of three elements.  That
+    # prefix is traced ONCE and its bundles are shared by all chains (the same RayBundle objects in every chain's
+    # result); only the suffixes go into the many-chain launch, all reading the prefix's last bundle.  Equality is
+    # exact: descriptors byte for byte, sources by content key (same generator arguments / copies, bundle.content_key).
+    if uniform and c > 1 and detectors is None and len({s.content_key() for s in sources}) == 1 \
+            and sources[0].content_key()[0] != "bundle":
+        L = 0
+        while L < m and all(bytes(descs[ci * m + L]) == bytes(descs[L]) for ci in range(1, c)):
+            L += 1
+        if L > 0:
+            head = RayTracingCalculation(sources[0], optical_elements_list[0][:L], IgnoreDefects, None, history)
+            if L == m:
+                return [list(head) for _ in range(c)]
+            tails = RayTracingCalculationMany([head[-1]] * c, [els[L:] for els in optical_elements_list], IgnoreDefects,
+                                              history)
+            return [list(head) + t for t in tails]
+    # One launch pays off where single launches are latency-bound (<= ~1e6 rays per chain).  With 1e7-ray chains the
+    # kernels fill the GPU either way and ONE allocation for all histories (20 GB for C3) is slower to obtain than ten
+    # 2-GB ones (tools/e2e_time.py: 10 chains x 1e7 rays 7.3 ms in one launch, 4.6 ms chain by chain; 1e5-1e6 rays
+    # 3.9-4.0 ms both ways, host-bound by descriptor building): above 4 GB of history the chains are launched one by one.
+    too_big = history and c * m * n * 65 > 4e9
+    if c == 1 or not uniform or too_big:
         return [RayTracingCalculation(s, els, IgnoreDefects, None, history, None if detectors is None else detectors[k])
                 for k, (s, els) in enumerate(zip(sources, optical_elements_list))]
     if history:

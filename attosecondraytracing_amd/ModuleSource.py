@@ -20,6 +20,9 @@ def _device_source(kind, size, S, Axis, n, n_total, Wavelength):
     b.number = None  # slot index == Ray.number for these sources
     rot = mgeo.rotation_matrix(_EZ, np.asarray(Axis, dtype=float))
     be.make_source(kind, size, rot, np.asarray(S, dtype=float), 0, n, n_total, b.view())
+    # the bundle is a pure function of these arguments (the generator is deterministic)
+    b.tag_content(("source", int(kind), float(size), np.asarray(S, dtype=float).tobytes(),
+                   np.asarray(Axis, dtype=float).tobytes(), int(n), int(n_total), Wavelength))
     return b
 
 
@@ -50,6 +53,8 @@ def ExtendedSource(S, Axis, Diameter: float, Divergence: float, NbRays: int, Wav
     rot = mgeo.rotation_matrix(_EZ, np.asarray(Axis, dtype=float))
     be.make_extended_source(Diameter / 2, Divergence, n_src, per, rot, np.asarray(S, dtype=float), 0, n_src * per,
                             b.view())
+    b.tag_content(("extended source", float(Diameter), float(Divergence), int(n_src), int(per),
+                   np.asarray(S, dtype=float).tobytes(), np.asarray(Axis, dtype=float).tobytes(), Wavelength))
     return b
 
 
@@ -80,7 +85,10 @@ def ApplyGaussianIntensityToRayList(RayList, IntensityFraction=1 / np.e ** 2):
         IntensityFraction = 1 / np.e ** 2
     from . import ModuleProcessing as mp
     B = RayList if isinstance(RayList, RayBundle) else RayBundle.from_ray_list(RayList)
+    before = B.content_key()
     axis = mp.FindCentralRay(B).vector
     B.intensity = B.backend.gaussian_intensity(B.view(), axis, IntensityFraction, B.n_slots)
     B.touch()
+    if before[0] != "bundle":       # weights of a tagged bundle are a pure function of its tag and the fraction
+        B.tag_content((before, "gaussian intensity", float(IntensityFraction)))
     return B

@@ -39,6 +39,7 @@ class RayBundle:
         # from Ray objects whose `path` tuples had k > 1 entries (the device keeps only their sum)
         self.path_head = None
         self._fused_readout = None    # (detector key, version, result) of a read-out computed in the tracing launch
+        self._content = None          # (key, version it was valid for): see content_key()
 
     # ------------------------------------------------------------------ backend / persistence
     @property
@@ -72,6 +73,7 @@ class RayBundle:
         self._index = None
         self._count = None
         self._fused_readout = None
+        self._content = None
         self._serial = next(_SERIAL)
 
     # ------------------------------------------------------------------ construction
@@ -171,6 +173,21 @@ class RayBundle:
         v.path, v.incidence = p + 6 * stride, p + 7 * stride
         v.alive = self.alive.data_ptr()
         return v
+
+    # ------------------------------------------------------------------ content identity
+    def tag_content(self, key):
+        """Declare that this bundle's contents (ray state, numbers, intensities, wavelength) are a pure function of the
+        hashable `key` -- e.g. the arguments of the generator that filled it.  Two bundles with equal keys are
+        bit-identical; the tag dies with the next touch()."""
+        self._content = (key, self.version)
+
+    def content_key(self):
+        """Hashable that is equal for two bundles only if their contents are known to be bit-identical (same
+        generator arguments, or a copy of such a bundle); unique per bundle and version otherwise.  Lets a list of
+        chains that start from equal sources share the trace of their common prefix (RayTracingCalculationMany)."""
+        if self._content is not None and self._content[1] == self.version:
+            return self._content[0]
+        return ("bundle", self._serial, self.version)
 
     def touch(self):
         self.version += 1
@@ -308,6 +325,7 @@ class RayBundle:
         alive.copy_(self.alive)
         out = RayBundle(data, alive, self.number, self.intensity, self.wavelength, self.parent, self.backend)
         out.path_head = self.path_head
+        out.tag_content(self.content_key())        # a copy is bit-identical to its original
         return out
 
     def __deepcopy__(self, memo):

@@ -222,3 +222,53 @@ def run_fused_readout():
     dead.alive.zero_()
     st = D.readout(mp.RayTracingCalculation(dead, e, detector=D)[-1])["stats"]
     assert st[0] == 0 and st[2] == np.inf and st[3] == -np.inf and st[1] == 0
+
+
+def run_prefix_sharing():
+    """A loop list as OEPlacement builds it (C2: the second toroid's distance varies; C3: its incidence plane): the
+    chains start from equal sources and share mask + first toroid, so RayTracingCalculationMany traces that prefix once,
+    every chain's result holds the SAME prefix bundles, and everything equals the chain-by-chain results bit for bit."""
+    import ART.ModuleMirror as mmirror, ART.ModuleMask as mmask, ART.ModuleSupport as msupp, ART.ModuleProcessing as mp
+    import ART.ModuleOpticalChain as moc
+    SP = {"Divergence": 0.025, "SourceSize": 0, "Wavelength": 50e-6, "DeltaFT": 0.5, "NumberRays": 3000}
+    Mask = mmask.Mask(msupp.SupportRoundHole(20, 7.0, 0, 0))
+    R, r = mmirror.ReturnOptimalToroidalRadii(500, 80)
+    Tor = mmirror.MirrorToroidal(R, r, msupp.SupportRectangle(150, 32))
+    for dist_, planes in (([400, 100, [300.0, 420.0, 500.0, 700.0]], [0, 0, 0]),          # C2-like: distance list
+                          ([400, 100, 500], [0, 0, [-60.0, 0.0, 25.0]])):                   # C3-like: twist list
+        import copy
+        # (OEPlacement, like the reference's, replaces the list-valued entry of its argument in place: hand it copies)
+        chains = mp.OEPlacement(SP, [Mask, Tor, Tor], copy.deepcopy(dist_), [0, 80, -80], copy.deepcopy(planes), "loop list")
+        keys = {ch.source_rays.content_key() for ch in chains}
+        assert len(keys) == 1 and next(iter(keys))[0] != "bundle"       # equal generator arguments + weights
+        calls = []
+        real = mp.RayTracingCalculation
+        mp.RayTracingCalculation = lambda *a, **k: calls.append(len(a[1])) or real(*a, **k)
+        try:
+            outs = mp.RayTracingCalculationMany([ch.source_rays for ch in chains], [ch.optical_elements for ch in chains])
+        finally:
+            mp.RayTracingCalculation = real
+        assert calls == [2], calls                                       # the shared prefix: mask + first toroid, once
+        for o in outs[1:]:
+            assert o[0] is outs[0][0] and o[1] is outs[0][1] and o[2] is not outs[0][2]
+        for ch, o in zip(chains, outs):
+            single = mp.RayTracingCalculation(ch.source_rays, ch.optical_elements)
+            for x, y in zip(o, single):
+                _equal_bundles(x, y)
+            assert np.array_equal(o[-1].path_segments(), single[-1].path_segments())      # path tuples through the shared prefix
+            assert [r_.number for r_ in o[-1][:3]] == [r_.number for r_ in single[-1][:3]]
+        # a source that was modified (touch) is no longer known to be equal: no sharing, same results
+        chains[1].source_rays.touch()
+        outs2 = mp.RayTracingCalculationMany([ch.source_rays for ch in chains], [ch.optical_elements for ch in chains])
+        assert outs2[1][0] is not outs2[0][0]
+        for o, o2 in zip(outs, outs2):
+            for x, y in zip(o, o2):
+                _equal_bundles(x, y)
+        # trace_chain_list (what ARTmain.main calls) fills the caches from the shared trace
+        fresh = mp.OEPlacement(SP, [Mask, Tor, Tor], copy.deepcopy(dist_), [0, 80, -80], copy.deepcopy(planes), "loop list")
+        got = moc.trace_chain_list(fresh)
+        assert got[1][0] is got[0][0] and all(ch.get_output_rays() is g for ch, g in zip(fresh, got))
+    # bundles built from arrays carry no tag: equal content is not assumed
+    s, a = load_golden("c2_fxf_chain00")
+    b1, b2 = pc.source_bundle(a, s), pc.source_bundle(a, s)
+    assert b1.content_key() != b2.content_key() and b1.copy().content_key() == b1.content_key()

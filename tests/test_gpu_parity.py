@@ -574,6 +574,12 @@ def test_gpu_scene_program_replays(hip):
     scene_cases.run_chain_list_cache()
 
 
+def test_gpu_loop_list_prefix_sharing(hip):
+    """Loop lists from OEPlacement share the trace of their common prefix (mask + first toroid in C2 / C3)."""
+    import scene_cases
+    scene_cases.run_prefix_sharing()
+
+
 def test_gpu_fused_readout(hip):
     """The detector read-out fused behind the tracing launch (art_trace_chain_readout, scene read-outs): per-ray values
     bit-identical to the separate art_detector_readout, statistics to rounding, Detector.readout reuses it."""

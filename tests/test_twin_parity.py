@@ -119,3 +119,8 @@ def test_twin_scene_program(twin):
 def test_twin_fused_readout(twin):
     import scene_cases
     scene_cases.run_fused_readout()
+
+
+def test_twin_loop_list_prefix_sharing(twin):
+    import scene_cases
+    scene_cases.run_prefix_sharing()
