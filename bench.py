@@ -71,24 +71,25 @@ def launch_workers(n, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         out = subprocess.PIPE if r == 0 else sys.stderr
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
-    line, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    deadline = time.time() + 120
-    for p in procs[1:]:
-        try:
-            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            rcs.append(-9)
-    if any(rc != 0 for rc in rcs):
+    # watch all workers: if one dies, the others would sit in a collective until RCCL's own timeout -- end them at once
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
+            break
+        time.sleep(0.2)
+    if failed:
+        time.sleep(1.0)                      # let the failing rank's traceback reach stderr first
         for p in procs:
             if p.poll() is None:
                 p.kill()
-        log(f"[bench] worker exit codes {rcs}: failing")
-        sys.stdout.write(line.decode(errors="replace"))
-        return 1
+    line = procs[0].stdout.read() if procs[0].stdout else b""     # one JSON line: far below the pipe's capacity
+    rcs = [p.wait() for p in procs]
     sys.stdout.write(line.decode(errors="replace"))
     sys.stdout.flush()
+    if any(rc != 0 for rc in rcs):
+        log(f"[bench] worker exit codes {rcs}: failing")
+        return 1
     return 0
 
 

@@ -77,3 +77,13 @@ def test_bench_single_rank_line_on_cpu_twin():
     assert p.returncode == 0, p.stderr[-3000:]
     j = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
     assert j["n_gpus"] == 1 and j["value_full_gather"] is None and j["config"]["name"] == "relay4"
+
+
+def test_launcher_ends_all_ranks_when_one_fails():
+    import time
+    t0 = time.time()
+    p = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--rays", "2000", "--cpu-sample", "0"],
+             ART_BENCH_BACKEND_HOOK="twin_backend:install_failing_on_rank_1")
+    assert p.returncode != 0 and time.time() - t0 < 120
+    assert "rank 1 fails on purpose" in p.stderr and "worker exit codes" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.strip().startswith("{")]

@@ -315,3 +315,12 @@ def install():
     from attosecondraytracing_amd import _lib
     _lib._BACKEND = TwinBackend()
     return _lib._BACKEND
+
+
+def install_failing_on_rank_1():
+    """Test hook target: rank 1 dies during set-up (the launcher must then end the other ranks instead of letting them
+    wait in a collective)."""
+    import os
+    if os.environ.get("RANK") == "1":
+        raise RuntimeError("rank 1 fails on purpose (launcher test)")
+    return install()
