@@ -619,7 +619,8 @@ def worker(args):
             # profiles/r0N_<config>.json: the configuration as bench runs it by default; the other read-out mode is
             # profiled as r0N_<config>_fused.json / _separate.json
             auto_fuse = batched or n_elems < 8
-            pkey = cfg if fuse == auto_fuse else cfg + ("_fused" if fuse else "_separate")
+            base = f"relay{args.mirrors}" if cfg == "relay4" else cfg        # (profiles exist for the 4-mirror headline)
+            pkey = base if fuse == auto_fuse else base + ("_fused" if fuse else "_separate")
             tr = profiled_traffic(pkey, kprefix, n)
             # 128 B per intersection, + 88 B per ray of read-out when that rides on the same launch
             algo_bytes = ALGO_BYTES_PER_INTERSECTION * inter_per_launch + (ALGO_BYTES_READOUT * n * n_chains / launches if fuse else 0.0)
