@@ -423,7 +423,7 @@ def worker(args):
     src = device_source(n, first, n_total, be, src_kind, wl, step=stride)
     batched = n_chains > 1
     # small bundles are launch-bound: replay the whole step (trace + read-outs) from a HIP graph
-    use_graph = on_gpu and (args.graph == "on" or (args.graph == "auto" and batched))
+    use_graph = on_gpu and (args.graph == "on" or (args.graph == "auto" and (batched or n <= 2_000_000)))
 
     # detectors: placed once (untimed) from the mean ray of each chain's last bundle, like ARTmain.setup_detector
     if batched:
@@ -701,7 +701,8 @@ def main(argv=None):
     ap.add_argument("--mirrors", type=int, default=4, help="relay4 only: number of toroidal mirrors")
     ap.add_argument("--mode", default=None, choices=[None, "chain", "element"])
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                    help="replay the step from a HIP graph (auto: for the multi-chain configurations)")
+                    help="replay the step from a HIP graph (auto: for the multi-chain configurations and for bundles of "
+                         "at most 2e6 rays, where eager launches are host-bound)")
     ap.add_argument("--shard", default="blocks", choices=["blocks", "strided"],
                     help="N > 1: contiguous index ranges per rank (default) or rank r traces rays r, r + N, ...")
     ap.add_argument("--readout", default="auto", choices=["auto", "fused", "separate"],
