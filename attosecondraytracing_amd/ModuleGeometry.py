@@ -162,20 +162,35 @@ def TranslationPointList(PointList, T):
     return [p + T for p in PointList]
 
 
+_FRAME_MAPS = {}
+
+
 def frame_maps(normal, majoraxis):
     """Constant lab->optic and optic->lab 3x3 maps of one optical element, composed exactly as
     RayTracingCalculation chains its per-ray rotations (ART/ModuleProcessing.py:289-294, :307-308):
-        fwd = R(m' -> ex) . R(n -> ez),  m' = R(n -> ez) m        bwd = R(ez -> n) . R(ex -> m')"""
-    ez = np.array([0.0, 0.0, 1.0])
-    ex = np.array([1.0, 0.0, 0.0])
+        fwd = R(m' -> ex) . R(n -> ez),  m' = R(n -> ez) m        bwd = R(ez -> n) . R(ex -> m')
+    Memoised on the exact bytes of the two axes: the chains of a loop list repeat most of their poses (read-only
+    arrays are returned)."""
     n = np.asarray(normal, dtype=float)
     m = np.asarray(majoraxis, dtype=float)
+    key = n.tobytes() + m.tobytes()
+    hit = _FRAME_MAPS.get(key)
+    if hit is not None:
+        return hit
+    ez = np.array([0.0, 0.0, 1.0])
+    ex = np.array([1.0, 0.0, 0.0])
     R1 = rotation_matrix(n, ez)
     mPrime = R1 @ m
     R2 = rotation_matrix(mPrime, ex)
     B2 = rotation_matrix(ex, mPrime)
     B1 = rotation_matrix(ez, n)
-    return R2 @ R1, B1 @ B2
+    fwd, bwd = R2 @ R1, B1 @ B2
+    fwd.setflags(write=False)
+    bwd.setflags(write=False)
+    if len(_FRAME_MAPS) > 4096:
+        _FRAME_MAPS.clear()
+    _FRAME_MAPS[key] = (fwd, bwd)
+    return fwd, bwd
 
 
 def normal_add(N1, N2):
