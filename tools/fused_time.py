@@ -19,6 +19,9 @@ else:
 src = bench.device_source(n, 0, n, be, kind)
 det = mdet.Detector(np.asarray(els[-1].position, dtype=float), np.asarray(els[-1].position, dtype=float) + np.array([600.0, 0, 0]),
                     np.array([-1.0, 0.0, 0.0]))
+import gc
+gc.collect()
+gc.freeze()       # keep Python's 40-ms full collections out of the 30-step timings
 tag = os.environ.get("ART_DIAG_TAG", os.environ.get("ART_HIP_LIB", "default").split("/")[-1])
 for name, fused in (("separate", False), ("fused", True), ("separate", False), ("fused", True)):
     def step():
