@@ -72,7 +72,8 @@ def run_edge_cases():
                 assert out[-1].path_segments().shape == (n, 20)
     for r in results[1:]:
         assert np.abs(r - results[0]).max() <= 1e-12 * 1000
-    # more Zernike tables than one fused launch can stage in LDS (16): the chain is traced element by element instead
+    # 24 Zernike tables in one fused launch (round 1 staged them in LDS and had to fall back to per-element launches
+    # above 16; they now travel through scalar loads, without a limit per launch)
     import ART.ModuleDefects as mdef
     S = msupp.SupportRound(1e4)
     warped = lambda: mmirror.DeformedMirror(mmirror.MirrorPlane(S), [mdef.Zernike(S, {(2, 1): 1e-6 * (k + 1)}) for k in range(4)])
@@ -123,6 +124,21 @@ def run_chunking(setenv):
             assert np.array_equal(o.alive.cpu().numpy(), q.alive.cpu().numpy())
             assert np.array_equal(o.points(), q.points()) and np.array_equal(o.paths_total(), q.paths_total())
         assert 0 < len(out[-1]) < 5000
+    # the many-chain launch walks the same chunks (slot offset as a kernel argument)
+    oe2 = _plane_element(3.0)
+    many = mp.RayTracingCalculationMany([b, b], [[tor, oe], [tor, oe2]])
+    for o, q in zip(many[0], ref["chain"]):
+        assert np.array_equal(o.alive.cpu().numpy(), q.alive.cpu().numpy()) and np.array_equal(o.points(), q.points())
+    assert 0 < len(many[1][-1]) < len(many[0][-1])
+    # a fused read-out needs its bundle in ONE launch: refused beyond it, with the library's message
+    import ART.ModuleDetector as mdet
+    det = mdet.Detector(np.zeros(3), np.array([0.3, -0.2, 200.0]), np.array([0.05, 0.02, -1.0]))
+    if b.backend.name == "hip":
+        try:
+            mp.RayTracingCalculation(b, [tor, oe], detector=det)
+            raise AssertionError("a fused read-out over several launches must be refused")
+        except RuntimeError as e:
+            assert "fused read-out" in str(e)
 
 
 def run_readout_chunking(setenv):
