@@ -38,6 +38,16 @@ struct Ray {
   double ox, oy, oz, dx, dy, dz, path, inc;
 };
 
+// slots of a PREPARED descriptor (prepare_element() below says what they hold)
+#define ART_D_IN_OFF bwd
+#define ART_D_OUT_OFF bwd + 3
+#define ART_D_R2 bwd[6]
+#define ART_D_BOX_RHO2 bwd[7]
+#define ART_D_BOX_Y2 bwd[8]
+#define ART_D_RB pos[0]
+#define ART_D_SUM2 pos[1]
+#define ART_D_DIF2 pos[2]
+
 // ---------------------------------------------------------------------------------------------------------
 // small helpers
 ART_HD double dot3(double ax, double ay, double az, double bx, double by, double bz) {
@@ -48,6 +58,19 @@ ART_HD void mat3_apply(const double* M, double x, double y, double z, double& rx
   rx = fma(M[0], x, fma(M[1], y, M[2] * z));
   ry = fma(M[3], x, fma(M[4], y, M[5] * z));
   rz = fma(M[6], x, fma(M[7], y, M[8] * z));
+}
+
+// M p + o and M^T p + o.  The offset is added LAST: M and o are both wave-uniform (scalar registers), an instruction
+// takes one scalar operand, and as the innermost addend of the FMA chain o would first be copied to vector registers.
+ART_HD void mat3_apply_off(const double* M, const double* o, double x, double y, double z, double& rx, double& ry, double& rz) {
+  rx = fma(M[0], x, fma(M[1], y, M[2] * z)) + o[0];
+  ry = fma(M[3], x, fma(M[4], y, M[5] * z)) + o[1];
+  rz = fma(M[6], x, fma(M[7], y, M[8] * z)) + o[2];
+}
+ART_HD void mat3t_apply_off(const double* M, const double* o, double x, double y, double z, double& rx, double& ry, double& rz) {
+  rx = fma(M[0], x, fma(M[3], y, M[6] * z)) + o[0];
+  ry = fma(M[1], x, fma(M[4], y, M[7] * z)) + o[1];
+  rz = fma(M[2], x, fma(M[5], y, M[8] * z)) + o[2];
 }
 
 ART_HD void mat3t_apply(const double* M, double x, double y, double z, double& rx, double& ry, double& rz) {
@@ -111,13 +134,42 @@ ART_HD void sqrt_rsqrt(double x, double& s, double& rs) {
   rs = 1.0 / s;
 #endif
 }
-ART_HD double sqrt_seed(double x) {  // single-precision accuracy: starting points only
+// sqrt(x) to < 1 ulp together with a 1/sqrt(x) that is only good to ~1e-13 relative (one coupled Goldschmidt step on
+// the seed, then a residual correction of the root): for the torus function, where 1/rho scales a derivative.
+ART_HD void sqrt_rsqrt_coarse(double x, double& s, double& rs) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return (double)__builtin_sqrtf((float)x);
+  const double y = __builtin_amdgcn_rsq(x);
+  const double g = x * y, h = 0.5 * y;
+  const double e = fma(-g, h, 0.5);
+  const double g1 = fma(g, e, g), h1 = fma(h, e, h);
+  s = fma(fma(-g1, g1, x), h1, g1);
+  rs = h1 + h1;
+#else
+  s = sqrt(x);
+  rs = 1.0 / s;
+#endif
+}
+ART_HD double sqrt_seed(double x) {  // ~1e-7 relative: starting points only
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_sqrt(x);  // the bare v_sqrt_f64 (sqrtf() on a converted operand expands to 17 instructions)
 #else
   return sqrt(x);
 #endif
 }
+
+// a * b + c with c a compile-time constant (or any wave-uniform value): the VOP3 form with c as its one scalar
+// operand.  v_fma_f64 cannot take a 64-bit literal, and left to itself the compiler selects the two-address
+// v_fmac_f64, whose addend must sit in a VGPR -- two v_mov_b32 per constant, on the vector pipe that bounds the tracing
+// kernels.  This way the constant is built by two s_mov_b32 on the scalar pipe, which has slots to spare.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double fma_sc(double a, double b, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+  return d;
+}
+#else
+ART_HD double fma_sc(double a, double b, double c) { return fma(a, b, c); }
+#endif
 
 // atan(q) for 0 <= q <= 1 (half the Kahan angle): table-free argument reduction to |t| <= tan(pi/16) by
 // atan(q) = atan(c) + atan((q - c) / (1 + q c)), c in {0, tan(pi/8), tan(pi/4)... } then an odd polynomial.
@@ -126,35 +178,35 @@ ART_HD double atan01(double q) {
   double c = 0.0, ac = 0.0;
   if (q > 0.19891236737965800691) { c = 0.41421356237309504880; ac = 0.39269908169872415481; }
   if (q > 0.66817863791929891999) { c = 1.0; ac = 0.78539816339744830962; }
-  const double t = div_full(q - c, fma(q, c, 1.0));
+  // (q - c) / (1 + q c) through the refined reciprocal: 1.5 ulp, no residual correction needed for an angle
+  const double t = (q - c) * rcp_full(fma(q, c, 1.0));
   const double z = t * t;  // |t| <= tan(pi/16) = 0.1989: z <= 0.0396, series to z^10 is < 1e-16 relative
   double p = -1.0 / 21.0;
-  p = fma(p, z, 1.0 / 19.0);
-  p = fma(p, z, -1.0 / 17.0);
-  p = fma(p, z, 1.0 / 15.0);
-  p = fma(p, z, -1.0 / 13.0);
-  p = fma(p, z, 1.0 / 11.0);
-  p = fma(p, z, -1.0 / 9.0);
-  p = fma(p, z, 1.0 / 7.0);
-  p = fma(p, z, -1.0 / 5.0);
-  p = fma(p, z, 1.0 / 3.0);
+  p = fma_sc(p, z, 1.0 / 19.0);
+  p = fma_sc(p, z, -1.0 / 17.0);
+  p = fma_sc(p, z, 1.0 / 15.0);
+  p = fma_sc(p, z, -1.0 / 13.0);
+  p = fma_sc(p, z, 1.0 / 11.0);
+  p = fma_sc(p, z, -1.0 / 9.0);
+  p = fma_sc(p, z, 1.0 / 7.0);
+  p = fma_sc(p, z, -1.0 / 5.0);
+  p = fma_sc(p, z, 1.0 / 3.0);
   return ac + fma(-t * z, p, t);
 }
 
-// Kahan angle between two UNIT vectors, ART/ModuleGeometry.py:40-44: 2*atan2(|U-V|, |U+V|).
-// (the reference scales by the two norms first; they are 1 +- 1e-16 here.)
-ART_HD double kahan_angle_unit(double ux, double uy, double uz, double vx, double vy, double vz) {
-  double ax = ux - vx, ay = uy - vy, az = uz - vz;
-  double bx = ux + vx, by = uy + vy, bz = uz + vz;
-  const double a2 = dot3(ax, ay, az, ax, ay, az);
-  const double b2 = dot3(bx, by, bz, bx, by, bz);
-  // tan(angle/2) = sqrt(a2/b2); evaluate atan on the ratio <= 1 and reflect for obtuse angles
-  const double lo = fmin(a2, b2), hi = fmax(a2, b2);
-  if (!(hi > 0.0)) return 0.0;
-  // sqrt(lo/hi) = lo / sqrt(lo*hi); angles below ~1e-145 rad (lo in the denormal range) read as 0
-  const double q = (lo > 1e-290) ? lo * rsqrt_full(lo * hi) : 0.0;
+// Kahan angle between two UNIT vectors, ART/ModuleGeometry.py:40-44: 2*atan2(|U-V|, |U+V|) (the reference scales by
+// the two norms first; they are 1 +- 1e-16 here).  `duv` = U.V, which the caller has anyway.  Of the two norms only
+// the SMALLER is formed from its vector -- that is the one Kahan's formula protects from cancellation; for unit
+// vectors |U-V|^2 + |U+V|^2 = 4, so the larger (>= 2) follows by a subtraction at full relative accuracy.
+ART_HD double kahan_angle_unit(double ux, double uy, double uz, double vx, double vy, double vz, double duv) {
+  const bool acute = duv >= 0.0;                       // |U-V| <= |U+V|
+  const double sg = -copysign(1.0, duv);
+  const double wx = fma(sg, vx, ux), wy = fma(sg, vy, uy), wz = fma(sg, vz, uz);
+  const double lo = dot3(wx, wy, wz, wx, wy, wz), hi = 4.0 - lo;
+  // tan(angle/2) = sqrt(lo/hi) = lo / sqrt(lo*hi); lo = 0 (U = +-V exactly) and denormal lo read as angle 0
+  const double q = lo * rsqrt_full(fmax(lo, 1e-290) * hi);
   const double h = atan01(q);
-  return (a2 <= b2) ? 2.0 * h : 3.14159265358979323846 - 2.0 * h;
+  return acute ? 2.0 * h : fma(-2.0, h, 3.14159265358979323846);
 }
 
 // ART/ModuleGeometry.py:249-268, ART/ModuleSupport.py:68-70,:151-155,:228-230,:322-326,:431-435
@@ -323,9 +375,8 @@ ART_HD void base_normal(const ArtElementDesc& e, double x, double y, double z, d
   } else if (KIND == ART_PARABOLA) {  // :349-355  normalize(-x, -y, p)
     gx = -x; gy = -y; gz = e.mp[0];
   } else if (KIND == ART_TORUS) {  // :480-498  -grad of the quartic form, 4x(S + A) - 8xR^2 = 4x(S - R^2 - r^2)
-    const double R2 = e.mp[0] * e.mp[0], r2 = e.mp[1] * e.mp[1];
     const double S = dot3(x, y, z, x, y, z);
-    const double kxz = S - R2 - r2, ky = S + R2 - r2;
+    const double kxz = S - e.ART_D_SUM2, ky = S + e.ART_D_DIF2;   // R^2 + r^2, R^2 - r^2
     gx = -x * kxz; gy = -y * ky; gz = -z * kxz;
   } else if (KIND == ART_ELLIPSOID) {  // :685-693
     // same direction as (-x/a^2, -y/b^2, -z/b^2), scaled by a^2 b^2 to avoid two divisions
@@ -352,7 +403,7 @@ ART_HD void torus_F(double R, double r2, double x, double y, double z, double ux
   // branch-free: on the torus axis (rho = 0) the clamp keeps 1/rho finite and the side selection below ignores it
   const double rho2 = fmax(fma(x, x, z * z), 1e-300);
   double rho, irho;
-  sqrt_rsqrt(rho2, rho, irho);
+  sqrt_rsqrt_coarse(rho2, rho, irho);
   const double drho = fma(x, ux, z * uz) * irho;  // d rho / dt
   // SIDE < 0: distance to the disk is |y| above/below it (rho <= R) -> a = max(rho - R, 0);  SIDE > 0: a = rho + R
   const double a = (SIDE < 0) ? fmax(rho - R, 0.0) : rho + R;
@@ -401,8 +452,8 @@ ART_HD bool torus_newton(double R, double r2, double Ax, double Ay, double Az, d
 // to cm off the equatorial plane, r ~ 100s of mm) Newton starts within ~1e-2 mm of the root and needs 2 steps where
 // the bounding sphere needed 4.  `ia2` = 1/(R+r)^2, `ic2` = 1/(r(R+r)) (prepare_element()).
 template <int SIDE>
-ART_HD int torus_body_roots(double R, double r2, double rb, double ia2, double ic2, double Ax, double Ay, double Az,
-                            double ux, double uy, double uz, double& ta, double& tb) {
+ART_HD int torus_body_roots(double R, double r2, double rb, double ia2, double ic2, double box_rho2, double box_y2,
+                            double Ax, double Ay, double Az, double ux, double uy, double uz, double& ta, double& tb) {
   // bounding quadric  qa t^2 + 2 hb t + c = 0.  Only starting points are needed, so a single-precision sqrt is
   // enough; the miss test keeps a safety margin for it.
   double qa, hb, c, iqa;
@@ -427,11 +478,9 @@ ART_HD int torus_body_roots(double R, double r2, double rb, double ia2, double i
   // Is the ray origin inside the body?  Usual case for a mirror (the previous optic sits inside the tube): decided
   // without a square root by the inscribed box |y| < 0.7 r, rho < R + 0.7 r (0.7^2 + 0.7^2 < 1); only origins
   // outside that box evaluate F(0) exactly.
+  // (`box_rho2` = (R + 0.7 r)^2, `box_y2` = (0.7 r)^2: wave-uniform, prepared on the host)
   bool origin_inside = false;
-  if (SIDE < 0) {
-    const double r07 = 0.7 * (rb - R), lim = R + r07;
-    origin_inside = (fma(Ax, Ax, Az * Az) < lim * lim) && (Ay * Ay < r07 * r07);
-  }
+  if (SIDE < 0) origin_inside = (fma(Ax, Ax, Az * Az) < box_rho2) && (Ay * Ay < box_y2);
   if (!origin_inside) {
     double F0, dF0;
     torus_F<SIDE>(R, r2, Ax, Ay, Az, ux, uy, uz, F0, dF0);
@@ -492,15 +541,16 @@ ART_HD bool intersect(const ArtElementDesc& e, double Ax, double Ay, double Az, 
   }
   Candidates c = {0, 0.0};
   if (KIND == ART_TORUS) {
-    const double R = e.mp[0], r = e.mp[1], r2 = r * r;
+    const double R = e.mp[0], r = e.mp[1], r2 = e.ART_D_R2;
     double ta = 0.0, tb = 0.0;
-    int n = torus_body_roots<-1>(R, r2, R + r, e.mp[2], e.mp[3], Ax, Ay, Az, ux, uy, uz, ta, tb);
+    int n = torus_body_roots<-1>(R, r2, e.ART_D_RB, e.mp[2], e.mp[3], e.ART_D_BOX_RHO2, e.ART_D_BOX_Y2, Ax, Ay, Az, ux, uy,
+                                 uz, ta, tb);
     consider<KIND>(e, Ax, Ay, Az, ux, uy, uz, ta, n > 0, c);
     consider<KIND>(e, Ax, Ay, Az, ux, uy, uz, tb, n > 1, c);
     if (r > R) {  // self-intersecting torus: the quartic's second factor has real roots too
       // bounding sphere of the lemon: (rho + R)^2 + y^2 <= r^2  =>  rho^2 + y^2 <= r^2 - R^2 (its tips sit on the axis
       // at |y| = sqrt(r^2 - R^2), farther out than its equator rho = r - R)
-      n = torus_body_roots<+1>(R, r2, sqrt(r2 - R * R), 0.0, 0.0, Ax, Ay, Az, ux, uy, uz, ta, tb);
+      n = torus_body_roots<+1>(R, r2, sqrt(r2 - R * R), 0.0, 0.0, 0.0, 0.0, Ax, Ay, Az, ux, uy, uz, ta, tb);
       consider<KIND>(e, Ax, Ay, Az, ux, uy, uz, ta, n > 0, c);
       consider<KIND>(e, Ax, Ay, Az, ux, uy, uz, tb, n > 1, c);
     }
@@ -534,13 +584,39 @@ ART_HD bool intersect(const ArtElementDesc& e, double Ax, double Ay, double Az, 
   return c.cnt == 1 || c.cnt == 2;
 }
 
-// Derived constants the library fills into its own copy of a descriptor before a launch (callers leave mp[2..3] of
-// a torus alone): the spheroid of torus_body_roots.
+// Derived constants.  Every entry point works on its OWN copy of the caller's descriptors and runs prepare_element()
+// on it first; the copy's `bwd` and `pos` (which the kernels do not need once the two offsets below exist: the way
+// back is the transpose of `fwd`) and mp[2..3] of a torus then hold:
+//   bwd[0..2] = centre - fwd * pos       P_optic = fwd * P_lab + bwd[0..2]
+//   bwd[3..5] = pos - fwd^T * centre     P_lab   = fwd^T * P_optic + bwd[3..5]
+// (formed in long double, so that they carry half an ulp of their own and nothing of the products' cancellation) and,
+// for a torus, the wave-uniform constants its intersection and normal would otherwise recompute in every lane:
+//   mp[2] = 1/(R+r)^2, mp[3] = 1/(r(R+r))  (spheroid of torus_body_roots)   bwd[6] = r^2
+//   bwd[7] = (R + 0.7 r)^2, bwd[8] = (0.7 r)^2  (origin-inside box)         pos[0] = R + r, pos[1] = R^2 + r^2,
+//   pos[2] = R^2 - r^2.
 inline void prepare_element(ArtElementDesc& e) {
+  long double in[3], out[3];
+  for (int i = 0; i < 3; ++i) {
+    in[i] = (long double)e.centre[i];
+    out[i] = (long double)e.pos[i];
+    for (int j = 0; j < 3; ++j) {
+      in[i] -= (long double)e.fwd[3 * i + j] * (long double)e.pos[j];
+      out[i] -= (long double)e.fwd[3 * j + i] * (long double)e.centre[j];
+    }
+  }
+  for (int i = 0; i < 3; ++i) { e.bwd[i] = (double)in[i]; e.bwd[3 + i] = (double)out[i]; }
+  e.bwd[6] = e.bwd[7] = e.bwd[8] = 0.0;
+  e.pos[0] = e.pos[1] = e.pos[2] = 0.0;
   if (e.kind == ART_TORUS) {
     const double R = e.mp[0], r = e.mp[1];
     e.mp[2] = 1.0 / ((R + r) * (R + r));
     e.mp[3] = 1.0 / (r * (R + r));
+    e.ART_D_R2 = r * r;
+    e.ART_D_BOX_RHO2 = (R + 0.7 * r) * (R + 0.7 * r);
+    e.ART_D_BOX_Y2 = (0.7 * r) * (0.7 * r);
+    e.ART_D_RB = R + r;
+    e.ART_D_SUM2 = R * R + r * r;
+    e.ART_D_DIF2 = R * R - r * r;
   }
 }
 
@@ -587,8 +663,7 @@ template <int KIND, bool DEFECT>
 ART_HD bool trace_ray(const ArtElementDesc& e, const double* zern, Ray& r) {
   // lab -> optic frame (:289-295)
   double Ax, Ay, Az, ux, uy, uz;
-  mat3_apply(e.fwd, r.ox - e.pos[0], r.oy - e.pos[1], r.oz - e.pos[2], Ax, Ay, Az);
-  Ax += e.centre[0]; Ay += e.centre[1]; Az += e.centre[2];
+  mat3_apply_off(e.fwd, e.ART_D_IN_OFF, r.ox, r.oy, r.oz, Ax, Ay, Az);
   mat3_apply(e.fwd, r.dx, r.dy, r.dz, ux, uy, uz);
 
   double t;
@@ -599,7 +674,7 @@ ART_HD bool trace_ray(const ArtElementDesc& e, const double* zern, Ray& r) {
   if (KIND == ART_MASK || (KIND == ART_KIND_DYN && e.kind == ART_MASK)) {
     // _TransmitMaskRay, ModuleMask.py:93-108: direction unchanged, incidence = angle(v, ez)
     vx = ux; vy = uy; vz = uz;
-    inc = kahan_angle_unit(ux, uy, uz, 0.0, 0.0, 1.0);
+    inc = kahan_angle_unit(ux, uy, uz, 0.0, 0.0, 1.0, uz);
   } else {
     double nx, ny, nz;
 #ifdef ART_DIAG_NONORMAL
@@ -639,19 +714,18 @@ ART_HD bool trace_ray(const ArtElementDesc& e, const double* zern, Ray& r) {
 #ifdef ART_DIAG_NOINC
     inc = dn;
 #else
-    inc = kahan_angle_unit(-ux, -uy, -uz, nx, ny, nz);
+    inc = kahan_angle_unit(-ux, -uy, -uz, nx, ny, nz, -dn);
 #endif
   }
   // optic -> lab frame (:306-309)
-  double ox, oy, oz, dx, dy, dz;
-  // (e.bwd holds the same map built the reference's way; the kernels use the transpose of fwd, which is equal
-  // to it to rounding, to halve the constants they keep in scalar registers)
-  mat3t_apply(e.fwd, Px - e.centre[0], Py - e.centre[1], Pz - e.centre[2], ox, oy, oz);
+  double dx, dy, dz;
+  // (a caller's bwd holds the same map built the reference's way; the kernels use the transpose of fwd, which is
+  // equal to it to rounding, to halve the constants they keep in scalar registers)
+  mat3t_apply_off(e.fwd, e.ART_D_OUT_OFF, Px, Py, Pz, r.ox, r.oy, r.oz);
   mat3t_apply(e.fwd, vx, vy, vz, dx, dy, dz);
   // Ray.vector setter renormalises (ModuleOpticalRay.py:85-90): one Newton step of 1/sqrt on |d|^2 ~ 1
   const double s2 = dot3(dx, dy, dz, dx, dy, dz);
   const double k = fma(-0.5, s2, 1.5);
-  r.ox = ox + e.pos[0]; r.oy = oy + e.pos[1]; r.oz = oz + e.pos[2];
   r.dx = dx * k; r.dy = dy * k; r.dz = dz * k;
   r.path += t;  // |P - A| with |u| = 1 (ModuleMirror.py:904, ModuleMask.py:100)
   r.inc = inc;

@@ -586,9 +586,14 @@ inline void launch_fold_scene(const ChainArgs* seg, int n_chains, int64_t nparts
 }
 
 template <bool DEFECT, int WAVES>
-__global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain(const ChainArgs a, const int64_t n, const int xmap) {
+__global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain(const ChainArgs, const int64_t n, const int xmap) {
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];   // used by the -DART_ZERN_LDS build only
-  chain_body<DEFECT>(a, 0, n, xmap, s_dyn);
+  // The descriptors are read where the launch put them, in the kernel-argument segment (constant address space ->
+  // scalar loads, first parameter = offset 0).  Through the by-value parameter itself that is only what the compiler
+  // usually makes of it: the element index is a run-time value, and one build of the defect kernel came out with the
+  // whole 3.3 KB copied to scratch at entry and 452 vector loads from there.
+  typedef const ChainArgs __attribute__((address_space(4)))* kernarg_t;
+  chain_body<DEFECT>(*(const ChainArgs*)(kernarg_t)__builtin_amdgcn_kernarg_segment_ptr(), 0, n, xmap, s_dyn);
 }
 
 // Many chains in one launch: blockIdx.y = chain, descriptors in the device-resident scene table (art_scene.h).

@@ -89,14 +89,18 @@ typedef struct ArtGridDefect {
  * ART/ModuleProcessing.py:289-295, :306-309 by two constant 3x3 maps built on the host with the
  * reference's own RotationPoint special cases (ART/ModuleGeometry.py:333-343):
  *     P_optic = fwd * (P_lab - pos) + centre        u_optic = fwd * u_lab
- *     P_lab   = bwd * (P_optic - centre) + pos      u_lab   = bwd * u_optic                          */
+ *     P_lab   = bwd * (P_optic - centre) + pos      u_lab   = bwd * u_optic
+ * Callers fill every field except mp[2..3].  Each entry point works on its own copy of the descriptors, in which it
+ * replaces bwd, pos and (torus) mp[2..3] by constants derived from the other fields (the two translations folded
+ * into one offset per direction, squared radii, ...: csrc/art_device.h prepare_element()); the caller's structs are
+ * never written.                                                                                       */
 typedef struct ArtElementDesc {
   int32_t kind;          /* ArtOpticKind                                    */
   int32_t support_kind;  /* ArtSupportKind                                  */
   int32_t n_defects;     /* 0..ART_MAX_DEFECTS Zernike defects on a mirror  */
   uint32_t flags;        /* ART_FLAG_*                                      */
   double fwd[9];         /* row-major                                       */
-  double bwd[9];
+  double bwd[9];         /* informational: the kernels go back through the transpose of fwd (see below) */
   double pos[3];         /* OpticalElement.position                         */
   double centre[3];      /* optic.get_centre() in the optic frame           */
   double sp[6];          /* support parameters                              */
@@ -113,7 +117,7 @@ typedef struct ArtElementDesc {
  * therefore not part of the per-element state (slot i of every bundle is source ray i).
  * Alignment: 8 bytes are enough for correctness; for full throughput every array should start on a cache-line
  * boundary (the package pitches its rows to 512 bytes): rows that start 8 bytes off a line cost about a third of
- * the bandwidth.  mp[2..3] of a torus descriptor are scratch the library fills in its own copy.              */
+ * the bandwidth.                                                                                             */
 typedef struct ArtBundleView {
   double* ox; double* oy; double* oz;   /* Ray.point  */
   double* dx; double* dy; double* dz;   /* Ray.vector */
