@@ -757,12 +757,16 @@ ART_HD void detector_ray(const ArtDetectorDesc& d, const Ray& r, double& Ix, dou
   const double num = dot3(d.normal[0], d.normal[1], d.normal[2], d.centre[0] - r.ox, d.centre[1] - r.oy,
                           d.centre[2] - r.oz);
   const double den = dot3(r.dx, r.dy, r.dz, d.normal[0], d.normal[1], d.normal[2]);
-  const double t = num / den;
+  // ordinary magnitudes (mm-scale lengths over a direction cosine): the refined-seed division and square root of
+  // the tracing path, a third of the IEEE expansions.  A ray parallel to the detector (den = 0) reads NaN.
+  const double t = div_full(num, den);
   Ix = fma(t, r.dx, r.ox); Iy = fma(t, r.dy, r.oy); Iz = fma(t, r.dz, r.oz);
   double rx, ry, rz;
   mat3_apply(d.rot, Ix - d.centre[0], Iy - d.centre[1], Iz - d.centre[2], rx, ry, rz);
   X = rx; Y = ry;
-  opl = fabs(t) * sqrt(dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz)) + r.path;
+  double un, iun;
+  sqrt_rsqrt_coarse(dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz), un, iun);
+  opl = fma(fabs(t), un, r.path);
 }
 
 // Read-out at the current detector position and its derivative with respect to a shift s along -normal

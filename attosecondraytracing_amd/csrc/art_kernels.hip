@@ -219,10 +219,18 @@ template <int CTRL>
 __device__ __forceinline__ double dpp_xchg(const double v) {
   int2 s, r;
   __builtin_memcpy(&s, &v, 8);
-  r.x = __builtin_amdgcn_update_dpp(s.x, s.x, CTRL, 0xf, 0xf, false);
-  r.y = __builtin_amdgcn_update_dpp(s.y, s.y, CTRL, 0xf, 0xf, false);
+  // every lane has a source under these controls: no "old" value to preserve (bound_ctrl), so no copy before the move
+  r.x = __builtin_amdgcn_update_dpp(0, s.x, CTRL, 0xf, 0xf, true);
+  r.y = __builtin_amdgcn_update_dpp(0, s.y, CTRL, 0xf, 0xf, true);
   double d;
   __builtin_memcpy(&d, &r, 8);
+  return d;
+}
+// fmin() on values that come out of LDS compiles to v_max(x, x) (quieting a signalling NaN) + v_min: the bare
+// instruction does the same fold in one
+__device__ __forceinline__ double min_raw(const double a, const double b) {
+  double d;
+  asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
 constexpr int kTileStride = 72;   // doubles per statistic row of the tile (64 + padding against bank conflicts)
@@ -231,17 +239,17 @@ constexpr int kTileStride = 72;   // doubles per statistic row of the tile (64 +
 // Entries >= 24 are padding.
 constexpr int kPassSlot[3][8] = {{0, 1, 6, 7, 8, 9, 10, 11}, {16, 17, 18, 19, 20, 21, 14, 15},
                                  {2, 4, 12, 3, 5, 13, 24, 24}};
-// kPassSlot[pass][j] for a run-time j as a select chain: a table in memory would put a load into the tail
-template <int PASS>
-__device__ __forceinline__ int pass_slot(const int j) {
-  int g = kPassSlot[PASS][0];
-#pragma unroll
-  for (int q = 1; q < 8; ++q) g = (j == q) ? kPassSlot[PASS][q] : g;
-  return g;
+// The per-wave partials go to the scratch area in THIS order (row = pass * 8 + j, rows 22 and 23 unused), so that the
+// tail's three stores need no slot look-up; the fold kernels translate (row_of_slot).
+constexpr int row_of_slot(const int slot) {
+  for (int p = 0; p < 3; ++p)
+    for (int j = 0; j < 8; ++j)
+      if (kPassSlot[p][j] == slot) return p * 8 + j;
+  return -1;
 }
 
 // tile: 8 * kTileStride doubles owned by this wave.  After the call, lanes with (lane & 7) == 0 hold in out[pass] the
-// wave total of statistic kPassSlot[pass][lane >> 3].
+// wave total of statistic kPassSlot[pass][lane >> 3] (= row pass * 8 + (lane >> 3) of the scratch area).
 __device__ __forceinline__ void wave_reduce24(const double (&acc)[kReadoutSlots], double* tile, double (&out)[3]) {
   const int l = threadIdx.x & 63, stat = l >> 3, part = l & 7;
 #pragma unroll
@@ -261,10 +269,10 @@ __device__ __forceinline__ void wave_reduce24(const double (&acc)[kReadoutSlots]
       v += dpp_xchg<0x141>(v);   // row_half_mirror      lane i <-> 7 - i of its group of 8
     } else {
 #pragma unroll
-      for (int k = 1; k < 8; ++k) v = fmin(v, row[8 * k]);
-      v = fmin(v, dpp_xchg<0xB1>(v));
-      v = fmin(v, dpp_xchg<0x4E>(v));
-      v = fmin(v, dpp_xchg<0x141>(v));
+      for (int k = 1; k < 8; ++k) v = min_raw(v, row[8 * k]);
+      v = min_raw(v, dpp_xchg<0xB1>(v));
+      v = min_raw(v, dpp_xchg<0x4E>(v));
+      v = min_raw(v, dpp_xchg<0x141>(v));
       v = (stat >= 3) ? -v : v;  // the maxima were folded as minima of their negatives
     }
     out[pass] = v;
@@ -321,6 +329,25 @@ __device__ __forceinline__ void readout_accumulate(double (&acc)[kReadoutSlots],
   const double ex = live ? x - cx : 0.0, ey = live ? y - cy : 0.0, eo = live ? o - co : 0.0;
   acc[16] = fma(ex, ex, acc[16]); acc[17] = fma(ey, ey, acc[17]); acc[18] = fma(eo, eo, acc[18]);
   acc[19] = fma(ww * ex, ex, acc[19]); acc[20] = fma(ww * ey, ey, acc[20]); acc[21] = fma(ww * eo, eo, acc[21]);
+}
+// The same for the fused tail, where a lane holds exactly ONE ray: the statistics are assigned, not added to their
+// identities (0.0 + x is not x for the compiler: -0.0), which is 14 instructions less per ray.
+__device__ __forceinline__ void readout_single(double (&acc)[kReadoutSlots], const bool live, const double x,
+                                               const double y, const double o, const double wi, const bool has_w,
+                                               const double cx, const double cy, const double co) {
+  const double ww = live ? (has_w ? wi : 1.0) : 0.0;
+  const double xs = live ? x : 0.0, ys = live ? y : 0.0, os = live ? o : 0.0;
+  acc[0] = live ? 1.0 : 0.0; acc[1] = os;
+  acc[2] = live ? x : INFINITY; acc[3] = live ? x : -INFINITY;
+  acc[4] = live ? y : INFINITY; acc[5] = live ? y : -INFINITY;
+  acc[6] = xs; acc[7] = ys;
+  acc[8] = ww; acc[9] = ww * xs; acc[10] = ww * ys; acc[11] = ww * os;
+  acc[12] = live ? o : INFINITY; acc[13] = live ? o : -INFINITY;
+  acc[14] = 0.0; acc[15] = 0.0;
+  const double ex = live ? x - cx : 0.0, ey = live ? y - cy : 0.0, eo = live ? o - co : 0.0;
+  acc[16] = ex * ex; acc[17] = ey * ey; acc[18] = eo * eo;
+  acc[19] = ww * ex * ex; acc[20] = ww * ey * ey; acc[21] = ww * eo * eo;
+  acc[22] = 0.0; acc[23] = 0.0;
 }
 #define ART_READOUT_OPS {RSUM, RSUM, RMIN, RMAX, RMIN, RMAX, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, \
                          RMIN, RMAX, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM}
@@ -479,10 +506,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
       // slot-major into ro.scratch -- no LDS, no barrier and no load down here: a __syncthreads() or a trailing load
       // would make every wave wait for the acknowledgement of its 36 outstanding stores (vmcnt counts loads and
       // stores in one queue) instead of retiring as soon as they are issued, which cost 35 %.
-      const int ops[kReadoutSlots] = ART_READOUT_OPS;
       double acc[kReadoutSlots];
-#pragma unroll
-      for (int k = 0; k < kReadoutSlots; ++k) acc[k] = (ops[k] == RSUM) ? 0.0 : (ops[k] == RMIN ? INFINITY : -INFINITY);
       double Ix, Iy, Iz, x = 0.0, y = 0.0, o = 0.0;
       if (ok) art::detector_ray(a.ro.det, r, Ix, Iy, Iz, x, y, o);
       const unsigned nb8 = (unsigned)(n * 8);
@@ -494,8 +518,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
 #endif
       // re-read the parked weight through an index the compiler cannot prove equal to the one it was stored with
       // (flags has no bit 30), so that the value is neither kept in a register nor spilled
-      readout_accumulate(acc, ok, x, y, o, s_w[threadIdx.x ^ ((unsigned)a.flags >> 30)], a.ro.w != nullptr, a.ro.cx,
-                         a.ro.cy, a.ro.co);
+      readout_single(acc, ok, x, y, o, s_w[threadIdx.x ^ ((unsigned)a.flags >> 30)], a.ro.w != nullptr, a.ro.cx, a.ro.cy,
+                     a.ro.co);
       const int64_t nparts = (int64_t)gridDim.x * (kBlock / 64);
       const int64_t part = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
       double tot[3];
@@ -513,17 +537,17 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
 #endif
         const int stat = (threadIdx.x & 63) >> 3;
         double* dst = a.ro.scratch + part;
-        dst[(int64_t)pass_slot<0>(stat) * nparts] = tot[0];
-        dst[(int64_t)pass_slot<1>(stat) * nparts] = tot[1];
-        if (stat < 6) dst[(int64_t)pass_slot<2>(stat) * nparts] = tot[2];
+        dst[(int64_t)stat * nparts] = tot[0];            // row = pass * 8 + stat (row_of_slot)
+        dst[(int64_t)(8 + stat) * nparts] = tot[1];
+        if (stat < 6) dst[(int64_t)(16 + stat) * nparts] = tot[2];
       }
     }
     i += stride;
   } while (DEFECT && kDefectLoop && i < n);
 }
 
-// Fold of the fused read-out's per-wave partials (slot-major: scratch[slot * nparts + part], 1.6e5 parts per 1e7
-// rays) in two tiny launches, both in a fixed order: kFoldChunks workgroups per statistic each fold one contiguous
+// Fold of the fused read-out's per-wave partials (row-major: scratch[row_of_slot(slot) * nparts + part], 1.6e5 parts
+// per 1e7 rays) in two tiny launches, both in a fixed order: kFoldChunks workgroups per statistic each fold one contiguous
 // chunk of its row into mid[slot * kFoldChunks + chunk] (mid = the tail of the scratch area), then one workgroup per
 // statistic folds the chunks.  (A single workgroup per statistic walking the whole 1.25 MB row took 0.2 ms -- as long
 // as a third of the trace.)  Grids: (24, chunks, chains) and (24, 1, chains).
@@ -547,7 +571,10 @@ __device__ __forceinline__ void fold_stage1(double* scratch, const int64_t npart
   const int ops[kReadoutSlots] = ART_READOUT_OPS;
   const int64_t per = (nparts + kFoldChunks - 1) / kFoldChunks;
   const int64_t lo = (int64_t)blockIdx.y * per, hi = (lo + per < nparts) ? lo + per : nparts;
-  fold_range(scratch + (int64_t)blockIdx.x * nparts, lo, hi, ops[blockIdx.x],
+  int row = 0;
+#pragma unroll
+  for (int k = 0; k < kUsedSlots; ++k) row = ((int)blockIdx.x == k) ? row_of_slot(k) : row;
+  fold_range(scratch + (int64_t)row * nparts, lo, hi, ops[blockIdx.x],
              fold_mid(scratch, nparts) + blockIdx.x * kFoldChunks + blockIdx.y);
 }
 __device__ __forceinline__ void fold_stage2(double* scratch, const int64_t nparts, double* out24) {
