@@ -47,6 +47,8 @@ struct Ray {
 #define ART_D_RB pos[0]
 #define ART_D_SUM2 pos[1]
 #define ART_D_DIF2 pos[2]
+#define ART_D_I2R mp[1]              /* torus: 1/(2R) in place of r (r^2 is ART_D_R2) */
+#define ART_FLAG_D_LEMON 0x80000000u /* torus with r > R: the quartic's second factor has real roots too */
 
 // ---------------------------------------------------------------------------------------------------------
 // small helpers
@@ -445,7 +447,8 @@ ART_HD bool torus_newton(double R, double r2, double Ax, double Ay, double Az, d
 }
 
 // Positive-side roots (entry, exit) of the line with one of the two convex bodies; `rb` = radius of a sphere
-// about the origin that contains the body (R + r for K, sqrt(r^2 - R^2) for L).  Returns the number of roots found.
+// about the origin that contains the body (R + r for K, sqrt(r^2 - R^2) for L).  Returns a mask: bit 0 = entry root
+// in ta, bit 1 = exit root in tb.
 // SIDE = -1 uses a tighter start than the bounding sphere: the oblate spheroid  rho^2/(R+r)^2 + y^2/(r(R+r)) = 1
 // contains K [squaring  (R+r) sqrt(1 - y^2/(r(R+r))) >= R + sqrt(r^2 - y^2)  leaves (R/r)(r - sqrt(r^2-y^2))^2 >= 0]
 // and osculates the outer half-tube along the equator: the gap is of 4th order in y, so for a mirror (rays a few mm
@@ -453,7 +456,8 @@ ART_HD bool torus_newton(double R, double r2, double Ax, double Ay, double Az, d
 // the bounding sphere needed 4.  `ia2` = 1/(R+r)^2, `ic2` = 1/(r(R+r)) (prepare_element()).
 template <int SIDE>
 ART_HD int torus_body_roots(double R, double r2, double rb, double ia2, double ic2, double box_rho2, double box_y2,
-                            double Ax, double Ay, double Az, double ux, double uy, double uz, double& ta, double& tb) {
+                            double dif2, double i2R, double Ax, double Ay, double Az, double ux, double uy, double uz,
+                            double& ta, double& tb) {
   // bounding quadric  qa t^2 + 2 hb t + c = 0.  Only starting points are needed, so a single-precision sqrt is
   // enough; the miss test keeps a safety margin for it.
   double qa, hb, c, iqa;
@@ -488,16 +492,44 @@ ART_HD int torus_body_roots(double R, double r2, double rb, double ia2, double i
     // origin outside the body and moving away from it: both roots (if any) are behind the origin
     any = any && (origin_inside || dF0 < 0.0);
   }
-  // exit root: start just outside the sphere exit, walk left
+  // exit root: start just outside the spheroid exit, walk left
   double t_out = ts2;
-  const bool has_out = torus_newton<SIDE>(R, r2, Ax, Ay, Az, ux, uy, uz, +1.0, any, t_out);
+  bool pre = false;
+  if (SIDE < 0) {
+    // First a Newton step on the EXPANDED quartic, scaled by 1/(4R^2):  g(t) = (W/2R)^2 - rho^2,  W = |P|^2 + R^2 - r^2
+    // = t^2 + 2 b t + c0,  rho^2 = al t^2 + 2 be t + ga  -- two quadratics in t, no square root: half the instructions
+    // of a step on H.  Its value carries the cancellation the reference's quartic suffers from (~1e-10 mm in t), which
+    // is irrelevant for a step that only has to bring the start (~1e-2 mm off) into the range where ONE step on H
+    // finishes.  Near the root g = H * [(rho+R)^2 + y^2 - r^2] / 4R^2 with the second factor positive and nearly
+    // constant, so the step is Newton's on H to first order; it is taken only if it moves left and stays right of the
+    // closest approach, and if the iteration on H then fails from it, the proven start is used after all (below).
+    const double al = fma(ux, ux, uz * uz), be = fma(Ax, ux, Az * uz), ga = fma(Ax, Ax, Az * Az);
+    const double b2 = 2.0 * fma(Ay, uy, be), c0 = fma(Ay, Ay, ga) + dif2;
+    const double s1 = ts2 + b2;
+    const double w = fma(ts2, s1, c0) * i2R, wp = (s1 + ts2) * i2R;
+    const double q1 = fma(al, ts2, be + be);
+    const double Q = fma(q1, ts2, ga), Qp = fma(al, ts2, q1);
+    const double g = fma(w, w, -Q), gp = fma(w + w, wp, -Qp);
+    const double dt = g * rcp_seed(gp);
+    pre = any && (dt > 0.0) && (dt <= ts2 - tm);
+    t_out = pre ? ts2 - dt : ts2;
+  }
+  bool has_out = torus_newton<SIDE>(R, r2, Ax, Ay, Az, ux, uy, uz, +1.0, any, t_out);
+  if (SIDE < 0) {
+    const bool redo = pre && !has_out;
+    if (ART_WAVE_ANY(redo)) {
+      double t2 = ts2;
+      const bool h2 = torus_newton<SIDE>(R, r2, Ax, Ay, Az, ux, uy, uz, +1.0, redo, t2);
+      t_out = redo ? t2 : t_out;
+      has_out = has_out || h2;
+    }
+  }
   // entry root only when the origin is outside the body: start at max(ts1, 0), walk right
   double t_in = (ts1 > 0.0 ? ts1 : 0.0);
   const bool has_in = torus_newton<SIDE>(R, r2, Ax, Ay, Az, ux, uy, uz, -1.0, any && has_out && !origin_inside, t_in);
-  int n = 0;
-  if (has_in) { ta = t_in; n = 1; }
-  if (has_out) { if (n) tb = t_out; else ta = t_out; ++n; }
-  return n;
+  // entry root first: ClosestPoint lets the LATER of two equally close candidates win
+  ta = t_in; tb = t_out;
+  return (has_in ? 1 : 0) | (has_out ? 2 : 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -541,18 +573,18 @@ ART_HD bool intersect(const ArtElementDesc& e, double Ax, double Ay, double Az, 
   }
   Candidates c = {0, 0.0};
   if (KIND == ART_TORUS) {
-    const double R = e.mp[0], r = e.mp[1], r2 = e.ART_D_R2;
+    const double R = e.mp[0], r2 = e.ART_D_R2;
     double ta = 0.0, tb = 0.0;
-    int n = torus_body_roots<-1>(R, r2, e.ART_D_RB, e.mp[2], e.mp[3], e.ART_D_BOX_RHO2, e.ART_D_BOX_Y2, Ax, Ay, Az, ux, uy,
-                                 uz, ta, tb);
-    consider<KIND>(e, Ax, Ay, Az, ux, uy, uz, ta, n > 0, c);
-    consider<KIND>(e, Ax, Ay, Az, ux, uy, uz, tb, n > 1, c);
-    if (r > R) {  // self-intersecting torus: the quartic's second factor has real roots too
+    int n = torus_body_roots<-1>(R, r2, e.ART_D_RB, e.mp[2], e.mp[3], e.ART_D_BOX_RHO2, e.ART_D_BOX_Y2, e.ART_D_DIF2,
+                                 e.ART_D_I2R, Ax, Ay, Az, ux, uy, uz, ta, tb);
+    consider<KIND>(e, Ax, Ay, Az, ux, uy, uz, ta, (n & 1) != 0, c);
+    consider<KIND>(e, Ax, Ay, Az, ux, uy, uz, tb, (n & 2) != 0, c);
+    if (e.flags & ART_FLAG_D_LEMON) {  // self-intersecting torus (r > R): the quartic's second factor has real roots too
       // bounding sphere of the lemon: (rho + R)^2 + y^2 <= r^2  =>  rho^2 + y^2 <= r^2 - R^2 (its tips sit on the axis
       // at |y| = sqrt(r^2 - R^2), farther out than its equator rho = r - R)
-      n = torus_body_roots<+1>(R, r2, sqrt(r2 - R * R), 0.0, 0.0, 0.0, 0.0, Ax, Ay, Az, ux, uy, uz, ta, tb);
-      consider<KIND>(e, Ax, Ay, Az, ux, uy, uz, ta, n > 0, c);
-      consider<KIND>(e, Ax, Ay, Az, ux, uy, uz, tb, n > 1, c);
+      n = torus_body_roots<+1>(R, r2, sqrt(r2 - R * R), 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, Ax, Ay, Az, ux, uy, uz, ta, tb);
+      consider<KIND>(e, Ax, Ay, Az, ux, uy, uz, ta, (n & 1) != 0, c);
+      consider<KIND>(e, Ax, Ay, Az, ux, uy, uz, tb, (n & 2) != 0, c);
     }
   } else {
     double qa, qb, qc;
@@ -593,7 +625,7 @@ ART_HD bool intersect(const ArtElementDesc& e, double Ax, double Ay, double Az, 
 // for a torus, the wave-uniform constants its intersection and normal would otherwise recompute in every lane:
 //   mp[2] = 1/(R+r)^2, mp[3] = 1/(r(R+r))  (spheroid of torus_body_roots)   bwd[6] = r^2
 //   bwd[7] = (R + 0.7 r)^2, bwd[8] = (0.7 r)^2  (origin-inside box)         pos[0] = R + r, pos[1] = R^2 + r^2,
-//   pos[2] = R^2 - r^2.
+//   pos[2] = R^2 - r^2, mp[1] = 1/(2R) (r itself is not needed any more), flags bit 31 = (r > R).
 inline void prepare_element(ArtElementDesc& e) {
   long double in[3], out[3];
   for (int i = 0; i < 3; ++i) {
@@ -607,6 +639,7 @@ inline void prepare_element(ArtElementDesc& e) {
   for (int i = 0; i < 3; ++i) { e.bwd[i] = (double)in[i]; e.bwd[3 + i] = (double)out[i]; }
   e.bwd[6] = e.bwd[7] = e.bwd[8] = 0.0;
   e.pos[0] = e.pos[1] = e.pos[2] = 0.0;
+  e.flags &= ~ART_FLAG_D_LEMON;
   if (e.kind == ART_TORUS) {
     const double R = e.mp[0], r = e.mp[1];
     e.mp[2] = 1.0 / ((R + r) * (R + r));
@@ -617,6 +650,8 @@ inline void prepare_element(ArtElementDesc& e) {
     e.ART_D_RB = R + r;
     e.ART_D_SUM2 = R * R + r * r;
     e.ART_D_DIF2 = R * R - r * r;
+    e.ART_D_I2R = 0.5 / R;
+    if (r > R) e.flags |= ART_FLAG_D_LEMON;
   }
 }
 
