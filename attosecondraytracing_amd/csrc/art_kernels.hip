@@ -250,8 +250,9 @@ constexpr int row_of_slot(const int slot) {
 
 // tile: 8 * kTileStride doubles owned by this wave.  After the call, lanes with (lane & 7) == 0 hold in out[pass] the
 // wave total of statistic kPassSlot[pass][lane >> 3] (= row pass * 8 + (lane >> 3) of the scratch area).
-__device__ __forceinline__ void wave_reduce24(const double (&acc)[kReadoutSlots], double* tile, double (&out)[3]) {
-  const int l = threadIdx.x & 63, stat = l >> 3, part = l & 7;
+__device__ __forceinline__ void wave_reduce24(const double (&acc)[kReadoutSlots], double* tile, const int l,
+                                              double (&out)[3]) {
+  const int stat = l >> 3, part = l & 7;   // l = lane of the wave
 #pragma unroll
   for (int pass = 0; pass < 3; ++pass) {
 #pragma unroll
@@ -465,8 +466,16 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
   const int64_t tile = tile_of(blockIdx.x, gridDim.x, xmap);
   const BundleRsrc bi = make_rsrc(a.in, n, first);
   const int64_t stride = (int64_t)gridDim.x * kBlock;
-  int64_t i = tile * kBlock + threadIdx.x;
+  int64_t i0 = tile * kBlock + threadIdx.x;
   do {
+    // One register identifies the lane from here on: the slot index, made opaque so that the compiler derives both the
+    // buffer offsets and the lane's position in its workgroup (tile * 256 is a multiple of 256) from IT instead of
+    // keeping threadIdx.x alive next to it -- at 80 registers (6 waves per SIMD) that second copy is spilled and its
+    // reload in the tail is a VMEM load behind 32 stores.
+    unsigned slot = (unsigned)i0;
+    asm volatile("" : "+v"(slot));
+    const int64_t i = slot;
+    const unsigned lane = slot & (kBlock - 1);
     art::Ray r;
     r.inc = 0.0;
     uint8_t al;
@@ -474,7 +483,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
     // Weight of the fused read-out: fetched with the ray (a zero-length descriptor without read-out or weights) and
     // parked in LDS until the tail needs it -- held in registers across the chain it costs the 2 VGPRs that push the
     // 5-wave build into scratch, and a scratch reload at the end is a VMEM load behind 36 stores (see the tail).
-    s_w[threadIdx.x] = ld_f64(rsrc_of(const_cast<double*>(a.ro.w) + first,
+    s_w[lane] = ld_f64(rsrc_of(const_cast<double*>(a.ro.w) + first,
                                       ((a.flags & art::kFlagReadout) && a.ro.w) ? (unsigned)(n * 8) : 0u), (unsigned)i * 8u);
     bool ok = al != 0;
     const double* zk = s_zern;
@@ -518,32 +527,32 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
 #endif
       // re-read the parked weight through an index the compiler cannot prove equal to the one it was stored with
       // (flags has no bit 30), so that the value is neither kept in a register nor spilled
-      readout_single(acc, ok, x, y, o, s_w[threadIdx.x ^ ((unsigned)a.flags >> 30)], a.ro.w != nullptr, a.ro.cx, a.ro.cy,
+      readout_single(acc, ok, x, y, o, s_w[lane ^ ((unsigned)a.flags >> 30)], a.ro.w != nullptr, a.ro.cx, a.ro.cy,
                      a.ro.co);
       const int64_t nparts = (int64_t)gridDim.x * (kBlock / 64);
-      const int64_t part = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+      const int64_t part = (int64_t)blockIdx.x * (kBlock / 64) + (lane >> 6);
       double tot[3];
 #ifdef ART_DIAG_RO_NOREDUCE  // ... without the wave reduction, ...
       tot[0] = acc[0] + acc[1] + acc[6] + acc[7] + acc[8] + acc[9] + acc[10] + acc[11];
       tot[1] = acc[16] + acc[17] + acc[18] + acc[19] + acc[20] + acc[21];
       tot[2] = acc[2] + acc[3] + acc[4] + acc[5] + acc[12] + acc[13];
 #else
-      wave_reduce24(acc, s_red + (threadIdx.x >> 6) * (8 * kTileStride), tot);
+      wave_reduce24(acc, s_red + (lane >> 6) * (8 * kTileStride), lane & 63, tot);
 #endif
 #ifdef ART_DIAG_RO_NOSCRATCH  // ... without the partial-statistics stores
       if (tot[0] + tot[1] + tot[2] == -1.2345e300) {
 #else
-      if ((threadIdx.x & 7) == 0) {
+      if ((lane & 7) == 0) {
 #endif
-        const int stat = (threadIdx.x & 63) >> 3;
+        const int stat = (lane & 63) >> 3;
         double* dst = a.ro.scratch + part;
         dst[(int64_t)stat * nparts] = tot[0];            // row = pass * 8 + stat (row_of_slot)
         dst[(int64_t)(8 + stat) * nparts] = tot[1];
         if (stat < 6) dst[(int64_t)(16 + stat) * nparts] = tot[2];
       }
     }
-    i += stride;
-  } while (DEFECT && kDefectLoop && i < n);
+    i0 += stride;
+  } while (DEFECT && kDefectLoop && i0 < n);
 }
 
 // Fold of the fused read-out's per-wave partials (row-major: scratch[row_of_slot(slot) * nparts + part], 1.6e5 parts
@@ -1138,9 +1147,10 @@ inline size_t zern_lds_bytes(const ChainArgs& a) {
   return d * ART_ZERN_STRIDE * sizeof(double);
 }
 #endif
-// register budget of the fused kernel in waves per SIMD: 5 (96 VGPRs, no spills) measures 2.5 % faster than 4
-// (98 VGPRs, which the allocation granule rounds to 104 = 4 waves); 6 needs 12 spilled registers and is 20 % slower.
-// ART_CHAIN_WAVES=4 selects the other build for comparison.
+// register budget of the fused kernel in waves per SIMD: 5 (85 VGPRs).  The 6-wave build (80 VGPRs, no spills either
+// since the lane id is derived from the slot register) is kept as ART_CHAIN_WAVES=6: measured on one box
+// (tools/r02_exp16.sh) it traces relay4 3 % faster without the read-out tail, the same with it, C2 1 % faster and the
+// 8-element C4 chain 13 % slower.
 inline int chain_waves() {
   const char* wv = getenv("ART_CHAIN_WAVES");
   return wv ? atoi(wv) : 5;
@@ -1217,8 +1227,8 @@ static int trace_chain_impl(const ArtElementDesc* elems, int32_t n_elems, const 
       if (a.flags & art::kFlagDefects)
         hipLaunchKernelGGL((k_trace_chain<true, 4>), dim3(kDefectLoop ? grid_for(cnt) : grid_stream_mapped(cnt, xm)), b, lds,
                            s, a, cnt, kDefectLoop ? 0 : xm);
-      else if (waves == 4)
-        hipLaunchKernelGGL((k_trace_chain<false, 4>), g, b, 0, s, a, cnt, xm);
+      else if (waves == 6)
+        hipLaunchKernelGGL((k_trace_chain<false, 6>), g, b, 0, s, a, cnt, xm);
       else
         hipLaunchKernelGGL((k_trace_chain<false, 5>), g, b, 0, s, a, cnt, xm);
       if (tail)
@@ -1290,8 +1300,8 @@ int art_trace_scene(const void* image_dev, int32_t n_chains, int32_t n_elems, in
       const ChainArgs* seg = tab + (int64_t)sg * n_chains;
       if (flags & 1)
         hipLaunchKernelGGL((k_trace_scene<true, 4>), g, b, 0, s, seg, off, cnt, xm);
-      else if (waves == 4)
-        hipLaunchKernelGGL((k_trace_scene<false, 4>), g, b, 0, s, seg, off, cnt, xm);
+      else if (waves == 6)
+        hipLaunchKernelGGL((k_trace_scene<false, 6>), g, b, 0, s, seg, off, cnt, xm);
       else
         hipLaunchKernelGGL((k_trace_scene<false, 5>), g, b, 0, s, seg, off, cnt, xm);
       if ((flags & art::kFlagReadout) && sg == S - 1)
