@@ -511,8 +511,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
     } while (++k < a.n_elems);
     if (a.flags & art::kFlagReadout) {
       // Fused detector read-out of the last bundle (art_trace_chain_readout): the ray is still in registers.  X, Y, opl
-      // of dead rays are dropped by the range check.  Statistics: one partial per WAVE (shuffle tree only), written
-      // slot-major into ro.scratch -- no LDS, no barrier and no load down here: a __syncthreads() or a trailing load
+      // of dead rays are dropped by the range check.  Statistics: one partial per WAVE (wave_reduce24), written row by
+      // row (row_of_slot) into ro.scratch -- no barrier and no load down here: a __syncthreads() or a trailing load
       // would make every wave wait for the acknowledgement of its 36 outstanding stores (vmcnt counts loads and
       // stores in one queue) instead of retiring as soon as they are issued, which cost 35 %.
       double acc[kReadoutSlots];
@@ -1155,8 +1155,8 @@ inline int chain_waves() {
   const char* wv = getenv("ART_CHAIN_WAVES");
   return wv ? atoi(wv) : 5;
 }
-// (the fused kernel WITH defects stays at 4 waves: 126 VGPRs without spills; at 5 waves it spills 25 dwords and
-// measured 0.40 instead of 0.23 ms per 1e7 rays on the C5 surface)
+// (the fused kernel WITH defects stays at 4 waves: 112 VGPRs without spills; at 5 waves it spills 15 dwords and
+// measured 0.335 instead of 0.31 ms per 1e7 rays on C5, tools/r02_exp17.sh)
 }  // namespace
 
 static int trace_chain_impl(const ArtElementDesc* elems, int32_t n_elems, const ArtBundleView* in,
