@@ -47,6 +47,31 @@ def run_edge_cases():
         wall = moe.OpticalElement(mmask.Mask(msupp.SupportRound(1e6)), np.array([0.0, 0.0, 10.0]),
                                   np.array([0.0, 0.0, -1.0]), np.array([1.0, 0.0, 0.0]))
         assert [len(o) for o in mp.RayTracingCalculation(_bundle(300), [wall, oe], mode=mode)] == [0, 0]
+    # Exactly normal incidence: one of the two Kahan norms is exactly 0 (no NaN from 0 * rsqrt(0)).  `oe`'s pose (normal
+    # -z, major axis x) is two point inversions = the identity frame, so a ray along +z meets the plane from BEHIND and
+    # the reference's angle(-v, n) is pi; with the major axis along y the frame is improper and the hit is frontal: 0.
+    head_on = RayBundle.from_arrays(np.zeros((2, 3)), np.array([[0.0, 0.0, 1.0], [0.0, 0.0, 1.0]]), np.arange(2), np.ones(2))
+    front = moe.OpticalElement(mmirror.MirrorPlane(msupp.SupportRound(10.0)), np.array([0.0, 0.0, 50.0]),
+                               np.array([0.0, 0.0, -1.0]), np.array([0.0, 1.0, 0.0]))
+    hole = moe.OpticalElement(mmask.Mask(msupp.SupportRoundHole(20.0, 5.0, 0.0, 0.0)), np.array([0.0, 0.0, 10.0]),
+                              np.array([0.0, 0.0, -1.0]), np.array([0.0, 1.0, 0.0]))
+    for mode in ("chain", "element"):
+        inc = mp.RayTracingCalculation(head_on, [oe, oe], mode=mode)[0].data[7].cpu().numpy()
+        assert np.array_equal(inc, [np.pi, np.pi])
+        out = mp.RayTracingCalculation(head_on, [hole, front], mode=mode)
+        assert len(out[0]) == 2 and len(out[1]) == 2
+        assert np.array_equal(out[0].data[7].cpu().numpy(), [np.pi, np.pi])       # mask: angle(v, ez) with v = -ez in its frame
+        assert np.array_equal(out[1].data[7].cpu().numpy(), [0.0, 0.0])
+    # incidence angles over the whole range against the closed form on a plane mirror
+    th = np.concatenate([np.linspace(0.0, 1.55, 400), [1e-9, 1e-6, 1e-3, 0.78539816339, 1.5]])
+    Vt = np.stack([np.sin(th), np.zeros_like(th), np.cos(th)], axis=1)
+    wide = moe.OpticalElement(mmirror.MirrorPlane(msupp.SupportRound(1e9)), np.array([0.0, 0.0, 50.0]),
+                              np.array([0.0, 0.0, -1.0]), np.array([0.0, 1.0, 0.0]))
+    fan = RayBundle.from_arrays(np.zeros((len(th), 3)), Vt, np.arange(len(th)), np.ones(len(th)))
+    out = mp.RayTracingCalculation(fan, [wide], mode="element")[0]
+    assert len(out) == len(th)
+    want = np.arctan2(Vt[:, 0], Vt[:, 2])
+    assert np.abs(out.data[7].cpu().numpy() - want).max() <= 6e-16
     # a chain longer than one fused launch (8 elements): 19 bounces between two facing plane mirrors, with and
     # without history, in both modes; the optical path is known in closed form
     top = moe.OpticalElement(mmirror.MirrorPlane(msupp.SupportRound(1e4)), np.array([0.0, 0.0, 50.0]),
