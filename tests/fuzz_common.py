@@ -149,6 +149,25 @@ def curvature_radius(e):
 GRAZING = 1.5   # rad (86 deg): beyond it the hit point is ill-conditioned (error amplified by 1/cos(incidence))
 
 
+def pose_noise(e):
+    """Rounding noise (rad) the REFERENCE's frame construction carries for this pose.  Its two RotationPoint steps
+    (normal -> ez, then the rotated major axis -> ex; ART/ModuleProcessing.py:284-295, ART/ModuleGeometry.py:333-343)
+    rotate about Axis1 x Axis2; when the two are within an angle d of antiparallel (but outside the 1e-10 special case)
+    that cross product is d long and carries ~1e-16 of rounding, i.e. the axis of a half-turn is uncertain by 1e-16/d
+    and so is everything behind it, twice.  Any two evaluations of the same formulas (the reference with
+    numpy-quaternion, the oracle, the package's frame_maps) differ by that much: seed 40030221 has d = 5.2e-7 and the
+    oracle and the kernels 5e-10 apart in every direction, with both builds of the kernels."""
+    n, m = np.asarray(e["normal"], float), np.asarray(e["majoraxis"], float)
+    ez, ex = np.array([0.0, 0.0, 1.0]), np.array([1.0, 0.0, 0.0])
+    m1 = orc.rotation_point(m[None, :], n, ez)[0]
+    noise = 0.0
+    for u, v in ((n, ez), (m1, ex)):
+        d = np.linalg.norm(np.cross(u, v)) / (np.linalg.norm(u) * np.linalg.norm(v))     # sin of the angle between them
+        if np.dot(u, v) < 0.0 and d > 1e-10:
+            noise += 8e-16 / d
+    return noise
+
+
 def run_differential(seeds, modes=("chain", "element"), n_rays=1500):
     """Trace every seeded scene with the active product backend and with the oracle.  Survivor indices must agree
     for every ray after every element; positions / directions / paths / incidence within the parity tolerances for
@@ -181,6 +200,7 @@ def run_differential(seeds, modes=("chain", "element"), n_rays=1500):
                 rc = curvature_radius(e)
                 if rc:
                     dir_tol = max(dir_tol, pc.REL_TOL * 2 * scale / rc)
+                dir_tol = max(dir_tol, pose_noise(e))    # nearly antiparallel frame axes: the reference's own noise
                 pos_tol = pc.REL_TOL if k == 0 else max(pc.REL_TOL, dir_tol)   # lever arm <= scene scale
                 m = well[ref.number]
                 if not m.any():
