@@ -586,12 +586,22 @@ __device__ __forceinline__ void fold_stage1(double* scratch, const int64_t npart
   fold_range(scratch + (int64_t)row * nparts, lo, hi, ops[blockIdx.x],
              fold_mid(scratch, nparts) + blockIdx.x * kFoldChunks + blockIdx.y);
 }
-__device__ __forceinline__ void fold_stage2(double* scratch, const int64_t nparts, double* out24) {
+// Small bundles (<= kFoldDirect per-wave partials, i.e. <= 5e5 rays): ONE launch, every statistic's workgroup folds its
+// whole row -- at 1e5 rays the step is three ~5-us graph nodes, and the middle one is pure launch latency.
+constexpr int64_t kFoldDirect = 8192;
+__device__ __forceinline__ void fold_stage2(double* scratch, const int64_t nparts, double* out24, const int direct) {
   if (blockIdx.x >= kUsedSlots) {
     if (threadIdx.x == 0) out24[blockIdx.x] = 0.0;
     return;
   }
   const int ops[kReadoutSlots] = ART_READOUT_OPS;
+  if (direct) {
+    int row = 0;
+#pragma unroll
+    for (int k = 0; k < kUsedSlots; ++k) row = ((int)blockIdx.x == k) ? row_of_slot(k) : row;
+    fold_range(scratch + (int64_t)row * nparts, 0, nparts, ops[blockIdx.x], out24 + blockIdx.x);
+    return;
+  }
   // nparts == 0 (an empty bundle): no chunk was written, the fold of nothing leaves the identities
   fold_range(fold_mid(scratch, nparts) + blockIdx.x * kFoldChunks, 0, nparts > 0 ? kFoldChunks : 0, ops[blockIdx.x],
              out24 + blockIdx.x);
@@ -599,26 +609,30 @@ __device__ __forceinline__ void fold_stage2(double* scratch, const int64_t npart
 __global__ __launch_bounds__(kBlock) void k_chain_readout_fold1(const ChainArgs* __restrict__ tab, const int64_t nparts) {
   fold_stage1(tab[blockIdx.z].ro.scratch, nparts);
 }
-__global__ __launch_bounds__(kBlock) void k_chain_readout_fold2(const ChainArgs* __restrict__ tab, const int64_t nparts) {
-  fold_stage2(tab[blockIdx.z].ro.scratch, nparts, tab[blockIdx.z].ro.out24);
+__global__ __launch_bounds__(kBlock) void k_chain_readout_fold2(const ChainArgs* __restrict__ tab, const int64_t nparts,
+                                                                const int direct) {
+  fold_stage2(tab[blockIdx.z].ro.scratch, nparts, tab[blockIdx.z].ro.out24, direct);
 }
 __global__ __launch_bounds__(kBlock) void k_chain_readout_fold1_one(double* scratch, const int64_t nparts) {
   fold_stage1(scratch, nparts);
 }
-__global__ __launch_bounds__(kBlock) void k_chain_readout_fold2_one(double* scratch, double* out24, const int64_t nparts) {
-  fold_stage2(scratch, nparts, out24);
+__global__ __launch_bounds__(kBlock) void k_chain_readout_fold2_one(double* scratch, double* out24, const int64_t nparts,
+                                                                    const int direct) {
+  fold_stage2(scratch, nparts, out24, direct);
 }
 
-// launch both stages (host side)
+// launch the fold (host side)
 inline void launch_fold_one(double* scratch, double* out24, int64_t nparts, hipStream_t s) {
-  if (nparts > 0)
+  const int direct = nparts <= kFoldDirect;
+  if (nparts > 0 && !direct)
     hipLaunchKernelGGL(k_chain_readout_fold1_one, dim3(kReadoutSlots, kFoldChunks), dim3(kBlock), 0, s, scratch, nparts);
-  hipLaunchKernelGGL(k_chain_readout_fold2_one, dim3(kReadoutSlots), dim3(kBlock), 0, s, scratch, out24, nparts);
+  hipLaunchKernelGGL(k_chain_readout_fold2_one, dim3(kReadoutSlots), dim3(kBlock), 0, s, scratch, out24, nparts, direct);
 }
 inline void launch_fold_scene(const ChainArgs* seg, int n_chains, int64_t nparts, hipStream_t s) {
-  if (nparts > 0)
+  const int direct = nparts <= kFoldDirect;
+  if (nparts > 0 && !direct)
     hipLaunchKernelGGL(k_chain_readout_fold1, dim3(kReadoutSlots, kFoldChunks, n_chains), dim3(kBlock), 0, s, seg, nparts);
-  hipLaunchKernelGGL(k_chain_readout_fold2, dim3(kReadoutSlots, 1, n_chains), dim3(kBlock), 0, s, seg, nparts);
+  hipLaunchKernelGGL(k_chain_readout_fold2, dim3(kReadoutSlots, 1, n_chains), dim3(kBlock), 0, s, seg, nparts, direct);
 }
 
 template <bool DEFECT, int WAVES>
