@@ -152,9 +152,15 @@ class Exchange:
     """The per-step exchange of a sharded run in ONE collective: statistics of every shard + an evenly spaced sample
     of every shard's read-out, all-gathered (every rank gets the global statistics; any rank can draw the sample).
     Buffers are allocated once; per step it costs two tiny kernels (art_exchange_pack / art_exchange_fold) and the
-    all-gather -- the host work of a step stays far below its GPU time."""
+    all-gather -- the host work of a step stays far below its GPU time.
 
-    def __init__(self, backend, n_slots, sample=20000):
+    Two ways to use it.  `exchange(stats, X, Y, opl, alive)` does everything in place on the caller's stream.
+    `start(b, ...)` / `finish(b)` split it over `buffers` independent buffer sets: `start` packs and enqueues the
+    collective asynchronously (it runs on the communicator's stream behind the pack kernel), `finish` makes the caller's
+    stream wait for it and folds -- so the all-gather of step i travels while step i+1 is traced, and its ~0.1 ms of
+    latency does not add to a 0.7-ms step."""
+
+    def __init__(self, backend, n_slots, sample=20000, buffers=2):
         self.be = backend
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         per_rank = 0 if sample <= 0 else max(1, sample // self.world)      # sample = 0: statistics only
@@ -164,19 +170,39 @@ class Exchange:
         # art_exchange_pack reads X/Y/opl/alive[slot] without a bounds check of its own
         assert self.k == 0 or (int(self.slots.min()) >= 0 and int(self.slots.max()) < int(n_slots)), "sample slot out of range"
         self.stride = 24 + 4 * self.k
-        self.send = torch.empty(self.stride, dtype=torch.float64, device=backend.device)
-        self.recv = torch.empty(self.world * self.stride, dtype=torch.float64, device=backend.device)
-        self.stats = torch.empty(24, dtype=torch.float64, device=backend.device)
+        self.sends = [torch.empty(self.stride, dtype=torch.float64, device=backend.device) for _ in range(buffers)]
+        self.recvs = [torch.empty(self.world * self.stride, dtype=torch.float64, device=backend.device) for _ in range(buffers)]
+        self.statss = [torch.empty(24, dtype=torch.float64, device=backend.device) for _ in range(buffers)]
+        self.work = [None] * buffers
+        self.pending = [False] * buffers
+        self.send, self.recv, self.stats = self.sends[0], self.recvs[0], self.statss[0]     # set 0 under the old names
+
+    def start(self, b, stats_dev, X, Y, opl, alive):
+        """Pack this rank's contribution into buffer set b and enqueue the all-gather (asynchronous where a process
+        group exists).  Set b must have been finished since its last start."""
+        assert not self.pending[b], "Exchange.start on a buffer set whose previous exchange was not finished"
+        self.be.exchange_pack(stats_dev, X, Y, opl, alive, self.slots, self.sends[b])
+        if self.world > 1 or (dist.is_available() and dist.is_initialized()):
+            self.work[b] = dist.all_gather_into_tensor(self.recvs[b], self.sends[b], async_op=True)
+        else:
+            self.recvs[b].copy_(self.sends[b])
+        self.pending[b] = True
+
+    def finish(self, b):
+        """-> (global statistics [24], sample [world, k, 4] = X, Y, opl, alive) of the exchange started on set b --
+        views of reused buffers, valid until set b is started again."""
+        assert self.pending[b], "Exchange.finish without a start"
+        if self.work[b] is not None:
+            self.work[b].wait()          # the caller's stream waits; the host does not (NCCL/RCCL), or blocks (gloo)
+            self.work[b] = None
+        self.pending[b] = False
+        self.be.exchange_fold(self.recvs[b], self.world, self.stride, self.statss[b])
+        return self.statss[b], self.recvs[b].view(self.world, self.stride)[:, 24:].reshape(self.world, self.k, 4)
 
     def __call__(self, stats_dev, X, Y, opl, alive):
         """Returns (global statistics [24], sample [world, k, 4] = X, Y, opl, alive) -- views of reused buffers."""
-        self.be.exchange_pack(stats_dev, X, Y, opl, alive, self.slots, self.send)
-        if self.world > 1 or (dist.is_available() and dist.is_initialized()):
-            dist.all_gather_into_tensor(self.recv, self.send)
-        else:
-            self.recv.copy_(self.send)
-        self.be.exchange_fold(self.recv, self.world, self.stride, self.stats)
-        return self.stats, self.recv.view(self.world, self.stride)[:, 24:].reshape(self.world, self.k, 4)
+        self.start(0, stats_dev, X, Y, opl, alive)
+        return self.finish(0)
 
 
 class ReadoutGather:

@@ -482,14 +482,26 @@ def worker(args):
     exchange = sharding.Exchange(be, n, sample=20000) if use_dist else None
     sample_k = exchange.k if exchange else 0
     gather = sharding.ReadoutGather(n, world, rank, be.device, dst=0, buffers=2) if use_dist else None
-    state = {"stats": None, "sample": None, "step": 0}
+    state = {"stats": None, "sample": None, "step": 0, "xstep": 0}
+
+    def exchange_drain():
+        # fold the exchange that is still in flight (the last step's) and start the numbering afresh
+        if exchange is not None and state["xstep"] > 0:
+            state["stats"], state["sample"] = exchange.finish((state["xstep"] - 1) % 2)
+            state["xstep"] = 0
 
     def step(full_gather):
         # nothing in a step blocks the host: launches queue up like the steps of a training loop
         o, r = trace_and_readout()
         if use_dist:
-            # ONE collective per step: statistics of every shard + a sample of every shard's read-out (last chain)
-            state["stats"], state["sample"] = exchange(r[-1]["stats_dev"], r[-1]["X"], r[-1]["Y"], r[-1]["opl"], o[-1][-1].alive)
+            # ONE collective per step: statistics of every shard + a sample of every shard's read-out (last chain).
+            # Double-buffered like the full gather below: the all-gather of this step travels while the next step is
+            # traced, its result is folded one step later (exchange_drain() picks up the last one).
+            b = state["xstep"] % 2
+            if state["xstep"] > 0:
+                state["stats"], state["sample"] = exchange.finish(1 - b)
+            exchange.start(b, r[-1]["stats_dev"], r[-1]["X"], r[-1]["Y"], r[-1]["opl"], o[-1][-1].alive)
+            state["xstep"] += 1
             if full_gather:
                 # + ONE gather of every ray's read-out to rank 0, overlapped with the next step's tracing
                 gather.start(state["step"] % 2, r[-1]["X"], r[-1]["Y"], r[-1]["opl"], o[-1][-1].alive)
@@ -507,6 +519,7 @@ def worker(args):
     def timed(full_gather, steps):
         for _ in range(args.warmup):
             step(full_gather)
+        exchange_drain()
         if gather:
             gather.drain()
         barrier()
@@ -515,8 +528,9 @@ def worker(args):
         for k in range(steps):
             o, r = step(full_gather)
         t_enq = time.perf_counter() - t0     # host time to enqueue all steps (diagnostic: host-bound if ~ dt)
+        exchange_drain()                     # the last step's statistics are folded ...
         if gather:
-            gather.drain()                   # every gather has landed on rank 0 before the clock stops
+            gather.drain()                   # ... and every gather has landed on rank 0 before the clock stops
         sync()
         barrier()
         dt = time.perf_counter() - t0
@@ -549,6 +563,7 @@ def worker(args):
         # a step COUNT, derived from the rank-reduced dt: identical on every rank (the steps carry a collective)
         for _ in range(max(1, int(np.ceil(SETTLE_SECONDS / (dt / args.steps))))):
             step(False)
+        exchange_drain()
         sync()
         saved_w, args.warmup = args.warmup, 0
         dt_sus, _, o, r = timed(False, args.steps)

@@ -101,6 +101,18 @@ def _worker(rank, world, port, n_total, q):
         if rank == 0:
             off = sizes[0]
             assert torch.equal(smp[1][:, 0:3], XYO[:, off + ex.slots].T)    # the other rank's sample, global order
+        # the pipelined form (bench.py: the all-gather of step i travels while step i+1 is traced): both buffer sets in
+        # flight, finished in order, same results; a set cannot be started twice without a finish
+        ex.start(0, r["stats_dev"], r["X"], r["Y"], r["opl"], last.alive)
+        ex.start(1, r["stats_dev"], r["X"], r["Y"], r["opl"], last.alive)
+        try:
+            ex.start(0, r["stats_dev"], r["X"], r["Y"], r["opl"], last.alive)
+            raise RuntimeError("second start on a pending buffer set was accepted")
+        except AssertionError:
+            pass
+        for b in (0, 1):
+            stb, smpb = ex.finish(b)
+            assert torch.equal(stb, stats) and torch.equal(smpb[rank], mine)
         # the north_star's gather as ONE collective (what bench.py times as value_full_gather): equal shards, two
         # buffer sets used alternately
         nmin = min(sizes)
