@@ -460,10 +460,11 @@ def worker(args):
     # the detectors are in place before the timed region, so their read-out rides on the tracing launch (the ray is
     # still in registers: 24 B/ray of outputs instead of a second pass that re-reads 57 B/ray); --readout separate
     # launches art_detector_readout on the last bundle instead
-    # auto: fused, except for one long chain (>= 8 elements, C4).  Measured per step, fused vs separate:
-    # C2 0.47 vs 0.70 ms, C3 4.09 vs 5.25 ms (many chains, a third to a half of the rays stopped by the mask: the fused
-    # tail skips them and replaces 10-11 small read-out launches), relay4 0.71 vs 0.75 ms, C5 0.40 vs 0.42 ms; C4
-    # 1.64 vs 1.55 ms -- behind eight elements the tail's extra arithmetic costs more than the saved re-read gains.
+    # auto: fused, except for one long chain (>= 8 elements, C4).  Measured per step, fused vs separate (DESIGN.md 5,
+    # tools/r02_exp19.sh, one box): C2 0.44 vs 0.69 ms, C3 3.97 vs 5.14 ms (many chains, a third to a half of the rays
+    # stopped by the mask: the fused tail skips them and replaces 10-11 small read-out launches), relay4 0.77 vs
+    # 0.80 ms; C4 1.65 vs 1.69 ms -- level behind eight elements (72 history streams already in flight), where the
+    # separate launch stays the default.
     fuse = mode == "chain" and (args.readout == "fused" or (args.readout == "auto" and (batched or n_elems < 8)))
     program = None
     if batched or use_graph:
