@@ -460,12 +460,11 @@ def worker(args):
     # the detectors are in place before the timed region, so their read-out rides on the tracing launch (the ray is
     # still in registers: 24 B/ray of outputs instead of a second pass that re-reads 57 B/ray); --readout separate
     # launches art_detector_readout on the last bundle instead
-    # auto: fused, except for one long chain (>= 8 elements, C4).  Measured per step, fused vs separate (DESIGN.md 5,
-    # tools/r02_exp19.sh, one box): C2 0.44 vs 0.69 ms, C3 3.97 vs 5.14 ms (many chains, a third to a half of the rays
-    # stopped by the mask: the fused tail skips them and replaces 10-11 small read-out launches), relay4 0.77 vs
-    # 0.80 ms; C4 1.65 vs 1.69 ms -- level behind eight elements (72 history streams already in flight), where the
-    # separate launch stays the default.
-    fuse = mode == "chain" and (args.readout == "fused" or (args.readout == "auto" and (batched or n_elems < 8)))
+    # auto = fused.  Measured per step, fused vs separate (tools/r02_exp19.sh, one box): C2 0.44 vs 0.69 ms,
+    # C3 3.97 vs 5.14 ms (many chains, a third to a half of the rays stopped by the mask: the fused tail skips them and
+    # replaces 10-11 small read-out launches), relay4 0.77 vs 0.80 ms, C4 1.56-1.58 vs 1.64-1.66 ms (behind eight
+    # elements the tail used to cost more than the saved re-read; since its instruction count went down it wins there too).
+    fuse = mode == "chain" and args.readout in ("fused", "auto")
     program = None
     if batched or use_graph:
         program = SceneProgram([src] * n_chains, element_lists, IgnoreDefects=ignore_defects,
@@ -634,7 +633,7 @@ def worker(args):
                 kprefix = "k_trace_element<"
             # profiles/r0N_<config>.json: the configuration as bench runs it by default; the other read-out mode is
             # profiled as r0N_<config>_fused.json / _separate.json
-            auto_fuse = batched or n_elems < 8
+            auto_fuse = True
             base = f"relay{args.mirrors}" if cfg == "relay4" else cfg        # (profiles exist for the 4-mirror headline)
             pkey = base if fuse == auto_fuse else base + ("_fused" if fuse else "_separate")
             tr = profiled_traffic(pkey, kprefix, n)
@@ -723,7 +722,7 @@ def main(argv=None):
                     help="N > 1: contiguous index ranges per rank (default) or rank r traces rays r, r + N, ...")
     ap.add_argument("--readout", default="auto", choices=["auto", "fused", "separate"],
                     help="fused: the detector read-out rides on the tracing launch; separate: its own kernel afterwards; "
-                         "auto (default): fused, except for a single chain of 8 or more elements")
+                         "auto (default) = fused")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="rays of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args(argv)
     if args.cpu_sample < 0:
