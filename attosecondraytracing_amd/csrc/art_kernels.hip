@@ -1169,6 +1169,17 @@ inline int chain_waves() {
   const char* wv = getenv("ART_CHAIN_WAVES");
   return wv ? atoi(wv) : 5;
 }
+// ART_CHAIN_DYN_LDS=<bytes>: unused dynamic LDS per workgroup of the fused kernel, i.e. FEWER resident workgroups per CU
+// (20 KB static + 20480 -> 4, + 33000 -> 3).  An experiment knob: the bare access pattern gains 3-7 % of bandwidth with 2-3
+// instead of 8 workgroups per CU (tools/stream_floor.hip); the kernel needs its waves to hide latency.
+inline size_t chain_dyn_lds() {
+  static const size_t v = [] {
+    const char* e = getenv("ART_CHAIN_DYN_LDS");
+    const long x = e ? atol(e) : 0;
+    return (size_t)(x < 0 ? 0 : (x > 100000 ? 100000 : x));
+  }();
+  return v;
+}
 // (the fused kernel WITH defects stays at 4 waves: 112 VGPRs without spills; at 5 waves it spills 15 dwords and
 // measured 0.335 instead of 0.31 ms per 1e7 rays on C5, tools/r02_exp17.sh)
 }  // namespace
@@ -1242,9 +1253,9 @@ static int trace_chain_impl(const ArtElementDesc* elems, int32_t n_elems, const 
         hipLaunchKernelGGL((k_trace_chain<true, 4>), dim3(kDefectLoop ? grid_for(cnt) : grid_stream_mapped(cnt, xm)), b, lds,
                            s, a, cnt, kDefectLoop ? 0 : xm);
       else if (waves == 6)
-        hipLaunchKernelGGL((k_trace_chain<false, 6>), g, b, 0, s, a, cnt, xm);
+        hipLaunchKernelGGL((k_trace_chain<false, 6>), g, b, chain_dyn_lds(), s, a, cnt, xm);
       else
-        hipLaunchKernelGGL((k_trace_chain<false, 5>), g, b, 0, s, a, cnt, xm);
+        hipLaunchKernelGGL((k_trace_chain<false, 5>), g, b, chain_dyn_lds(), s, a, cnt, xm);
       if (tail)
         launch_fold_one(ro->scratch, ro->out24, (int64_t)g.x * (kBlock / 64), s);
       cur = a.out[m - 1];

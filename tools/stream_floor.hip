@@ -17,18 +17,18 @@ constexpr int kB = 256;
 
 template <int E, bool NT>
 __global__ __launch_bounds__(kB) void k_soa(const double* __restrict__ in, const uint8_t* __restrict__ ain, double* __restrict__ out,
-                                            uint8_t* __restrict__ aout, int64_t n) {
+                                            uint8_t* __restrict__ aout, int64_t n, int64_t pitch) {
   const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
   if (i >= n) return;
   double v[8];
 #pragma unroll
-  for (int f = 0; f < 7; ++f) v[f] = __builtin_nontemporal_load(in + f * n + i);
+  for (int f = 0; f < 7; ++f) v[f] = __builtin_nontemporal_load(in + f * pitch + i);
   v[7] = (double)ain[i];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
 #pragma unroll
     for (int f = 0; f < 8; ++f) {
-      double* p = out + ((int64_t)e * 8 + f) * n + i;
+      double* p = out + ((int64_t)e * 8 + f) * pitch + i;
       if (NT) __builtin_nontemporal_store(v[f] + e, p); else *p = v[f] + e;
     }
     if (NT) __builtin_nontemporal_store((uint8_t)1, aout + (int64_t)e * n + i); else aout[(int64_t)e * n + i] = 1;
@@ -149,13 +149,29 @@ static int run(int64_t n) {
   const int64_t nb = (n + kB - 1) / kB;
   n = nb * kB;                                   // whole tiles, so that the tiled variants need no tail
   double *in, *out; uint8_t *ain, *aout;
-  CK(hipMalloc(&in, 8 * n * 8)); CK(hipMalloc(&out, (size_t)E * 8 * n * 8)); CK(hipMalloc(&ain, n)); CK(hipMalloc(&aout, (size_t)E * n));
+  const int64_t kMaxPad = 1 << 22;   // doubles of extra row pitch tried below (<= 32 MB per row)
+  CK(hipMalloc(&in, 8 * (n + kMaxPad) * 8)); CK(hipMalloc(&out, (size_t)E * 8 * (n + kMaxPad) * 8)); CK(hipMalloc(&ain, n)); CK(hipMalloc(&aout, (size_t)E * n));
   CK(hipMemset(in, 0, 8 * n * 8)); CK(hipMemset(ain, 1, n));
   const double bytes = (57.0 + 65.0 * E) * n;
   const int reps = 100;
   auto line = [&](const char* name, float ms, double b) { printf("%-34s E=%d  %8.4f ms  %7.3f TB/s  (%.3f GB)\n", name, E, ms, b / ms * 1e-9, b * 1e-9); fflush(stdout); };
-  line("soa  nt stores", timeit([&] { k_soa<E, true><<<nb, kB>>>(in, ain, out, aout, n); }, reps), bytes);
-  line("soa  plain stores", timeit([&] { k_soa<E, false><<<nb, kB>>>(in, ain, out, aout, n); }, reps), bytes);
+  line("soa  nt stores", timeit([&] { k_soa<E, true><<<nb, kB>>>(in, ain, out, aout, n, n); }, reps), bytes);
+  line("soa  plain stores", timeit([&] { k_soa<E, false><<<nb, kB>>>(in, ain, out, aout, n, n); }, reps), bytes);
+  // the same rows further apart: does the relative placement of the 8E + 7 streams in the channel / bank interleave matter?
+  const int64_t pads[] = {64, 512, 8192 + 64, 131072 + 512, 1 << 18, 1 << 19, 1 << 20, (1 << 20) + (1 << 19), 1 << 21, (1 << 21) + 512,
+                          3 << 20, kMaxPad};
+  // fewer resident workgroups per CU (dynamic LDS as the limiter; 160 KB per CU): a narrower window of addresses in flight
+  const int ldss[] = {20 * 1024, 32 * 1024, 53 * 1024, 80 * 1024};
+  for (int lds : ldss) {
+    char name[64];
+    snprintf(name, sizeof name, "soa  nt, %d workgroups per CU", 160 * 1024 / lds);
+    line(name, timeit([&] { k_soa<E, true><<<nb, kB, lds>>>(in, ain, out, aout, n, n); }, reps), bytes);
+  }
+  for (int64_t pad : pads) {
+    char name[64];
+    snprintf(name, sizeof name, "soa  nt, row pitch + %lld B", (long long)pad * 8);
+    line(name, timeit([&] { k_soa<E, true><<<nb, kB>>>(in, ain, out, aout, n, n + pad); }, reps), bytes);
+  }
   line("tile 256 rays (16 KB blocks)", timeit([&] { k_tile<E, 256><<<nb, kB>>>(in, ain, out, aout, n); }, reps), bytes);
   line("tile 64 rays (4 KB blocks)", timeit([&] { k_tile<E, 64><<<nb, kB>>>(in, ain, out, aout, n); }, reps), bytes);
   line("soa  16 B per lane, 512 rays/WG", timeit([&] { k_soa16<E, 256, true><<<(n / 2 + 255) / 256, 256>>>(in, ain, out, aout, n); }, reps), bytes);
