@@ -204,4 +204,19 @@ int art_cpu_make_extended_source(double radius, double divergence, int64_t n_poi
   return 0;
 }
 
+// test hooks for the scalar helpers of art_device.h (tests/test_device_math.py): n values each
+void art_cpu_kahan_angle_unit(const double* u, const double* v, int64_t n, double* out) {
+  for (int64_t i = 0; i < n; ++i)
+    out[i] = art::kahan_angle_unit(u[3 * i], u[3 * i + 1], u[3 * i + 2], v[3 * i], v[3 * i + 1], v[3 * i + 2],
+                                   art::dot3(u[3 * i], u[3 * i + 1], u[3 * i + 2], v[3 * i], v[3 * i + 1], v[3 * i + 2]));
+}
+void art_cpu_atan01(const double* q, int64_t n, double* out) {
+  for (int64_t i = 0; i < n; ++i) out[i] = art::atan01(q[i]);
+}
+// prepare_element on a copy: the derived slots (art_device.h) for inspection
+void art_cpu_prepare_element(const ArtElementDesc* in, ArtElementDesc* out) {
+  *out = *in;
+  art::prepare_element(*out);
+}
+
 }  // extern "C"

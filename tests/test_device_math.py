@@ -1,0 +1,105 @@
+"""Scalar helpers of csrc/art_device.h checked on their own through the CPU twin (oracle/_twin, the same header compiled
+by g++; on the device only the reciprocal / square-root seeds differ): the Kahan angle with one norm, atan on [0, 1], and
+the constants prepare_element() derives.  The tracing tests cover them only through whole scenes."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+from attosecondraytracing_amd import _abi  # noqa: E402
+import twin_backend  # noqa: E402
+
+
+def _lib():
+    lib = C.CDLL(twin_backend.build_twin())
+    dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+    lib.art_cpu_kahan_angle_unit.argtypes = [dp, dp, C.c_int64, dp]
+    lib.art_cpu_kahan_angle_unit.restype = None
+    lib.art_cpu_atan01.argtypes = [dp, C.c_int64, dp]
+    lib.art_cpu_atan01.restype = None
+    lib.art_cpu_prepare_element.argtypes = [C.POINTER(_abi.ArtElementDesc), C.POINTER(_abi.ArtElementDesc)]
+    lib.art_cpu_prepare_element.restype = None
+    return lib
+
+
+def _unit(v):
+    return v / np.linalg.norm(v, axis=-1, keepdims=True)
+
+
+def test_atan01_against_long_double():
+    lib = _lib()
+    q = np.concatenate([np.linspace(0.0, 1.0, 20001), [0.19891236737965800, 0.19891236737965803, 0.66817863791929891,
+                                                        0.66817863791929902, 1e-300, 1e-17, 1.0 - 1e-16]])
+    out = np.empty_like(q)
+    lib.art_cpu_atan01(np.ascontiguousarray(q), len(q), out)
+    want = np.arctan(q.astype(np.longdouble))
+    err = np.abs(out.astype(np.longdouble) - want)
+    assert float(err.max()) <= 2.3e-16          # ~1 ulp at pi/4
+    assert float((err / np.maximum(want, np.longdouble(1e-300))).max()) <= 4e-16
+
+
+def test_kahan_angle_of_unit_vectors_against_long_double():
+    lib = _lib()
+    rng = np.random.default_rng(11)
+    n = 20000
+    u = _unit(rng.normal(size=(n, 3)))
+    # angles from 1e-12 rad to pi - 1e-12 rad, log-spaced at both ends + uniform in between
+    ang = np.concatenate([10.0 ** rng.uniform(-12, 0, n // 4), np.pi - 10.0 ** rng.uniform(-12, 0, n // 4),
+                          rng.uniform(0.0, np.pi, n - 2 * (n // 4))])
+    t = _unit(np.cross(u, rng.normal(size=(n, 3))))            # unit, orthogonal to u
+    v = _unit(np.cos(ang)[:, None] * u + np.sin(ang)[:, None] * t)
+    out = np.empty(n)
+    lib.art_cpu_kahan_angle_unit(np.ascontiguousarray(u), np.ascontiguousarray(v), n, out)
+    # truth from the stored (rounded) vectors in long double: 2 atan2(|u|v - v|u||, |u|v + v|u||)
+    ul, vl = u.astype(np.longdouble), v.astype(np.longdouble)
+    nu, nv = np.sqrt((ul * ul).sum(1))[:, None], np.sqrt((vl * vl).sum(1))[:, None]
+    a, b = ul * nv - vl * nu, ul * nv + vl * nu
+    want = 2 * np.arctan2(np.sqrt((a * a).sum(1)), np.sqrt((b * b).sum(1)))
+    err = np.abs(out.astype(np.longdouble) - want)
+    # absolute 7e-16 (1.5 ulp of pi; measured worst 5.0e-16 near 2.7 rad) or relative 1.5e-15 of the angle (of pi - angle
+    # near a half-turn), whichever is larger: the vectors are unit to 1.1e-16 each, which is what "4 - lo" assumes
+    tol = np.maximum(np.longdouble(7e-16), np.longdouble(1.5e-15) * np.minimum(want, np.pi - want))
+    assert bool((err <= tol).all()), (float((err / tol).max()), float(want[np.argmax(err / tol)]))
+    # exact cases
+    e = np.array([[0.0, 0.0, 1.0], [0.0, 0.0, 1.0], [1.0, 0.0, 0.0]])
+    f = np.array([[0.0, 0.0, 1.0], [0.0, 0.0, -1.0], [0.0, 1.0, 0.0]])
+    o3 = np.empty(3)
+    lib.art_cpu_kahan_angle_unit(e, f, 3, o3)
+    assert o3[0] == 0.0 and o3[1] == np.pi and abs(o3[2] - np.pi / 2) <= 2.3e-16
+
+
+def test_prepared_descriptor_slots():
+    lib = _lib()
+    rng = np.random.default_rng(5)
+    d = _abi.ArtElementDesc()
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    pos, centre = rng.uniform(-2000, 2000, 3), np.array([0.0, 0.0, -5585.0 - 173.0])
+    d.kind = 3                               # ART_TORUS
+    d.fwd[:] = q.ravel()
+    d.bwd[:] = q.T.ravel()
+    d.pos[:] = pos
+    d.centre[:] = centre
+    R, r = 5585.1223, 173.6482
+    d.mp[0], d.mp[1] = R, r
+    before = bytes(d)
+    out = _abi.ArtElementDesc()
+    lib.art_cpu_prepare_element(C.byref(d), C.byref(out))
+    assert bytes(d) == before                                   # the caller's struct is not written
+    ql, pl, cl = q.astype(np.longdouble), pos.astype(np.longdouble), centre.astype(np.longdouble)
+    in_off, out_off = cl - ql @ pl, pl - ql.T @ cl
+    got = np.array(out.bwd[:])
+    assert np.abs(got[0:3] - in_off.astype(float)).max() <= 1e-12 and np.abs(got[3:6] - out_off.astype(float)).max() <= 1e-12
+    # a point goes in and comes back to 1e-12 mm through the two offsets
+    P = rng.uniform(-3000, 3000, 3)
+    back = q.T @ (q @ P + got[0:3]) + got[3:6]
+    assert np.abs(back - P).max() <= 2e-12
+    assert got[6] == r * r and got[7] == (R + 0.7 * r) ** 2 and got[8] == (0.7 * r) ** 2
+    assert out.pos[0] == R + r and out.pos[1] == R * R + r * r and out.pos[2] == R * R - r * r
+    assert out.mp[0] == R and out.mp[1] == 0.5 / R and out.mp[2] == 1.0 / ((R + r) ** 2) and out.mp[3] == 1.0 / (r * (R + r))
+    assert out.flags & 0x80000000 == 0
+    d.mp[0], d.mp[1] = 100.0, 150.0                             # r > R: the "lemon" flag
+    lib.art_cpu_prepare_element(C.byref(d), C.byref(out))
+    assert out.flags & 0x80000000
