@@ -59,9 +59,13 @@ def test_kahan_angle_of_unit_vectors_against_long_double():
     a, b = ul * nv - vl * nu, ul * nv + vl * nu
     want = 2 * np.arctan2(np.sqrt((a * a).sum(1)), np.sqrt((b * b).sum(1)))
     err = np.abs(out.astype(np.longdouble) - want)
-    # absolute 7e-16 (1.5 ulp of pi; measured worst 5.0e-16 near 2.7 rad) or relative 1.5e-15 of the angle (of pi - angle
-    # near a half-turn), whichever is larger: the vectors are unit to 1.1e-16 each, which is what "4 - lo" assumes
-    tol = np.maximum(np.longdouble(7e-16), np.longdouble(1.5e-15) * np.minimum(want, np.pi - want))
+    # Small angles keep their RELATIVE accuracy (what Kahan's form is for): 1.5e-15 of the angle, plus what treating the
+    # vectors as exactly unit costs -- |u| and |v| differ by d ~ 2e-16, a radial component that enters |u - v|^2 beside
+    # the angular one: relative (d / angle)^2 / 2, i.e. 1e-8 at 1e-12 rad (an absolute 1e-20 rad) and below 1e-16 from
+    # 1e-8 rad on.  From 1 rad on, and near a half-turn where the result is pi - 2 atan(.), 1.5 ulp of pi (measured
+    # worst: 5.0e-16 near 2.7 rad).
+    tol = np.where(want < 1.0, want * (np.longdouble(1.5e-15) + (np.longdouble(3e-16) / np.maximum(want, 1e-300)) ** 2),
+                   np.longdouble(7e-16))
     assert bool((err <= tol).all()), (float((err / tol).max()), float(want[np.argmax(err / tol)]))
     # exact cases
     e = np.array([[0.0, 0.0, 1.0], [0.0, 0.0, 1.0], [1.0, 0.0, 0.0]])
