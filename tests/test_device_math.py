@@ -59,14 +59,33 @@ def test_kahan_angle_of_unit_vectors_against_long_double():
     a, b = ul * nv - vl * nu, ul * nv + vl * nu
     want = 2 * np.arctan2(np.sqrt((a * a).sum(1)), np.sqrt((b * b).sum(1)))
     err = np.abs(out.astype(np.longdouble) - want)
-    # Small angles keep their RELATIVE accuracy (what Kahan's form is for): 1.5e-15 of the angle, plus what treating the
-    # vectors as exactly unit costs -- |u| and |v| differ by d ~ 2e-16, a radial component that enters |u - v|^2 beside
-    # the angular one: relative (d / angle)^2 / 2, i.e. 1e-8 at 1e-12 rad (an absolute 1e-20 rad) and below 1e-16 from
-    # 1e-8 rad on.  From 1 rad on, and near a half-turn where the result is pi - 2 atan(.), 1.5 ulp of pi (measured
-    # worst: 5.0e-16 near 2.7 rad).
-    tol = np.where(want < 1.0, want * (np.longdouble(1.5e-15) + (np.longdouble(3e-16) / np.maximum(want, 1e-300)) ** 2),
-                   np.longdouble(7e-16))
+    # From 1e-3 rad on (long double is a good enough truth there): 1.5e-15 of the angle below 1 rad; beyond, and near a
+    # half-turn where the result is pi - 2 atan(.), 1.5 ulp of pi (measured worst: 5.0e-16 near 2.7 rad).
+    tol = np.where(want < 1e-3, np.inf, np.where(want < 1.0, np.longdouble(1.5e-15) * want, np.longdouble(7e-16)))
     assert bool((err <= tol).all()), (float((err / tol).max()), float(want[np.argmax(err / tol)]))
+    # Small angles keep their RELATIVE accuracy (what Kahan's form is for).  Truth in 60-digit decimal arithmetic (at
+    # 1e-8 rad long double resolves the angle between two stored vectors to 1e-11 only).  Allowed: 1.5e-15 of the angle
+    # plus what treating the vectors as exactly unit costs -- |u| and |v| differ by d ~ 2e-16, a radial component that
+    # enters |u - v|^2 beside the angular one: relative (d / angle)^2 / 2, i.e. 1e-8 at 1e-12 rad (an absolute 1e-20
+    # rad) and below 1e-16 from 1e-8 rad on.
+    from decimal import Decimal, getcontext
+    getcontext().prec = 60
+    small = np.flatnonzero(want < 1e-3)[:400]
+    assert len(small) > 100
+    for i in small:
+        U, V = [Decimal(float(c)) for c in u[i]], [Decimal(float(c)) for c in v[i]]
+        lu, lv = sum(c * c for c in U).sqrt(), sum(c * c for c in V).sqrt()
+        A = sum((p * lv - q * lu) ** 2 for p, q in zip(U, V)).sqrt()
+        B = sum((p * lv + q * lu) ** 2 for p, q in zip(U, V)).sqrt()
+        x = A / B
+        th, term, k = Decimal(0), x, 0
+        while abs(term) > Decimal(10) ** -55:
+            th += term / (2 * k + 1) * (-1) ** k
+            term *= x * x
+            k += 1
+        th *= 2
+        rel = abs(Decimal(float(out[i])) - th) / th
+        assert rel <= Decimal(1.5e-15) + (Decimal(3e-16) / th) ** 2, (float(th), float(rel))
     # exact cases
     e = np.array([[0.0, 0.0, 1.0], [0.0, 0.0, 1.0], [1.0, 0.0, 0.0]])
     f = np.array([[0.0, 0.0, 1.0], [0.0, 0.0, -1.0], [0.0, 1.0, 0.0]])
