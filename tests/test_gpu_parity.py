@@ -614,6 +614,31 @@ def test_gpu_fused_readout_full_size(hip):
     assert rel <= 1e-11
 
 
+def test_gpu_fused_readout_fold_boundary(hip):
+    """The fused read-out's partial statistics are folded by one launch up to 8192 per-wave partials (524 288 rays) and
+    by two above: both sides of the boundary, and a scene launch of two chains, against the separate read-out."""
+    import torch
+    import bench
+    import ART.ModuleProcessing as mp
+    import ART.ModuleDetector as mdet
+    chain, _ = bench.build_scene(2)
+    els = chain.optical_elements
+    for n in (8192 * 64, 8192 * 64 + 1, 8193 * 64, 300_001):
+        src = bench.device_source(n, 0, n, hip)
+        plain = mp.RayTracingCalculation(src, els)
+        D = mdet.Detector(np.asarray(els[-1].position, dtype=float))
+        D.autoplace(plain[-1], 600.0)
+        want = D.readout(plain[-1], sync=False)["stats_dev"].cpu().numpy()
+        outs = [mp.RayTracingCalculation(src, els, detector=D)] + mp.RayTracingCalculationMany([src, src], [els, els], detectors=[D, D])
+        for out in outs:
+            got = D.readout(out[-1], sync=False)
+            assert got["X"] is out[-1]._fused_readout[2]["X"]
+            g = got["stats_dev"].cpu().numpy()
+            assert g[0] == want[0] == n and all(g[k] == want[k] for k in (2, 3, 4, 5, 12, 13)) and g[22] == 0.0 and g[23] == 0.0
+            for k in (1, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 20, 21):
+                assert abs(g[k] - want[k]) <= 1e-11 * abs(want[k]), (n, k, g[k], want[k])
+
+
 def test_gpu_batched_full_size_c2(hip):
     """BASELINE C2 size: 11 chains x 1e6 rays in one launch == 11 single launches, bit for bit."""
     import torch
