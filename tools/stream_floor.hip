@@ -53,6 +53,42 @@ __global__ __launch_bounds__(kB) void k_tile(const double* __restrict__ in, cons
   }
 }
 
+// variants of the 8-byte pattern that take it apart: MODE 0 = loads only (the 7 + 1 input streams, one dummy store per
+// workgroup), 1 = plain (cached) loads instead of non-temporal ones, 2 = the stores do not depend on the loads (issued
+// first), 3 = the loads come from a 57-KB block that stays in cache (stores as in the pattern)
+template <int E, int MODE>
+__global__ __launch_bounds__(kB) void k_soa_parts(const double* __restrict__ in, const uint8_t* __restrict__ ain, double* __restrict__ out,
+                                                  uint8_t* __restrict__ aout, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= n) return;
+  double v[8];
+  if (MODE == 2) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+#pragma unroll
+      for (int f = 0; f < 8; ++f) __builtin_nontemporal_store((double)(e + f), out + ((int64_t)e * 8 + f) * n + i);
+      __builtin_nontemporal_store((uint8_t)1, aout + (int64_t)e * n + i);
+    }
+  }
+  const int64_t li = (MODE == 3) ? (i & 1023) : i;
+#pragma unroll
+  for (int f = 0; f < 7; ++f) v[f] = (MODE == 1 || MODE == 3) ? in[f * n + li] : __builtin_nontemporal_load(in + f * n + li);
+  v[7] = (double)ain[li];
+  if (MODE == 0 || MODE == 2) {
+    double s = 0;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) s += v[f];
+    if (s == -1.2345e300) out[i] = s;      // keeps the loads alive, never true
+    return;
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+#pragma unroll
+    for (int f = 0; f < 8; ++f) __builtin_nontemporal_store(v[f] + e, out + ((int64_t)e * 8 + f) * n + i);
+    __builtin_nontemporal_store((uint8_t)1, aout + (int64_t)e * n + i);
+  }
+}
+
 // two adjacent rays per lane: 16-byte loads and stores, WG threads per workgroup (2 * WG rays)
 template <int E, int WG, bool ALIVE>
 __global__ __launch_bounds__(WG) void k_soa16(const double* __restrict__ in, const uint8_t* __restrict__ ain, double* __restrict__ out,
@@ -160,6 +196,10 @@ static int run(int64_t n) {
   // the same rows further apart: does the relative placement of the 8E + 7 streams in the channel / bank interleave matter?
   const int64_t pads[] = {64, 512, 8192 + 64, 131072 + 512, 1 << 18, 1 << 19, 1 << 20, (1 << 20) + (1 << 19), 1 << 21, (1 << 21) + 512,
                           3 << 20, kMaxPad};
+  line("parts: loads only (57 B/ray)", timeit([&] { k_soa_parts<E, 0><<<nb, kB>>>(in, ain, out, aout, n); }, reps), 57.0 * n);
+  line("parts: plain (cached) loads", timeit([&] { k_soa_parts<E, 1><<<nb, kB>>>(in, ain, out, aout, n); }, reps), bytes);
+  line("parts: stores first, then loads", timeit([&] { k_soa_parts<E, 2><<<nb, kB>>>(in, ain, out, aout, n); }, reps), bytes);
+  line("parts: loads from cache, stores", timeit([&] { k_soa_parts<E, 3><<<nb, kB>>>(in, ain, out, aout, n); }, reps), 65.0 * E * n);
   // fewer resident workgroups per CU (dynamic LDS as the limiter; 160 KB per CU): a narrower window of addresses in flight
   const int ldss[] = {20 * 1024, 32 * 1024, 53 * 1024, 80 * 1024};
   for (int lds : ldss) {
