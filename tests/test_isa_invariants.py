@@ -5,7 +5,9 @@
     one in-order queue, so a late load, a fence or a scratch reload makes every wave wait for the acknowledgement of all
     its outstanding stores instead of retiring;
   * the scene kernel fetches its descriptors with scalar loads only (no vector loads of table data);
-  * the Zernike evaluators keep their coefficients scalar (no LDS traffic in the defect kernels; <= 128 VGPRs)."""
+  * the Zernike evaluators keep their coefficients scalar (no LDS traffic in the defect kernels; <= 128 VGPRs);
+  * the vector-instruction count of the torus path and of the fused kernel stays where the round-2 work put it
+    (compile-time constants as scalar operands, no IEEE sqrtf / division expansions, no select chains in the tail)."""
 import os
 import re
 import shutil
@@ -91,3 +93,23 @@ def test_zernike_coefficients_stay_scalar(kernels):
         assert sum(bool(re.search(r"v_fma_f64 v\[\d+:\d+\], v\[\d+:\d+\], v\[\d+:\d+\], s\[\d+:\d+\]", l)) for l in code) > 300, kind
         # ... not copied into VGPRs first (the compiler's two-address v_fmac form needs 2 v_mov per coefficient)
         assert sum("v_mov_b32" in l for l in code) < 400, kind
+
+
+def _valu(code):
+    return [l.split()[0] for l in (x.strip() for x in code) if l.startswith("v_")]
+
+
+def test_vector_instruction_budget(kernels):
+    """Static VALU counts (all paths of the kernel, lemon and retry blocks included): a quarter below the mid-round build.
+    A constant that slips back into a VGPR pair, an IEEE expansion or a select chain shows up here before it shows up
+    as milliseconds (tools/valu_count.py)."""
+    torus = _valu(kernels["k_trace_element<3, false>"]["code"])
+    chain = _valu(kernels["k_trace_chain<false, 5>"]["code"])
+    assert len(torus) <= 730, len(torus)            # 694 (mid-round: 838 with one solver path less)
+    assert len(chain) <= 2170, len(chain)           # 2066 (mid-round: 2558)
+    # no IEEE division / sqrt expansions on the torus path (the quadrics keep ONE IEEE division on purpose: q / a with a
+    # leading coefficient that may be 1e-34)
+    assert not [i for i in torus if i.startswith(("v_div_scale", "v_div_fmas", "v_div_fixup", "v_sqrt_f32"))]
+    # the atan polynomial's 10 coefficients are scalar operands: few literal moves into VGPRs remain in the whole kernel
+    lit = [l for l in kernels["k_trace_element<3, false>"]["code"] if re.search(r"v_mov_b32_e32 v\d+, 0x[0-9a-f]{6,}", l)]
+    assert len(lit) <= 24, len(lit)
