@@ -787,7 +787,43 @@ __global__ __launch_bounds__(kBlock) void k_detector_readout(const ArtDetectorDe
     st_2f64(r3x, o16, p3[0][0], p3[0][1]); st_2f64(r3y, o16, p3[1][0], p3[1][1]); st_2f64(r3z, o16, p3[2][0], p3[2][1]);
     st_2f64(rX, o16, xo[0], xo[1]); st_2f64(rY, o16, yo[0], yo[1]); st_2f64(rO, o16, oo[0], oo[1]);
   }
+#ifdef ART_READOUT_SHUFFLE_REDUCE      // round-1 form: 24 shuffle trees per wave + __syncthreads()
   block_reduce_store<kReadoutSlots>(acc, ops, scratch + (int64_t)blockIdx.x * kReadoutSlots);
+#else
+  // One partial per WORKGROUP, [block][24] as k_readout_final expects it.  Per wave the LDS transpose of the fused tail
+  // (wave_reduce24, ~100 instructions instead of 24 shuffle trees), then the four waves meet in LDS behind a bare
+  // s_barrier: __syncthreads() would also wait for the acknowledgement of every store this workgroup has in flight
+  // (vmcnt).  174 -> 158 us per 1e7 rays (tools/r02_exp21.sh).
+  __shared__ double s_tile[(kBlock / 64) * 8 * kTileStride];
+  __shared__ double s_part[kBlock / 64][kReadoutSlots];
+  const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
+  double tot[3];
+  wave_reduce24(acc, s_tile + wv_ * (8 * kTileStride), lane, tot);
+  if ((lane & 7) == 0) {
+    const int stat = lane >> 3;
+    int g0 = 0, g1 = 0, g2 = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      g0 = (stat == q) ? kPassSlot[0][q] : g0;
+      g1 = (stat == q) ? kPassSlot[1][q] : g1;
+      g2 = (stat == q) ? kPassSlot[2][q] : g2;
+    }
+    s_part[wv_][g0] = tot[0];
+    s_part[wv_][g1] = tot[1];
+    if (stat < 6) s_part[wv_][g2] = tot[2];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (threadIdx.x < kUsedSlots) {
+    const int k = threadIdx.x;
+    double v = s_part[0][k];
+#pragma unroll
+    for (int j = 1; j < kBlock / 64; ++j)
+      v = (ops[k] == RSUM) ? v + s_part[j][k] : (ops[k] == RMIN ? fmin(v, s_part[j][k]) : fmax(v, s_part[j][k]));
+    scratch[(int64_t)blockIdx.x * kReadoutSlots + k] = v;
+  } else if (threadIdx.x < kReadoutSlots) {
+    scratch[(int64_t)blockIdx.x * kReadoutSlots + threadIdx.x] = 0.0;    // reserved slots 22, 23
+  }
+#endif
 }
 
 constexpr int kScanSlots = 33;
@@ -1161,6 +1197,18 @@ inline size_t zern_lds_bytes(const ChainArgs& a) {
   return d * ART_ZERN_STRIDE * sizeof(double);
 }
 #endif
+// Workgroups per launch of the separate read-out: a persistent grid of kReadoutBlocks (2048).  The scratch area has room
+// for 8 x that; ART_READOUT_BLOCKS=<n> uses it (measured at 1e7 rays, tools/r02_exp21.sh: 2048 -> 157-160 us, 4096 ->
+// 161, 8192 -> 161, 16384 -> 170-177: here the per-workgroup reduction outweighs what shorter-lived workgroups gain).
+inline int64_t readout_block_cap(int64_t launches) {
+  static const int64_t env = [] {
+    const char* e = getenv("ART_READOUT_BLOCKS");
+    const long x = e ? atol(e) : 0;
+    return (int64_t)(x < 1 ? 0 : x);
+  }();
+  const int64_t room = (int64_t)8 * kReadoutBlocks / (launches < 1 ? 1 : launches);
+  return (env > 0) ? (env < room ? env : room) : (kReadoutBlocks < room ? kReadoutBlocks : room);
+}
 // register budget of the fused kernel in waves per SIMD: 5 (85 VGPRs).  The 6-wave build (80 VGPRs, no spills either
 // since the lane id is derived from the slot register) is kept as ART_CHAIN_WAVES=6: measured on one box
 // (tools/r02_exp16.sh) it traces relay4 3 % faster without the read-out tail, the same with it, C2 1 % faster and the
@@ -1403,12 +1451,14 @@ int art_detector_readout(const ArtDetectorDesc* d, const ArtBundleView* b, const
   // one launch per <= 2^28 rays (32-bit buffer offsets); every launch leaves one partial per workgroup, all of
   // them folded by the final kernel: scratch holds up to 8 launches x kReadoutBlocks workgroups x 24 doubles
   const int64_t chunk = max_rays_per_launch();
-  if ((n + chunk - 1) / chunk > 8) return fail(ART_ERR_UNSUPPORTED, "more than 2^31 rays in one read-out");
+  const int64_t launches = (n + chunk - 1) / chunk;
+  if (launches > 8) return fail(ART_ERR_UNSUPPORTED, "more than 2^31 rays in one read-out");
   int nb_total = 0;
   for (int64_t off = 0; off < n; off += chunk) {
     const int64_t m = (n - off < chunk) ? n - off : chunk;
     const int64_t want = ((m + 1) / 2 + kBlock - 1) / kBlock;      // two slots per thread
-    const int nb = (int)(want < 1 ? 1 : (want > kReadoutBlocks ? kReadoutBlocks : want));
+    const int64_t cap = readout_block_cap(launches);
+    const int nb = (int)(want < 1 ? 1 : (want > cap ? cap : want));
     const ArtBundleView v = view_at(*b, off);
     hipLaunchKernelGGL(k_detector_readout, dim3(nb), dim3(kBlock), 0, s, *d, v, w ? w + off : nullptr, m, cx, cy, co,
                        p3x ? p3x + off : nullptr, p3y ? p3y + off : nullptr, p3z ? p3z + off : nullptr,
