@@ -411,23 +411,30 @@ __global__ __launch_bounds__(kBlock) void k_trace_element(const ElemArg ea, cons
 using art::ChainArgs;
 using art::kChainMax;
 
-#ifdef ART_STORE_LDS4
-// Experiment: the 8 fp64 outputs of an element go through LDS so that every wave instruction
-// stores 16 B per lane = 1 KiB of ONE stream (wave w owns streams 2w and 2w+1 of the workgroup's 256 rays) instead of
-// 8 B per lane = 512 B.  Dead rays' slots receive unspecified values (their alive byte is 0).
+#ifndef ART_STORE_DIRECT
+// The 8 fp64 outputs of an element go through LDS so that every wave instruction stores 16 B per lane = 1 KiB of ONE
+// stream (wave w owns streams 2w and 2w+1 of the workgroup's 256 rays) instead of 8 B per lane = 512 B: half the store
+// instructions per element.  Mid-round, with the kernel bound by arithmetic, this bought nothing; with a quarter of the
+// instructions gone it is 4-5 % on relay4 and 11 % on the 8-element C4 chain (tools/r02_exp22.sh; -DART_STORE_DIRECT is
+// the 8-byte form).  A PAIR of slots is written when either ray is alive (the dead one's slot receives its last live
+// state: unspecified by contract, its alive byte is 0); pairs of dead rays are dropped by the range check, so a masked
+// bundle costs the bytes of its survivors, as before.  The two barriers order LDS only (no vmcnt wait: ISA checked).
 __device__ __forceinline__ void store_tile_lds4(const ArtBundleView& v, const int64_t n, const int64_t first,
-                                                const int64_t tile0, const art::Ray& r, const bool ok,
-                                                double (*s_out)[kBlock]) {
-  const int t = threadIdx.x;
+                                                const int64_t tile0, const unsigned t, const art::Ray& r, const bool ok,
+                                                double (*s_out)[kBlock], uint8_t* s_al) {
   s_out[0][t] = r.ox; s_out[1][t] = r.oy; s_out[2][t] = r.oz;
   s_out[3][t] = r.dx; s_out[4][t] = r.dy; s_out[5][t] = r.dz;
   s_out[6][t] = r.path; s_out[7][t] = r.inc;
+  s_al[t] = (uint8_t)(ok ? 1 : 0);
   const unsigned nb = (unsigned)(v.alive != nullptr ? n : 0);
   __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(ok ? 1 : 0), rsrc_of(v.alive + first, nb), (int)(unsigned)(tile0 + t), 0,
                                        ART_ST_AUX);
   __syncthreads();
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(t >> 6)), l = (int)(t & 63);
   double* const* rows = &v.ox;   // ox, oy, oz, dx, dy, dz, path, incidence are consecutive pointers
+  bool keep[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) keep[h] = (s_al[h * 128 + 2 * l] | s_al[h * 128 + 2 * l + 1]) != 0;
 #pragma unroll
   for (int js = 0; js < 2; ++js) {
     const int j = 2 * w + js;
@@ -435,7 +442,7 @@ __device__ __forceinline__ void store_tile_lds4(const ArtBundleView& v, const in
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int s0 = h * 128 + 2 * l;
-      st_2f64(rs, (unsigned)(tile0 + s0) * 8u, s_out[j][s0], s_out[j][s0 + 1]);
+      st_2f64(rs, keep[h] ? (unsigned)(tile0 + s0) * 8u : kDropOffset, s_out[j][s0], s_out[j][s0 + 1]);
     }
   }
   __syncthreads();
@@ -458,11 +465,15 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
     __syncthreads();
   }
 #endif
-#ifdef ART_STORE_LDS4
-  __shared__ __attribute__((aligned(16))) double s_out[8][kBlock];
-#endif
   __shared__ double s_w[kBlock];   // per-lane parking slot (no barrier: a lane only reads what it wrote)
-  __shared__ double s_red[(kBlock / 64) * 8 * kTileStride];   // wave-private tiles of wave_reduce24 (18 KiB)
+  __shared__ __attribute__((aligned(16))) double s_red[(kBlock / 64) * 8 * kTileStride];   // wave-private tiles of wave_reduce24 (18 KiB)
+#ifndef ART_STORE_DIRECT
+  // the staging tile of the 16-byte stores shares the tail's reduction tiles: the tail runs behind the last element's
+  // closing barrier
+  double (*s_out)[kBlock] = reinterpret_cast<double (*)[kBlock]>(s_red);
+  static_assert(sizeof(double) * 8 * kBlock <= sizeof(double) * (kBlock / 64) * 8 * kTileStride, "staging tile fits");
+  __shared__ uint8_t s_al[kBlock];
+#endif
   const int64_t tile = tile_of(blockIdx.x, gridDim.x, xmap);
   const BundleRsrc bi = make_rsrc(a.in, n, first);
   const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -502,8 +513,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
       if (ok) ok = art::trace_ray_dyn<DEFECT>(a.e[k], a.e[k].zern, r);
 #endif
 #endif
-#ifdef ART_STORE_LDS4
-      store_tile_lds4(a.out[k], n, first, tile * kBlock, r, ok, s_out);
+#ifndef ART_STORE_DIRECT
+      store_tile_lds4(a.out[k], n, first, (int64_t)(slot - lane), lane, r, ok, s_out, s_al);
 #else
       // no history view for this element -> zero-length descriptors: every store is dropped by the range check
       store_slot(make_rsrc(a.out[k], a.out[k].alive != nullptr ? n : 0, first), i, r, ok);

@@ -149,7 +149,9 @@ int art_trace_element(const ArtElementDesc* e, const ArtBundleView* in, const Ar
 
 /* Whole chain in ONE launch: the ray stays in registers from element to element.  outs[k] receives the
  * bundle after element k for every k with outs[k].alive != NULL (pass zeroed views to skip history);
- * outs[n_elems-1] is mandatory.  Same results as n_elems calls of art_trace_element.                   */
+ * outs[n_elems-1] is mandatory.  Same results as n_elems calls of art_trace_element for every slot that is alive in
+ * the respective bundle; the other outputs of a DEAD slot are unspecified (untouched, or the ray's last live state:
+ * the fused kernels store pairs of neighbouring slots with one 16-byte access).                          */
 int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundleView* in,
                     const ArtBundleView* outs, int64_t n, void* stream);
 

@@ -53,9 +53,6 @@ def test_fused_chain_kernel_occupancy(kernels):
         assert k["vgpr"] <= 96, (name, k["vgpr"])        # 5 waves per SIMD
         assert k["scratch"] == 0, (name, k["scratch"])    # a scratch reload is a VMEM load behind the stores
         assert k["lds"] <= 32 * 1024, (name, k["lds"])    # 5 workgroups per CU fit 160 KiB
-    for name in ("k_trace_chain<false, 6>", "k_trace_scene<false, 6>"):   # the ART_CHAIN_WAVES=6 alternative
-        k = kernels[name]
-        assert k["vgpr"] <= 80 and k["scratch"] == 0, (name, k["vgpr"], k["scratch"])
     for name in ("k_trace_chain<true, 4>", "k_trace_scene<true, 4>"):
         k = kernels[name]
         assert k["vgpr"] <= 128, (name, k["vgpr"])
@@ -65,11 +62,12 @@ def test_fused_chain_kernel_occupancy(kernels):
 
 
 def test_no_wait_for_store_acknowledgements(kernels):
-    for name in ("k_trace_chain<false, 5>", "k_trace_chain<false, 6>", "k_trace_scene<false, 5>", "k_trace_scene<false, 6>"):
+    for name in ("k_trace_chain<false, 5>", "k_trace_scene<false, 5>"):
         waits = _after_first_store(kernels[name]["code"], r"s_waitcnt.*vmcnt")
         assert not waits, (name, waits[:5])
-        # nothing that needs such a wait either: loads of any kind, barriers
-        late = _after_first_store(kernels[name]["code"], r"\b(buffer_load|global_load|flat_load|scratch_load|s_barrier)\b")
+        # nothing that needs such a wait either: loads of any kind.  (The 16-byte store path has two s_barrier per
+        # element; they order LDS only -- the check above proves that no vmcnt wait comes with them.)
+        late = _after_first_store(kernels[name]["code"], r"\b(buffer_load|global_load|flat_load|scratch_load)\b")
         assert not late, (name, late[:5])
 
 
