@@ -1220,10 +1220,10 @@ inline int64_t readout_block_cap(int64_t launches) {
   const int64_t room = (int64_t)8 * kReadoutBlocks / (launches < 1 ? 1 : launches);
   return (env > 0) ? (env < room ? env : room) : (kReadoutBlocks < room ? kReadoutBlocks : room);
 }
-// register budget of the fused kernel in waves per SIMD: 5 (85 VGPRs).  The 6-wave build (80 VGPRs, no spills either
-// since the lane id is derived from the slot register) is kept as ART_CHAIN_WAVES=6: measured on one box
-// (tools/r02_exp16.sh) it traces relay4 3 % faster without the read-out tail, the same with it, C2 1 % faster and the
-// 8-element C4 chain 13 % slower.
+// register budget of the fused kernel in waves per SIMD: 5 (91 VGPRs with the LDS store path).  A 6-wave build (80
+// VGPRs) is kept as ART_CHAIN_WAVES=6 for experiments: with 8-byte stores it fitted without spills and measured 3 %
+// faster on relay4 without the read-out tail, the same with it, C2 +1 %, C4 13 % slower (tools/r02_exp16.sh); with the
+// LDS store path it spills 5 dwords.
 inline int chain_waves() {
   const char* wv = getenv("ART_CHAIN_WAVES");
   return wv ? atoi(wv) : 5;
