@@ -15,6 +15,12 @@
 #include "art_device.h"
 #include "art_scene.h"
 
+// The -DART_ZERN_LDS comparison build keeps a persistent grid whose last pass may leave part of a workgroup idle: no
+// workgroup barriers there, i.e. the 8-byte store path.
+#if defined(ART_ZERN_LDS) && !defined(ART_STORE_DIRECT)
+#define ART_STORE_DIRECT 1
+#endif
+
 namespace {
 
 constexpr int kBlock = 256;          // 4 waves per workgroup
