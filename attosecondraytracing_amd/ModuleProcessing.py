@@ -290,9 +290,9 @@ def RayTracingCalculationMany(source_rays_list, optical_elements_list, IgnoreDef
             d._iscomplete()
             ros.append(be.new_chain_readout(d._desc(), s_.intensity, n, scratch=area))
     host, dev = be.scene_alloc(c, m, transient=True)
-    flags = be.scene_pack(descs, [s.view() for s in sources], views, c, m, host, ros)
+    be.scene_pack(descs, [s.view() for s in sources], views, c, m, host, ros)
     be.scene_upload(host, dev)
-    be.trace_scene(dev, c, m, flags, n)
+    be.trace_scene(dev, host, n)
     for ci, outs in enumerate(grid):
         outs[-1]._keepalive = (keep, scratch)
         if ros is not None:

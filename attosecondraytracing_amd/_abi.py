@@ -1,7 +1,7 @@
 """ctypes mirror of include/art_hip.h (structs, enums, prototypes).  Keep in sync with ART_ABI_VERSION."""
 import ctypes as C
 
-ART_ABI_VERSION = 8
+ART_ABI_VERSION = 9
 
 ART_OK = 0
 ART_ERR_BAD_ARG = -1
@@ -93,7 +93,7 @@ PROTOTYPES = {
                                           C.POINTER(ArtBundleView), C.POINTER(ArtChainReadout), C.c_int64, C.c_void_p]),
     "art_scene_pack": (C.c_int, [C.POINTER(ArtElementDesc), C.c_int32, C.c_int32, C.POINTER(ArtBundleView),
                                  C.POINTER(ArtBundleView), C.POINTER(ArtChainReadout), C.c_void_p]),
-    "art_trace_scene": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
+    "art_trace_scene": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "art_pack_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(ArtBundleView), C.c_void_p]),
     "art_transform_bundle": (C.c_int, [c_double_p, c_double_p, C.c_int32, C.POINTER(ArtBundleView),
                                        C.POINTER(ArtBundleView), C.c_int64, C.c_void_p]),
@@ -123,6 +123,9 @@ PROTOTYPES = {
                                           C.c_int64, C.POINTER(ArtBundleView), C.c_void_p]),
     "art_exchange_pack": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_void_p, C.c_void_p]),
     "art_exchange_fold": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+    "art_survivor_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
+    "art_pack_survivors": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 4 + [C.c_int64, C.c_int64, C.c_void_p,
+                                                                                    C.c_void_p, C.c_int64, C.c_void_p]),
     "art_make_extended_source": (C.c_int, [C.c_double, C.c_double, C.c_int64, C.c_int64, c_double_p, c_double_p,
                                            C.c_int64, C.c_int64, C.POINTER(ArtBundleView), C.c_void_p]),
 }

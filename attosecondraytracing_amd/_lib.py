@@ -183,9 +183,11 @@ class HipBackend:
         self._scene_uploads[host_image.data_ptr()] = ev
         return ev
 
-    def trace_scene(self, dev_image, n_chains, n_elems, flags, n):
+    def trace_scene(self, dev_image, host_image, n):
+        """ONE launch (per 8 elements) for every chain of a packed scene; counts and flags come from the host image's
+        header (art_scene_pack), of which dev_image is the uploaded copy."""
         sp = self.stream_ptr()
-        self.check(self._timed(lambda: self.fn["art_trace_scene"](dev_image.data_ptr(), n_chains, n_elems, flags, n, sp)),
+        self.check(self._timed(lambda: self.fn["art_trace_scene"](dev_image.data_ptr(), host_image.data_ptr(), n, sp)),
                    "art_trace_scene")
 
     def pack_rays(self, points, vectors, path0, n, view):
@@ -313,6 +315,19 @@ class HipBackend:
         """Fold `world` gathered statistics vectors into the global 24 (art_exchange_fold)."""
         self.check(self.fn["art_exchange_fold"](recv.data_ptr(), int(world), int(stride), out.data_ptr(),
                                                 self.stream_ptr()), "art_exchange_fold")
+
+    def survivor_bytes(self, count, dense=False):
+        return int(self.fn["art_survivor_bytes"](int(count), 1 if dense else 0))
+
+    def pack_survivors(self, alive, X, Y, opl, number, first, step, send):
+        """Records (X, Y, path, number:int32) of the alive slots, in slot order, behind a (count, flags) header in
+        the uint8 tensor `send` (art_pack_survivors); nothing returns to the host."""
+        n = int(alive.numel())
+        sc = self.scratch("compact", self.fn["art_compact_scratch_ints"](n), torch.int32)
+        ptr = lambda t: None if (t is None or n == 0) else t.data_ptr()
+        self.check(self.fn["art_pack_survivors"](ptr(alive), n, ptr(X), ptr(Y), ptr(opl), ptr(number), int(first),
+                                                 int(step), sc.data_ptr(), send.data_ptr(), int(send.numel()),
+                                                 self.stream_ptr()), "art_pack_survivors")
 
     def make_extended_source(self, radius, divergence, n_points, per, rot, S, first, n, view):
         r = (C.c_double * 9)(*[float(v) for v in np.asarray(rot).reshape(9)])

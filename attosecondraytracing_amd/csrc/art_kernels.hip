@@ -112,7 +112,10 @@ typedef int v2i32 __attribute__((ext_vector_type(2)));
 #define ART_ST_AUX 2
 #endif
 constexpr int64_t kMaxRaysPerLaunchHw = (int64_t)1 << 28;  // 2^28 rays * 8 B = 2 GiB per stream
-constexpr unsigned kDropOffset = 0xFFFFFFFFu;
+// Offset of a store that must be dropped by the range check: 2^31.  num_records never exceeds 2^31 (2^28 rays x 8 B), so
+// it is out of range for every descriptor; it is 16-byte aligned, and the component offsets of a 16-byte store (+4, +8,
+// +12) cannot wrap around 2^32 into the first slots of the stream (0xFFFFFFFF, used before, relied on that not happening).
+constexpr unsigned kDropOffset = 0x80000000u;
 
 struct BundleRsrc {
   __amdgpu_buffer_rsrc_t ox, oy, oz, dx, dy, dz, path, inc, alive;
@@ -261,11 +264,16 @@ __device__ __forceinline__ void wave_reduce24(const double (&acc)[kReadoutSlots]
   const int stat = l >> 3, part = l & 7;   // l = lane of the wave
 #pragma unroll
   for (int pass = 0; pass < 3; ++pass) {
+    // The lanes exchange data through the tile: wave-level barriers (no instruction, a scheduling fence for the compiler)
+    // keep the stores of a pass in front of its row loads and the row loads in front of the next pass's stores.  The
+    // hardware executes a wave's LDS operations in order; this pins the compiler to the same order.
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int g = kPassSlot[pass][j];
       tile[j * kTileStride + l] = (g >= kReadoutSlots) ? INFINITY : ((pass == 2 && j >= 3) ? -acc[g] : acc[g]);
     }
+    __builtin_amdgcn_wave_barrier();
     const double* row = tile + stat * kTileStride + part;
     double v = row[0];
     if (pass < 2) {
@@ -1049,6 +1057,59 @@ __global__ __launch_bounds__(kBlock) void k_compact_scatter(const uint8_t* alive
   }
 }
 
+// ------------------------------------------------------------------------------------------- survivor records
+// Send buffer of the multi-GPU gather (art_pack_survivors, include/art_hip.h): a 16-byte header (count, flags) followed
+// by the sections X[count], Y[count], path[count] (fp64) and number[count] (int32) of the SURVIVING rays in slot order.
+// Pass 1 + 2 are the compaction's (per-tile counts, one-workgroup scan); the header is written from the scan's total,
+// and pass 3 scatters the records instead of slot indices.
+constexpr int64_t kSurvHeader = 16;
+constexpr int64_t kSurvDense = 1;   // header flag: every slot alive and numbers implicit -> no number section
+
+__global__ void k_survivor_header(const int64_t* total, const int64_t n, const int implicit_numbers, int64_t* header) {
+  if (threadIdx.x == 0) {
+    header[0] = *total;
+    header[1] = (implicit_numbers && *total == n) ? kSurvDense : 0;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_survivor_scatter(const uint8_t* alive, const int64_t n,
+                                                             const int64_t* tile_offsets, const double* X,
+                                                             const double* Y, const double* opl, const int64_t* number,
+                                                             const int64_t first, const int64_t step,
+                                                             unsigned char* send) {
+  __shared__ int s_wave[kBlock / 64];
+  const int64_t* header = reinterpret_cast<const int64_t*>(send);
+  const int64_t count = header[0];
+  const bool dense = (header[1] & kSurvDense) != 0;
+  double* sx = reinterpret_cast<double*>(send + kSurvHeader);
+  double* sy = sx + count;
+  double* so = sy + count;
+  int32_t* sn = reinterpret_cast<int32_t*>(so + count);
+  const int64_t base = (int64_t)blockIdx.x * kTile;
+  int64_t run = tile_offsets[blockIdx.x];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int j = 0; j < kTile / kBlock; ++j) {
+    const int64_t i = base + j * kBlock + threadIdx.x;
+    const bool a = (i < n) && alive[i] != 0;
+    const unsigned long long m = __ballot(a);
+    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wv] = __popcll(m);
+    __syncthreads();
+    int before = 0, tot = 0;
+    for (int k = 0; k < kBlock / 64; ++k) {
+      if (k < wv) before += s_wave[k];
+      tot += s_wave[k];
+    }
+    if (a) {
+      const int64_t p = run + before + rank;
+      sx[p] = X[i]; sy[p] = Y[i]; so[p] = opl[i];
+      if (!dense) sn[p] = (int32_t)(number ? number[i] : first + i * step);
+    }
+    run += tot;
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------------- sources
 __global__ __launch_bounds__(kBlock) void k_make_source(const int32_t kind, const double size, const ArtDetectorDesc rs,
                                                         const int64_t first, const int64_t step, const int64_t n,
@@ -1363,9 +1424,18 @@ int art_scene_pack(const ArtElementDesc* elems, int32_t n_chains, int32_t n_elem
   return rc;
 }
 
-int art_trace_scene(const void* image_dev, int32_t n_chains, int32_t n_elems, int32_t flags, int64_t n, void* stream) {
-  if (!image_dev) return fail(ART_ERR_BAD_ARG, "scene image is NULL");
-  if (n_chains <= 0 || n_chains > 65535 || n_elems <= 0) return fail(ART_ERR_BAD_ARG, "bad chain or element count");
+int art_trace_scene(const void* image_dev, const void* image_host, int64_t n, void* stream) {
+  if (!image_dev || !image_host) return fail(ART_ERR_BAD_ARG, "scene image is NULL");
+  // Counts and flags are read from the header art_scene_pack wrote, not taken from the caller: a read-out bit without
+  // read-out descriptors in the table would make the tail dereference NULL on the device, a wrong defect bit select the
+  // wrong kernel body.
+  art::SceneHeader h;
+  memcpy(&h, image_host, sizeof(h));
+  if (h.magic != art::kSceneMagic) return fail(ART_ERR_BAD_ARG, "host image was not written by art_scene_pack");
+  const int32_t n_chains = h.n_chains, n_elems = h.n_elems, flags = h.flags;
+  if (n_chains <= 0 || n_chains > 65535 || n_elems <= 0 || h.n_segments != art::scene_segments(n_elems) ||
+      (flags & ~(art::kFlagDefects | art::kFlagReadout)))
+    return fail(ART_ERR_BAD_ARG, "scene header is corrupt");
   if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
 #ifdef ART_ZERN_LDS
   if (flags & 1) return fail(ART_ERR_UNSUPPORTED, "ART_ZERN_LDS build: scenes with defects go through art_trace_chain");
@@ -1622,6 +1692,42 @@ int art_compact(const uint8_t* alive, int64_t n, int32_t* block_counts, int64_t*
   hipLaunchKernelGGL(k_compact_scatter, dim3((unsigned)tiles), dim3(kBlock), 0, s, alive, n, offsets, idx_out);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_compact launch");
+  return ART_OK;
+}
+
+int64_t art_survivor_bytes(int64_t count, int32_t dense) {
+  if (count < 0) count = 0;
+  const int64_t b = kSurvHeader + count * (dense ? 24 : 28);
+  return (b + 15) / 16 * 16;
+}
+
+int art_pack_survivors(const uint8_t* alive, int64_t n, const double* X, const double* Y, const double* opl,
+                       const int64_t* number, int64_t first, int64_t step, int32_t* scratch_ints, void* send,
+                       int64_t send_bytes, void* stream) {
+  if (!scratch_ints || !send) return fail(ART_ERR_BAD_ARG, "NULL argument");
+  if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
+  if (send_bytes < art_survivor_bytes(n, 0)) return fail(ART_ERR_BAD_ARG, "send buffer smaller than art_survivor_bytes(n, 0)");
+  if (((uintptr_t)send & 7u) != 0) return fail(ART_ERR_BAD_ARG, "send buffer must be 8-byte aligned");
+  if (!number && (first < 0 || step < 1 || (n > 0 && first + (n - 1) * step > INT32_MAX)))
+    return fail(ART_ERR_UNSUPPORTED, "ray numbers do not fit int32");
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    hipError_t e0 = hipMemsetAsync(send, 0, kSurvHeader, s);
+    if (e0 != hipSuccess) return fail_hip(e0, "hipMemsetAsync");
+    return ART_OK;
+  }
+  if (!alive || !X || !Y || !opl) return fail(ART_ERR_BAD_ARG, "NULL argument");
+  const int64_t tiles = (n + kTile - 1) / kTile;
+  const int64_t c = (tiles + 1) & ~1ll;
+  int64_t* offsets = reinterpret_cast<int64_t*>(scratch_ints + c);
+  int64_t* total = offsets + tiles;    // art_compact_scratch_ints() leaves two ints behind the offsets
+  hipLaunchKernelGGL(k_compact_count, dim3((unsigned)tiles), dim3(kBlock), 0, s, alive, n, scratch_ints);
+  hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, s, scratch_ints, tiles, total, offsets);
+  hipLaunchKernelGGL(k_survivor_header, dim3(1), dim3(64), 0, s, total, n, number ? 0 : 1, reinterpret_cast<int64_t*>(send));
+  hipLaunchKernelGGL(k_survivor_scatter, dim3((unsigned)tiles), dim3(kBlock), 0, s, alive, n, offsets, X, Y, opl, number,
+                     first, step, reinterpret_cast<unsigned char*>(send));
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail_hip(err, "art_pack_survivors launch");
   return ART_OK;
 }
 

@@ -167,7 +167,7 @@ class SceneProgram:
                 self._mp._attach_readout(outs[-1], self.detectors[ci], 0.0, self.readouts[ci])
 
     def _launch(self):
-        self.be.trace_scene(self.dev, self.c, self.m, self.flags, self.n)
+        self.be.trace_scene(self.dev, self.host, self.n)
         self._mark()
         if self.post is not None:
             self.post_result = self.post(self.outputs)

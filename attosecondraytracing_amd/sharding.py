@@ -249,3 +249,88 @@ class ReadoutGather:
             return None, None
         parts = [self._split(t) for t in self.recv[b]]
         return torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts])
+
+
+class SurvivorGather:
+    """The gather of SURVEY.md 8(e) as written: `(number:int32, X, Y, path)` = 28 B per SURVIVING ray from every shard to
+    rank `dst` in ONE collective (the consumer, ART/ModuleDetector.py:254-279, sees survivors only; ReadoutGather above
+    ships all slots, dead or alive).  Per step and rank:
+      1. `art_pack_survivors` compacts the read-out of the alive slots into the rank's send buffer (header: count, flags;
+         a shard whose every slot is alive and whose numbers are the implicit first + slot * step drops the number section:
+         24 B/ray);
+      2. the 16-byte headers are all-gathered and read by the host -- the one host synchronisation of the exchange: a
+         collective's size must be known on the host, and it is the survivors' count that makes it small;
+      3. ONE `gather` of max_r art_survivor_bytes(count_r) bytes per rank, asynchronous on the communicator's stream.
+    `buffers` independent sets let the gather of step i overlap the tracing of step i + 1 (start / drain / result as in
+    ReadoutGather).  `result(b)` -> per-rank list of (number int64, X, Y, path) views on dst; `assemble(b)` -> the four
+    arrays of the whole job in global ray order."""
+
+    def __init__(self, backend, n, world, rank, dst=0, buffers=2, specs=None):
+        self.be, self.n, self.world, self.rank, self.dst = backend, int(n), int(world), int(rank), int(dst)
+        # (first, step, n) of every rank's shard: for the implicit numbers of dense shards on the root
+        self.specs = specs if specs is not None else [(0, 1, self.n)] * self.world
+        dev = backend.device
+        self.cap = backend.survivor_bytes(max(s[2] for s in self.specs) if specs is not None else self.n, False)
+        self.send = [torch.empty(self.cap, dtype=torch.uint8, device=dev) for _ in range(buffers)]
+        self.recv = [[torch.empty(self.cap, dtype=torch.uint8, device=dev) for _ in range(self.world)]
+                     if self.rank == self.dst else None for _ in range(buffers)]
+        self.hdr = [torch.zeros((self.world, 2), dtype=torch.int64, device=dev) for _ in range(buffers)]
+        self.headers = [None] * buffers       # host copies: [[count, flags]] per rank
+        self.nbytes = [0] * buffers           # size of the collective issued on set b
+        self.work = [None] * buffers
+
+    def start(self, b, X, Y, opl, alive, number=None):
+        if self.work[b] is not None:
+            self.work[b].wait()
+            self.work[b] = None
+        first, step, _ = self.specs[self.rank]
+        self.be.pack_survivors(alive, X, Y, opl, number, first, step, self.send[b])
+        mine = self.send[b][:16].view(torch.int64)
+        if dist.is_available() and dist.is_initialized():
+            dist.all_gather_into_tensor(self.hdr[b].view(-1), mine)
+        else:
+            self.hdr[b][0].copy_(mine)
+        self.headers[b] = self.hdr[b].cpu().tolist()            # host sync: the collective's size
+        self.nbytes[b] = max(self.be.survivor_bytes(c, bool(f & 1)) for c, f in self.headers[b])
+        nb = self.nbytes[b]
+        if dist.is_available() and dist.is_initialized():
+            recv = None if self.recv[b] is None else [t[:nb] for t in self.recv[b]]
+            self.work[b] = dist.gather(self.send[b][:nb], recv, dst=self.dst, async_op=True)     # ONE collective
+        elif self.recv[b] is not None:
+            self.recv[b][0][:nb].copy_(self.send[b][:nb])
+        return nb
+
+    def drain(self):
+        for b, w in enumerate(self.work):
+            if w is not None:
+                w.wait()
+                self.work[b] = None
+
+    def result(self, b):
+        """On dst: [(number int64 [c], X [c], Y [c], path [c])] per rank (views of receive set b; the numbers of a dense
+        shard are generated).  None elsewhere."""
+        if self.recv[b] is None:
+            return None
+        out = []
+        for r, buf in enumerate(self.recv[b]):
+            c, flags = self.headers[b][r]
+            f64 = buf[16:16 + 24 * c].view(torch.float64).view(3, c)
+            if flags & 1:
+                first, step, _ = self.specs[r]
+                num = first + step * torch.arange(c, dtype=torch.int64, device=buf.device)
+            else:
+                num = buf[16 + 24 * c:16 + 28 * c].view(torch.int32).to(torch.int64)
+            out.append((num, f64[0], f64[1], f64[2]))
+        return out
+
+    def assemble(self, b):
+        """On dst: (number, X, Y, path) of all survivors of the job in global ray order (rank order for contiguous
+        shards; merged by ray number for strided ones)."""
+        parts = self.result(b)
+        if parts is None:
+            return None
+        num, X, Y, P = (torch.cat([p[k] for p in parts]) for k in range(4))
+        if any(s[1] != 1 for s in self.specs):
+            order = torch.argsort(num, stable=True)
+            num, X, Y, P = num[order], X[order], Y[order], P[order]
+        return num, X, Y, P

@@ -19,8 +19,9 @@ A step = one pass of the hot path over resident bundles:
     N > 1:  + ONE RCCL all-gather per step carrying every shard's 24 statistics and an evenly spaced 20000-ray sample of
             the read-out (the delays are relative to the GLOBAL mean path, ART/ModuleDetector.py:277; the plots draw a
             sample) -- this is `value`;
-            and, measured in a second timed region of the same K steps, the same step + ONE RCCL gather of every ray's
-            read-out (X, Y, optical path, alive: 25 B/ray, the gather BASELINE.json's north_star names) to rank 0 in
+            and, measured in a second timed region of the same K steps, the same step + ONE RCCL gather of every
+            SURVIVING ray's read-out (number:int32, X, Y, optical path: 28 B per survivor, SURVEY.md 8e -- the gather
+            BASELINE.json's north_star names; 24 B where a shard lost nothing and its numbers are implicit) to rank 0 in
             every step, double-buffered behind the next step's tracing -- this is `value_full_gather`.
 Inputs are resident in HBM before the timed region; nothing is copied to the host inside a step.  N > 1 is weak scaling:
 every rank traces its own shard (index range of an N x rays source), no collective on the tracing path.
@@ -71,6 +72,12 @@ def launch_workers(n, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         out = subprocess.PIPE if r == 0 else sys.stderr
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
+    # rank 0's stdout is drained while the workers run (a reader thread): a rank 0 that printed more than the pipe holds
+    # would otherwise block in write() while this loop waits for it to exit
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     # watch all workers: if one dies, the others would sit in a collective until RCCL's own timeout -- end them at once
     failed = False
     while any(p.poll() is None for p in procs):
@@ -83,8 +90,9 @@ def launch_workers(n, argv):
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    line = procs[0].stdout.read() if procs[0].stdout else b""     # one JSON line: far below the pipe's capacity
     rcs = [p.wait() for p in procs]
+    reader.join(timeout=10.0)
+    line = b"".join(chunks)
     sys.stdout.write(line.decode(errors="replace"))
     sys.stdout.flush()
     if any(rc != 0 for rc in rcs):
@@ -481,8 +489,9 @@ def worker(args):
     # ------------------------------------------------------------------ N > 1 exchanges
     exchange = sharding.Exchange(be, n, sample=20000) if use_dist else None
     sample_k = exchange.k if exchange else 0
-    gather = sharding.ReadoutGather(n, world, rank, be.device, dst=0, buffers=2) if use_dist else None
-    state = {"stats": None, "sample": None, "step": 0, "xstep": 0}
+    specs = [sharding.shard_spec(n_total, rk, world, args.shard) for rk in range(world)]
+    gather = sharding.SurvivorGather(be, n, world, rank, dst=0, buffers=2, specs=specs) if use_dist else None
+    state = {"stats": None, "sample": None, "step": 0, "xstep": 0, "gather_bytes": 0}
 
     def exchange_drain():
         # fold the exchange that is still in flight (the last step's) and start the numbering afresh
@@ -504,7 +513,7 @@ def worker(args):
             state["xstep"] += 1
             if full_gather:
                 # + ONE gather of every ray's read-out to rank 0, overlapped with the next step's tracing
-                gather.start(state["step"] % 2, r[-1]["X"], r[-1]["Y"], r[-1]["opl"], o[-1][-1].alive)
+                state["gather_bytes"] = gather.start(state["step"] % 2, r[-1]["X"], r[-1]["Y"], r[-1]["opl"], o[-1][-1].alive)
                 state["step"] += 1
         return o, r
 
@@ -545,11 +554,17 @@ def worker(args):
     if use_dist:
         dt_full, _, o, r = timed(True, args.steps)
         if rank == 0:
-            XYO, alv = gather.result((state["step"] - 1) % 2)
-            assert XYO.shape == (world, 3, n) and int(alv.sum().item()) > 0
-            # rank 0's own shard arrived bit for bit (compared as integers: the slots of dead rays hold whatever was
-            # in the freshly allocated arrays, NaNs included)
-            assert torch.equal(XYO[0].view(torch.int64), torch.stack([r[-1]["X"], r[-1]["Y"], r[-1]["opl"]]).view(torch.int64))
+            b_last = (state["step"] - 1) % 2
+            parts = gather.result(b_last)
+            gathered_counts = [c for c, _ in gather.headers[b_last]]
+            assert len(parts) == world and sum(gathered_counts) == surv_last_job, (gathered_counts, surv_last_job)
+            # rank 0's own shard arrived bit for bit: the records of its survivors, in slot order, numbers included
+            idx0 = o[-1][-1].index()
+            mine = torch.stack([r[-1]["X"], r[-1]["Y"], r[-1]["opl"]]).index_select(1, idx0)
+            assert torch.equal(torch.stack(parts[0][1:]).view(torch.int64), mine.view(torch.int64))
+            assert torch.equal(parts[0][0], specs[0][0] + specs[0][1] * idx0)
+            num_all = gather.assemble(b_last)[0]
+            assert bool((num_all[1:] > num_all[:-1]).all()) and int(num_all[-1]) < n_total     # global ray order, each ray once
             S = state["sample"]
             assert S.shape == (world, sample_k, 4)
             own = torch.stack([r[-1]["X"], r[-1]["Y"], r[-1]["opl"]]).index_select(1, exchange.slots).T
@@ -611,8 +626,12 @@ def worker(args):
                                + (f" + ONE RCCL all-gather of every shard's 24 statistics and a {sample_k * world}-ray sample "
                                   f"of the read-out, folded on the device" if use_dist else ""),
                        "step_full_gather": None if not use_dist else
-                       "the same + ONE RCCL gather of every ray's read-out (X, Y, optical path, alive; 25 B/ray) to rank 0 in "
-                       "every step, double-buffered behind the next step's tracing (value_full_gather)"},
+                       "the same + ONE RCCL gather of every SURVIVING ray's read-out (number:int32, X, Y, optical path; 28 B "
+                       "per survivor, 24 B in shards that lost nothing) to rank 0 in every step, double-buffered behind the "
+                       "next step's tracing (value_full_gather)",
+                       "gather_bytes_per_rank": None if not use_dist else state["gather_bytes"],
+                       "gather_survivors": None if not use_dist else surv_last_job,
+                       "dist_backend": None if not use_dist else dist.get_backend()},
             "value_sustained": None if dt_sus is None else inter_per_step_job * args.steps / dt_sus,
             "ms_per_step_sustained": None if dt_sus is None else dt_sus / args.steps * 1e3,
             "sustained_note": None if dt_sus is None else
@@ -681,9 +700,14 @@ def worker(args):
                     "achieved_algorithmic": algo_ro, "frac_algorithmic": algo_ro / HBM_PEAK_GBS,
                     "algorithmic_bytes_per_ray": ALGO_BYTES_READOUT, "kernel_ms": readout_ms, "launches_per_step": n_chains}
             res["trace_only_intersections_per_s"] = inter_per_step_rank / (kernel_ms * launches * 1e-3)
-        if world == 1 and args.cpu_sample > 0 and on_gpu:
-            v, inter, secs, oracle_result = cpu_baseline(element_lists[-1], src_kind, det_dist, args.cpu_sample, ignore_defects)
+        if args.cpu_sample > 0 and on_gpu:
+            # N = 1: the CPU baseline (the oracle timed on a bounded sample) and the parity of that sample.  N > 1: the
+            # baseline is an N = 1 figure, but `parity` stays on the line -- rank 0 traces a smaller oracle sample on its
+            # own device after the timed regions (no collective involved; the other ranks are done)
+            n_cpu = args.cpu_sample if world == 1 else min(args.cpu_sample, 200_000)
+            v, inter, secs, oracle_result = cpu_baseline(element_lists[-1], src_kind, det_dist, n_cpu, ignore_defects)
             res["parity"] = parity_against(oracle_result, element_lists[-1], be, mode, ignore_defects)
+        if world == 1 and args.cpu_sample > 0 and on_gpu:
             res["cpu_baseline"] = {"value": v, "unit": "intersections/s", "cores": 1, "kind": "port",
                                    "sample": f"oracle/art_oracle.py (NumPy, batched LAPACK eigvals; single thread) on "
                                              f"{args.cpu_sample} rays x {n_elems} elements of one chain + detector = {inter} "

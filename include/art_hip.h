@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ART_ABI_VERSION 8
+#define ART_ABI_VERSION 9
 
 /* error codes */
 #define ART_OK 0
@@ -186,17 +186,22 @@ int art_trace_chain_readout(const ArtElementDesc* elems, int32_t n_elems, const 
  *                                              art_trace_chain: outs[..].alive == NULL skips that history bundle, the
  *                                              last view of a chain and every 8th are mandatory); readouts = NULL or
  *                                              one ArtChainReadout per chain (fused read-out of each chain's last
- *                                              bundle, see art_trace_chain_readout).  Returns flags >= 0 to pass on
- *                                              to art_trace_scene, or a negative error code;
+ *                                              bundle, see art_trace_chain_readout).  Returns the scene's flags >= 0
+ *                                              (bit 0: defects, bit 1: read-outs; informational -- they are also in
+ *                                              the image's header), or a negative error code;
  *   3. the caller copies the image to DEVICE memory (its own allocation and memcpy);
- *   4. art_trace_scene(image_dev, ...)         ONE kernel launch per 8 elements: grid.y = chain, grid.x = 256-ray tile.
+ *   4. art_trace_scene(image_dev, image_host, n, stream)
+ *                                              ONE kernel launch per 8 elements: grid.y = chain, grid.x = 256-ray tile.
+ *                                              Chain count, element count and flags are read from the header of
+ *                                              `image_host` (the packed host buffer image_dev is a copy of; it must stay
+ *                                              valid until the call returns), never taken from the caller.
  * A launch reads nothing but the device image and the bundles: re-packing new poses into the same device buffer and
  * replaying a captured HIP graph re-traces a modified scene without host-side launch work.  Same per-ray results as
  * art_trace_chain, bit for bit.                                                                                      */
 int64_t art_scene_bytes(int32_t n_chains, int32_t n_elems);
 int art_scene_pack(const ArtElementDesc* elems, int32_t n_chains, int32_t n_elems, const ArtBundleView* ins,
                    const ArtBundleView* outs, const ArtChainReadout* readouts, void* image_host);
-int art_trace_scene(const void* image_dev, int32_t n_chains, int32_t n_elems, int32_t flags, int64_t n, void* stream);
+int art_trace_scene(const void* image_dev, const void* image_host, int64_t n, void* stream);
 
 /* Bundle from array-of-structs input (the layout a caller holding ART Ray lists / (n,3) NumPy arrays has):
  * points[n][3], vectors[n][3] (DEVICE, row-major) -> SoA view; directions normalised like the Ray.vector setter
@@ -316,6 +321,22 @@ int art_make_extended_source(double radius, double divergence, int64_t n_points,
 int art_exchange_pack(const double* stats24, const double* X, const double* Y, const double* opl,
                       const uint8_t* alive, const int64_t* slots, int64_t k, double* send, void* stream);
 int art_exchange_fold(const double* recv, int32_t world, int64_t stride_doubles, double* stats_out24, void* stream);
+
+/* Survivor records for the ONE gather of a sharded run (`(number:int32, X, Y, path)` = 28 B per SURVIVING
+ * ray; the consumer, ART/ModuleDetector.py:254-279, sees survivors only).  Compacts the read-out of the alive slots, in
+ * slot order, into `send` (DEVICE, 8-byte aligned, capacity send_bytes >= art_survivor_bytes(n, 0)):
+ *   [0, 8)   int64 count                     number of alive slots
+ *   [8, 16)  int64 flags                     bit 0 "dense": every slot is alive and the numbers are implicit -> the number
+ *                                            section is absent (24 B per ray)
+ *   [16 ...) double X[count], Y[count], path[count], then int32 number[count] (absent when dense)
+ * number[j] = number ? number[slot_j] : first + slot_j * step (the global index of a shard generated by
+ * art_make_source / art_make_source_strided; must fit int32, ART_ERR_UNSUPPORTED otherwise).  A rank sends the first
+ * art_survivor_bytes(count, dense) bytes; the header tells the receiver how to read them.  scratch_ints: DEVICE,
+ * art_compact_scratch_ints(n) int32.  Everything is enqueued on `stream`; nothing returns to the host.                  */
+int64_t art_survivor_bytes(int64_t count, int32_t dense);
+int art_pack_survivors(const uint8_t* alive, int64_t n, const double* X, const double* Y, const double* opl,
+                       const int64_t* number, int64_t first, int64_t step, int32_t* scratch_ints, void* send,
+                       int64_t send_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -90,7 +90,11 @@ static void readout_tail(const ArtChainReadout& ro, const ArtBundleView& last, i
   }
 }
 
-int art_cpu_trace_scene(const void* image, int32_t n_chains, int32_t n_elems, int32_t flags, int64_t n) {
+int art_cpu_trace_scene(const void* image, const void* image_host, int64_t n) {
+  art::SceneHeader h;
+  memcpy(&h, image_host, sizeof(h));
+  if (h.magic != art::kSceneMagic) return ART_ERR_BAD_ARG;
+  const int n_chains = h.n_chains, n_elems = h.n_elems;
   const art::ChainArgs* tab = art::scene_table(image);
   const int S = art::scene_segments(n_elems);
   for (int sg = 0; sg < S; ++sg) {

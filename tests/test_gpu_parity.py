@@ -657,3 +657,39 @@ def test_gpu_batched_full_size_c2(hip):
             m = x.alive.bool()
             assert torch.equal(x.data[:, m], y.data[:, m])
         assert 0.4 < len(o[-1]) / 1e6 < 0.6          # SURVEY: C2 1e6 -> 4.9e5
+
+
+def test_gpu_dropped_store_pairs_touch_nothing(hip):
+    """The fused kernels store pairs of neighbouring slots with one 16-byte access and drop a pair of dead rays through
+    the range check of the buffer descriptor (offset 2^31).  Output arrays pre-filled with a sentinel: a pair of dead
+    slots keeps the sentinel in all eight streams, live slots -- slots 0 and 1 of every stream in particular, where a
+    wrapped-around offset would land -- equal the per-element kernel's 8-byte stores bit for bit."""
+    import torch
+    import ART.ModuleProcessing as mp
+    from attosecondraytracing_amd.bundle import RayBundle
+    import bench
+    element_lists, _, _ = bench.scene_c3()
+    els = element_lists[3]
+    n = 100_001
+    src = bench.device_source(n, 0, n, hip, ("point", 0.025))
+    ref = mp.RayTracingCalculation(src, els, mode="element")
+    descs = [mp.element_descriptor(oe, True, hip)[0] for oe in els]
+    outs = RayBundle.allocate_many(n, len(els), src, hip)
+    sentinel = torch.tensor([0x7FF8DEADBEEF0123], dtype=torch.int64, device=hip.device).view(torch.float64)
+    for b in outs:
+        b.data[:] = sentinel
+        b.alive.fill_(7)
+    hip.trace_chain(descs, src.view(), [b.view() for b in outs], n)
+    torch.cuda.synchronize()
+    lost = 0
+    for k, (b, r) in enumerate(zip(outs, ref)):
+        assert torch.equal(b.alive, r.alive)
+        live = r.alive.bool()
+        assert torch.equal(b.data[:, live].view(torch.int64), r.data[:, live].view(torch.int64))
+        assert bool(live[0]) and bool(live[1])
+        assert torch.equal(b.data[:, :2].view(torch.int64), r.data[:, :2].view(torch.int64))
+        pad = torch.cat([live, torch.zeros(n % 2, dtype=torch.bool, device=hip.device)]).view(-1, 2)
+        dead_pair = (~pad.any(dim=1)).repeat_interleave(2)[:n]
+        lost += int(dead_pair.sum())
+        assert bool((b.data[:, dead_pair].view(torch.int64) == sentinel.view(torch.int64)).all()), k
+    assert lost > 10_000        # the mask stops a third of the rays: whole pairs among them

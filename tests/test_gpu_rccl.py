@@ -1,0 +1,116 @@
+"""GPU (-m gpu): the N > 1 code path of bench.py through RCCL itself.  A test box has ONE GPU, so the process group has
+one rank (ART_FORCE_DIST=1) -- but it is a real `nccl` group on the device: init_process_group, the per-step all-gather
+(statistics + sample, pipelined), the header all-gather and the ONE gather of the survivor records, the stream ordering
+between torch's stream and the communicator's, all run as they do at N = 8; only the peers are missing.  Each run is a
+FRESH child process (never a re-exec of the pytest process).  Plus the survivor-record kernel against torch."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import report
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, **extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ART_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="VERSION")
+    env.update(extra)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]          # the contract: ONE JSON line on stdout (RCCL's banner goes to stderr)
+    return json.loads(lines[0]), p.stderr
+
+
+def _check_line(j, name):
+    c = j["config"]
+    assert j["n_gpus"] == 1 and c["world_size_seen"] == 1 and c["dist_backend"] == "nccl"
+    assert j["value"] > 0 and j["value_full_gather"] > 0 and j["ms_per_step_full_gather"] > 0
+    assert "all-gather" in c["step"] and "SURVIVING" in c["step_full_gather"]
+    # the survivor records: 28 B per surviving ray (24 B when the shard lost nothing), header included
+    s = c["gather_survivors"]
+    dense = s == c["rays_per_gpu"]
+    assert c["gather_bytes_per_rank"] == (16 + (24 if dense else 28) * s + 15) // 16 * 16
+    # parity stays on the N > 1 line
+    par = j["parity"]
+    assert par["survivor_indices_equal"] and par["delay_max_rel_err"] <= 1e-10 and par["position_max_rel_err"] <= 1e-10
+    assert par["path_max_rel_err"] <= 1e-10
+    report(f"[rccl {name}] backend {c['dist_backend']}, world {c['world_size_seen']}: step {j['ms_per_step']:.3f} ms, + survivor gather "
+           f"{j['ms_per_step_full_gather']:.3f} ms ({c['gather_bytes_per_rank']} B for {s} survivors of {c['rays_per_gpu']}); "
+           f"parity delay {par['delay_max_rel_err']:.1e} pos {par['position_max_rel_err']:.1e}")
+
+
+def test_bench_n_gt_1_path_through_rccl_relay4():
+    j, err = _bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--rays", "200000", "--cpu-sample", "20000"])
+    _check_line(j, "relay4")
+    assert j["config"]["gather_survivors"] == 200000          # every ray survives the relay: the dense form, 24 B/ray
+    assert "NCCL version" in err or "RCCL version" in err, err[-1500:]
+
+
+def test_bench_n_gt_1_path_through_rccl_c2_strided():
+    j, _ = _bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--config", "C2", "--shard", "strided", "--rays", "200000",
+                   "--cpu-sample", "20000"])
+    _check_line(j, "C2 strided")
+    c = j["config"]
+    assert c["chains"] == 11 and c["shard_layout"] == "strided"
+    assert 0.4 * c["rays_per_gpu"] < c["gather_survivors"] < 0.6 * c["rays_per_gpu"]        # the mask stops half of the rays
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    import __graft_entry__
+    from attosecondraytracing_amd import _lib
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    __graft_entry__.ensure_built()
+    _lib._BACKEND = None
+    return _lib.get_backend()
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 2048, 2049, 100_003])
+def test_gpu_survivor_records_match_torch(hip, n):
+    """art_pack_survivors against torch.nonzero + index_select: masked shards (explicit and implicit numbers), a shard
+    with every slot alive (dense, 24 B/ray), a shard with nothing alive, an empty shard."""
+    import torch
+    from attosecondraytracing_amd import sharding
+    g = torch.Generator(device="cpu").manual_seed(1234 + n)
+    X, Y, O = (torch.randn(n, dtype=torch.float64, generator=g).to(hip.device) for _ in range(3))
+    number = torch.randint(0, 2 ** 31 - 1, (n,), generator=g, dtype=torch.int64).to(hip.device)
+    for case in ("masked", "dense", "none", "numbers"):
+        if case == "masked" or case == "numbers":
+            alive = (torch.rand(n, generator=g) < 0.37).to(torch.uint8).to(hip.device)
+        elif case == "dense":
+            alive = torch.ones(n, dtype=torch.uint8, device=hip.device)
+        else:
+            alive = torch.zeros(n, dtype=torch.uint8, device=hip.device)
+        first, step = 7, 3
+        sg = sharding.SurvivorGather(hip, n, 1, 0, specs=[(first, step, n)])
+        nb = sg.start(0, X, Y, O, alive, number=number if case == "numbers" else None)
+        num, gx, gy, go = sg.result(0)[0]
+        idx = torch.nonzero(alive).reshape(-1)
+        c, flags = sg.headers[0][0]
+        assert c == idx.numel() and flags == (1 if (case != "numbers" and c == n) else 0)
+        assert nb == hip.survivor_bytes(c, bool(flags)) == (16 + (24 if flags else 28) * c + 15) // 16 * 16
+        assert torch.equal(num, number[idx] if case == "numbers" else first + step * idx)
+        for got, ref in ((gx, X), (gy, Y), (go, O)):
+            assert torch.equal(got.view(torch.int64), ref[idx].view(torch.int64))
+
+
+def test_gpu_survivor_records_refuse_numbers_beyond_int32(hip):
+    import torch
+    from attosecondraytracing_amd import _lib
+    n = 10
+    z = torch.zeros(n, dtype=torch.float64, device=hip.device)
+    alive = torch.ones(n, dtype=torch.uint8, device=hip.device)
+    send = torch.empty(hip.survivor_bytes(n), dtype=torch.uint8, device=hip.device)
+    with pytest.raises(_lib.ArtError, match="int32"):
+        hip.pack_survivors(alive, z, z, z, None, 2 ** 31 - 5, 1, send)
+    with pytest.raises(_lib.ArtError, match="smaller"):
+        hip.pack_survivors(alive, z, z, z, None, 0, 1, send[:64])

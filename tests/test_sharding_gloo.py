@@ -129,10 +129,27 @@ def _worker(rank, world, port, n_total, q):
                 off += sizes[kk]
         else:
             assert got is None and galive is None
+        # the gather of SURVEY 8(e) as written: (number:int32, X, Y, path) of the SURVIVORS only, one collective,
+        # unequal shards, two buffer sets used alternately; then a shard with every slot alive (dense: no number section)
+        specs = [sharding.shard_spec(n_total, k, world) for k in range(world)]
+        sg = sharding.SurvivorGather(_lib.get_backend(), sizes[rank], world, rank, dst=0, buffers=2, specs=specs)
+        nb = [sg.start(b, r["X"], r["Y"], r["opl"], last.alive) for b in (0, 1, 0)]
+        sg.drain()
+        counts = [c for c, _ in sg.headers[0]]
+        assert nb[0] == nb[1] == nb[2] == max((16 + (24 if f else 28) * c + 15) // 16 * 16 for c, f in sg.headers[0])
+        assert [f for _, f in sg.headers[0]] == [int(c == sz) for c, sz in zip(counts, sizes)]    # dense iff nothing was lost
+        assert sum(counts) < n_total and counts[rank] == int(last.alive.sum())
+        surv = sg.assemble(0)
+        everyone = torch.ones_like(last.alive)
+        nbd = sg.start(1, r["X"], r["Y"], r["opl"], everyone)
+        sg.drain()
+        assert [f for _, f in sg.headers[1]] == [1] * world and nbd == 16 + 24 * max(sizes) + (-24 * max(sizes)) % 16
+        dense = sg.assemble(1)
         if rank == 0:
-            q.put((stats.numpy(), XYO.numpy(), alive.numpy()))
+            assert torch.equal(dense[0], torch.arange(n_total)) and torch.equal(torch.stack(dense[1:]), XYO)
+            q.put((stats.numpy(), XYO.numpy(), alive.numpy(), [t.numpy() for t in surv]))
         else:
-            assert XYO is None and alive is None
+            assert XYO is None and alive is None and surv is None and dense is None
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -158,12 +175,15 @@ def test_two_rank_shards_match_single_process(n_total):
     procs = [ctx.Process(target=_worker, args=(rk, 2, port, n_total, q)) for rk in range(2)]
     for p in procs:
         p.start()
-    stats, XYO, alive = q.get(timeout=180)
+    stats, XYO, alive, surv = q.get(timeout=180)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert np.array_equal(alive, ref_alive)
     m = ref_alive.astype(bool)
+    # survivor-only gather == the single-process Detector read-out of the survivors, numbers included
+    assert np.array_equal(surv[0], np.nonzero(m)[0]) and surv[0].dtype == np.int64
+    assert np.array_equal(np.stack(surv[1:]), ref[:, m])
     assert 0 < m.sum() < n_total
     assert np.array_equal(XYO[:, m], ref[:, m])            # bit-exact: same per-ray code, same inputs
     assert stats[0] == ref_stats[0]
@@ -241,6 +261,16 @@ def test_strided_shards_reassemble_to_the_single_process_result():
             assert torch.equal(alive, full_alive)
             m = full_alive.bool()
             assert torch.equal(XYO[:, m], full[:, m])
+            # survivor records of every shard (art_pack_survivors' layout), merged into global ray order
+            sgs = [sharding.SurvivorGather(be, sp[2], 1, 0, specs=[sp]) for sp in specs]
+            recs = []
+            for g, p in zip(sgs, parts):
+                g.start(0, p[0][0], p[0][1], p[0][2], p[1])
+                recs.append(g.result(0)[0])
+            num = torch.cat([t[0] for t in recs])
+            order = torch.argsort(num, stable=True)
+            assert torch.equal(num[order], torch.nonzero(full_alive).reshape(-1))
+            assert torch.equal(torch.stack([torch.cat([t[k] for t in recs])[order] for k in (1, 2, 3)]), full[:, m])
             counts = [int(p[1].sum()) for p in parts]
             if layout == "strided":
                 assert max(counts) - min(counts) <= 2, counts          # balanced

@@ -146,10 +146,10 @@ class TwinBackend:
     def scene_upload(self, host_image, dev_image):
         return None
 
-    def trace_scene(self, dev_image, n_chains, n_elems, flags, n):
+    def trace_scene(self, dev_image, host_image, n):
         f = self.lib.art_cpu_trace_scene
-        f.restype, f.argtypes = C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64]
-        assert f(dev_image.data_ptr(), n_chains, n_elems, flags, n) == 0
+        f.restype, f.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]
+        assert f(dev_image.data_ptr(), host_image.data_ptr(), n) == 0
         for ro, last in (getattr(self, "_scene_ro", {}).get(dev_image.data_ptr()) or []):
             self._finish_readout(ro, last, n)
 
@@ -302,6 +302,24 @@ class TwinBackend:
         for s in (3, 5, 13):
             res[s] = allv[:, s].max()
         out.copy_(res)
+
+    @staticmethod
+    def survivor_bytes(count, dense=False):
+        return (16 + int(count) * (24 if dense else 28) + 15) // 16 * 16
+
+    def pack_survivors(self, alive, X, Y, opl, number, first, step, send):
+        """Layout of art_pack_survivors (include/art_hip.h), written with NumPy."""
+        n = int(alive.numel())
+        a = alive.numpy().astype(bool)
+        c = int(a.sum())
+        dense = number is None and c == n
+        buf = send.numpy()
+        buf[:16].view(np.int64)[:] = [c, 1 if dense else 0]
+        for k, t in enumerate((X, Y, opl)):
+            buf[16 + 8 * c * k:16 + 8 * c * (k + 1)].view(np.float64)[:] = t.numpy()[a]
+        if not dense:
+            num = number.numpy()[a] if number is not None else first + np.nonzero(a)[0] * step
+            buf[16 + 24 * c:16 + 28 * c].view(np.int32)[:] = num.astype(np.int32)
 
     def make_extended_source(self, radius, divergence, n_points, per, rot, S, first, n, view):
         r = (C.c_double * 9)(*[float(v) for v in np.asarray(rot).reshape(9)])
