@@ -141,11 +141,6 @@ def random_scene(seed, n_rays=1500):
     return scene, arrays
 
 
-def curvature_radius(e):
-    return {"sphere": e.get("R"), "cylinder": e.get("R"), "torus": e.get("r"), "parabola": e.get("p"),
-            "ellipsoid": (e.get("b", 0) ** 2 / e["a"]) if "a" in e else None}.get(e["kind"])
-
-
 GRAZING = 1.5   # rad (86 deg): beyond it the hit point is ill-conditioned (error amplified by 1/cos(incidence))
 
 
@@ -168,45 +163,90 @@ def pose_noise(e):
     return noise
 
 
-def run_differential(seeds, modes=("chain", "element"), n_rays=1500):
-    """Trace every seeded scene with the active product backend and with the oracle.  Survivor indices must agree
-    for every ray after every element; positions / directions / paths / incidence within the parity tolerances for
-    every ray that met no optic above GRAZING incidence (for tangential rays both answers lie on the surface to
-    1e-15 but apart along the ray: the reference's np.roots and the kernels' solvers are both at the conditioning
-    limit there).  Returns the worst errors and how many scenes produced hits on their last element."""
+# Local accuracy of ONE element of the product against the long-double truth (tests/truth_common.py), each element judged
+# on the product's OWN incoming rays: relative to the scene scale for positions and segment lengths, absolute for
+# directions (unit vectors) and incidence angles (rad).  The bars do NOT grow along a chain -- a 1e-11-level regression
+# of any intersector, normal or reflection fails here whatever the conditioning of the scene.
+# Measured over 6 000 random scenes on the CPU twin: pos <= 2.2e-13, segment <= 2.5e-13, dir <= 5.7e-12 (strongly curved
+# optics: a hit-point error dP turns the normal by dP / rc), incidence <= 2.4e-12.
+LOCAL_TOL = {"pos": 1e-12, "dir": 2e-11, "seg": 1e-12, "inc": 2e-11}
+STRICT_TOL = {"pos": pc.REL_TOL, "dir": pc.REL_TOL, "path": pc.REL_TOL, "inc": 1e-9}    # product vs oracle, no allowances
+
+
+def _local_truth_errors(E, prev, out, scale, ignore_defects, well):
+    """Worst errors of the product's bundle `out` (after element E) against the truth computed from its bundle `prev`."""
+    import truth_common as T
+    num = out.numbers()
+    if len(num) == 0:
+        return None
+    sel = np.searchsorted(prev["number"], num)
+    seg = out.path_segments()[:, -1]
+    P, v, t, inc = T.element_truth(E, prev["point"][sel], prev["vector"][sel], seg, ignore_defects)
+    m = well[num]
+    if not m.any():
+        return None
+    return {"pos": float(np.abs(out.points() - P)[m].max() / scale), "dir": float(np.abs(out.vectors() - v)[m].max()),
+            "seg": float(np.abs(seg - t)[m].max() / scale), "inc": float(np.abs(out.incidences() - inc)[m].max())}
+
+
+def run_differential(seeds, modes=("chain", "element"), n_rays=1500, stats=None):
+    """Trace every seeded scene with the active product backend and with the oracle.
+
+    1. Survivor indices must agree for every ray after every element.
+    2. Every element of the product is checked against the long-double truth on the product's own incoming rays
+       (LOCAL_TOL): its intersection, normal, reflection, path and incidence are accurate to ~1e-12 whatever the scene.
+    3. Product vs oracle on every ray that met no optic above GRAZING incidence (for tangential rays both answers lie on
+       the surface to 1e-15 but apart along the ray): within STRICT_TOL -- 1e-10 relative, no curvature or chain-length
+       allowance -- or else ADJUDICATED BY TRUTH: the rays are traced through the whole chain in long double from the
+       source, and the product must be at least as close to that truth as the oracle (the reference's algorithm) is,
+       or within the bar itself.  Ill-conditioned chains (a direction difference d arriving at a curved optic after a
+       flight of L leaves as d (1 + 2 L / rc)) amplify BOTH implementations' rounding; what is asserted is that the
+       product's is not the larger one.
+    `stats` (optional dict) receives counters: scenes, adjudicated, the worst local errors, the worst adjudicated pair.
+    Returns the worst product-vs-oracle differences and how many scenes produced hits on their last element."""
     import ART.ModuleProcessing as mp
+    import truth_common as T
     worst = {"pos": 0.0, "dir": 0.0, "path": 0.0, "inc": 0.0}
+    stats = {} if stats is None else stats
+    stats.setdefault("scenes", 0)
+    stats.setdefault("adjudicated", 0)
+    stats.setdefault("adjudicated_seeds", [])
+    stats.setdefault("local_worst", {k: 0.0 for k in LOCAL_TOL})
+    stats.setdefault("adjudicated_worst", {"product": 0.0, "oracle": 0.0})
     hits = 0
     for seed in seeds:
         scene, a = random_scene(seed, n_rays)
+        stats["scenes"] += 1
         tag = f"seed {seed} (" + " -> ".join(
             f"{e['type']}{' + Zernike' if e.get('defects') else ''} [{e['support']['kind']}]" for e in scene["elements"]) + ")"
         src_o = orc.make_bundle(a["src_point"], a["src_vector"], a["src_number"], a["src_intensity"], None)
-        refs = orc.ray_tracing_calculation(src_o, orc.elements_from_scene(scene, a), IgnoreDefects=scene["IgnoreDefects"])
+        els_o = orc.elements_from_scene(scene, a)
+        refs = orc.ray_tracing_calculation(src_o, els_o, IgnoreDefects=scene["IgnoreDefects"])
         hits += int(len(refs[-1]) > 0)
         scale = pc.scene_scale(a, scene)
         els = pc.build_elements(scene, a)
         src = RayBundle.from_arrays(a["src_point"], a["src_vector"], a["src_number"], None, None)
+        noise = [pose_noise(e) for e in scene["elements"]]      # nearly antiparallel frame axes: the reference's own noise
         for mode in modes:
             outs = mp.RayTracingCalculation(src, els, IgnoreDefects=scene["IgnoreDefects"], mode=mode)
-            well = np.ones(n_rays, dtype=bool)      # per source ray: no grazing hit so far
-            dir_tol = pc.REL_TOL
+            well = np.ones(len(a["src_number"]), dtype=bool)      # per source ray: no grazing hit so far
+            prev = {"number": np.asarray(a["src_number"]), "point": a["src_point"], "vector": src.vectors()}
+            frame_noise = 0.0
             for k, (out, ref, e) in enumerate(zip(outs, refs, scene["elements"])):
                 assert np.array_equal(out.numbers(), ref.number), f"{tag}, mode {mode}: survivors differ after {k}"
                 well[ref.number[ref.incidence >= GRAZING]] = False
-                # a hit-point difference dP (allowed: REL_TOL * scale) turns the normal by dP / rc, the reflected
-                # direction by twice that: on strongly curved optics the direction tolerance follows from the
-                # position tolerance (and carries over to the elements downstream)
-                rc = curvature_radius(e)
-                if rc:
-                    # ... and a direction difference d that ARRIVES at a curved optic after a flight of L moves the hit
-                    # point by L d, the normal by L d / rc: it leaves as d (1 + 2 L / rc).  Differences compound along a
-                    # chain of curved optics (seed 60039358: 2.3e-11 -> 2.3e-10 -> 1.6e-9 over an ellipsoid, an
-                    # ellipsoid and a sphere with L / rc = 4-5, with both builds of the kernels and the oracle alike).
-                    L = float(ref.path[:, -1].max()) if (k > 0 and len(ref.number)) else 0.0
-                    dir_tol = max(dir_tol * (1.0 + 2.0 * L / rc), pc.REL_TOL * 2 * scale / rc)
-                dir_tol = max(dir_tol, pose_noise(e))    # nearly antiparallel frame axes: the reference's own noise
-                pos_tol = pc.REL_TOL if k == 0 else max(pc.REL_TOL, dir_tol)   # lever arm <= scene scale
+                frame_noise += noise[k]
+                # -- 2. local truth (grazing hits of THIS element excluded as well: conditioning of the hit itself)
+                if T.HAVE_LD:
+                    loc = _local_truth_errors(els_o[k], prev, out, scale, scene["IgnoreDefects"], well)
+                    if loc is not None:
+                        for key, v in loc.items():
+                            lim = LOCAL_TOL[key] + noise[k]
+                            assert v <= lim, (f"{tag}, mode {mode}, element {k}: LOCAL {key} error {v:.3e} > {lim:.1e} "
+                                              f"against the long-double truth")
+                            stats["local_worst"][key] = max(stats["local_worst"][key], v)
+                prev = {"number": out.numbers(), "point": out.points(), "vector": out.vectors()}
+                # -- 3. product vs oracle
                 m = well[ref.number]
                 if not m.any():
                     continue
@@ -216,10 +256,35 @@ def run_differential(seeds, modes=("chain", "element"), n_rays=1500):
                        "path": max(np.abs(out.paths_total() - np.sum(ref.path, axis=1))[m].max(),
                                    np.abs(out.path_segments() - ref.path)[m].max()) / mean_path,
                        "inc": np.abs(out.incidences() - ref.incidence)[m].max()}
-                tols = {"pos": pos_tol, "dir": dir_tol, "path": pos_tol, "inc": max(1e-9, dir_tol)}
                 for key, v in err.items():
-                    assert v <= tols[key], f"{tag}, mode {mode}, element {k}: {key} error {v:.3e} > {tols[key]:.1e}"
                     worst[key] = max(worst[key], float(v))
+                tols = {key: STRICT_TOL[key] + frame_noise for key in STRICT_TOL}
+                if all(err[key] <= tols[key] for key in err):
+                    continue
+                # -- adjudication by truth: whole chain in long double for the rays that got this far
+                assert T.HAVE_LD, f"{tag}, mode {mode}, element {k}: {err} beyond {tols} and no long double to adjudicate"
+                stats["adjudicated"] += 1
+                stats["adjudicated_seeds"].append(int(seed))
+                surv = [o.numbers() for o in outs[:k + 1]]
+                seeds_t = [o.path_segments()[:, -1] for o in outs[:k + 1]]
+                keep, truth = T.chain_truth(els_o[:k + 1], a["src_point"], src.vectors(), a["src_number"], surv, seeds_t,
+                                            scene["IgnoreDefects"])
+                tP, tv, tpath, tinc = truth[-1]
+                mk = well[keep]
+                sel_p = np.searchsorted(out.numbers(), keep)
+                sel_o = np.searchsorted(ref.number, keep)
+
+                def vs_truth(pts, vec, path, inc):
+                    return {"pos": float(np.abs(pts - tP)[mk].max() / scale), "dir": float(np.abs(vec - tv)[mk].max()),
+                            "path": float(np.abs(path - tpath)[mk].max() / mean_path), "inc": float(np.abs(inc - tinc)[mk].max())}
+                ep = vs_truth(out.points()[sel_p], out.vectors()[sel_p], out.paths_total()[sel_p], out.incidences()[sel_p])
+                eo = vs_truth(ref.point[sel_o], ref.vector[sel_o], np.sum(ref.path, axis=1)[sel_o], ref.incidence[sel_o])
+                for key in ep:
+                    assert ep[key] <= max(tols[key], eo[key]), (
+                        f"{tag}, mode {mode}, element {k}: {key} differs from the oracle by {err[key]:.3e} and the product is the "
+                        f"one farther from the long-double truth ({ep[key]:.3e} vs the oracle's {eo[key]:.3e})")
+                stats["adjudicated_worst"]["product"] = max(stats["adjudicated_worst"]["product"], max(ep.values()))
+                stats["adjudicated_worst"]["oracle"] = max(stats["adjudicated_worst"]["oracle"], max(eo.values()))
             if mode == "chain" and seed % 3 == 0:
                 # The scene-table launch (two copies of the chain in one launch) runs the fused kernel's per-ray code:
                 # bit-identical to the single launch when that is the same kernel body (>= 2 elements, no defects); a

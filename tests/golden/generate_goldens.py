@@ -532,6 +532,7 @@ if __name__ == "__main__":
     scene_zernike_tierA()
     scene_geometry_units()
     scene_c1(1000, "c1_singleparabola")
+    scene_c1(10000, "c1_singleparabola_1e4")     # BASELINE.json config 1 at its own size (N = 1000 and 1e4)
     scene_c2()
     scene_c3()
     scene_c5()

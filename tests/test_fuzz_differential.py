@@ -17,8 +17,12 @@ def twin():
 
 @pytest.mark.parametrize("block", range(6))
 def test_fuzz_twin_vs_oracle(twin, block):
-    res = fz.run_differential(range(block * 20, block * 20 + 20))
+    st = {}
+    res = fz.run_differential(range(block * 20, block * 20 + 20), stats=st)
     assert res["scenes_with_hits"] >= 12, res   # the generator must actually exercise the optics
+    # every element of every scene was checked against the long-double truth; product vs oracle beyond 1e-10 only where
+    # the truth says the product is the closer one (seed 65 in block 3)
+    assert st["scenes"] == 20 and max(st["local_worst"].values()) > 0.0 and st["adjudicated"] <= 4, st
 
 
 def test_fuzz_regressions(twin):

@@ -248,8 +248,12 @@ def test_gpu_extended_source_matches_reference(hip):
 def test_gpu_fuzz_differential(hip):
     """300 random scenes (every optic x aperture kind, arbitrary poses) on the GPU against the pinned oracle."""
     import fuzz_common as fz
-    res = fz.run_differential(list(range(300)) + [20797, 23917])
+    st = {}
+    res = fz.run_differential(list(range(300)) + [20797, 23917, 60039358, 40030221], stats=st)
     assert res["scenes_with_hits"] >= 250, res
+    report(f"[gpu fuzz, {st['scenes']} scenes] local error vs long-double truth: " + "  ".join(f"{k} {v:.1e}" for k, v in st["local_worst"].items())
+           + f"; adjudicated by truth: seeds {sorted(set(st['adjudicated_seeds']))}, product {st['adjudicated_worst']['product']:.1e} vs oracle "
+           f"{st['adjudicated_worst']['oracle']:.1e}")
     assert fz.run_detector_fuzz(range(150)) >= 200
     fz.run_source_fuzz(range(100))
 
@@ -548,6 +552,13 @@ def test_gpu_torus_hit_distance_vs_long_double_truth(hip, name):
     """The kernels' hardware-seeded reciprocal / rsqrt paths against an 80-bit truth (tests/test_accuracy_truth.py)."""
     from test_accuracy_truth import check_against_truth
     check_against_truth(name)
+
+
+@pytest.mark.parametrize("name", chain_golden_names())
+def test_gpu_every_element_vs_long_double_truth(hip, name):
+    """Every optic kind, the deformations and the reflection of the HIP kernels against tests/truth_common.py."""
+    from test_accuracy_truth import check_every_element_against_truth
+    check_every_element_against_truth(name)
 
 
 # ------------------------------------------------------------------------------------------------ scene table

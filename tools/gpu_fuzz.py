@@ -14,11 +14,11 @@ def main():
     first, count = int(sys.argv[1]), int(sys.argv[2])
     from attosecondraytracing_amd import _lib
     _lib.get_backend()                      # raises without the HIP library / a GPU
-    worst, fails, hits, det = {}, [], 0, 0
+    worst, fails, hits, det, st = {}, [], 0, 0, {}
     t0 = time.time()
     for s in range(first, first + count):
         try:
-            r = fz.run_differential([s])
+            r = fz.run_differential([s], stats=st)
             hits += r["scenes_with_hits"]
             for k, v in r["worst"].items():
                 worst[k] = max(worst.get(k, 0.0), v)
@@ -29,6 +29,10 @@ def main():
         if (s - first) % 500 == 499:
             print(f"[{time.time() - t0:.0f} s] {s - first + 1} scenes, {len(fails)} failures", flush=True)
     print(f"scenes {count} (seeds {first}..{first + count - 1}), with hits {hits}, detector poses {det}, worst {worst}")
+    print(f"local errors vs long-double truth (every element of every scene): {st.get('local_worst')}")
+    print(f"scenes whose product-vs-oracle difference exceeded 1e-10 and were adjudicated by truth: "
+          f"{len(set(st.get('adjudicated_seeds', [])))} {sorted(set(st.get('adjudicated_seeds', [])))[:40]}; worst error vs truth there: "
+          f"{st.get('adjudicated_worst')}")
     print(f"failures: {len(fails)}")
     for f in fails[:40]:
         print(f)
