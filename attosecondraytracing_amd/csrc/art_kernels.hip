@@ -206,6 +206,7 @@ __device__ __forceinline__ void store_ray(const ArtBundleView& v, int64_t i, con
 constexpr int kRedBlocks = 1024;
 constexpr int kRedSlots = 16;
 constexpr int kReadoutSlots = 24;   // art_detector_readout / fused chain read-out statistics
+constexpr int kUsedSlots = 22;      // slots 22, 23 are reserved (always 0): the fused tail writes no partials for them
 
 enum RedOp { RSUM = 0, RMIN = 1, RMAX = 2 };
 
@@ -488,6 +489,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
   static_assert(sizeof(double) * 8 * kBlock <= sizeof(double) * (kBlock / 64) * 8 * kTileStride, "staging tile fits");
   __shared__ uint8_t s_al[kBlock];
 #endif
+  __shared__ double s_part[kBlock / 64][kReadoutSlots];   // wave totals of the fused read-out, combined per workgroup
   const int64_t tile = tile_of(blockIdx.x, gridDim.x, xmap);
   const BundleRsrc bi = make_rsrc(a.in, n, first);
   const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -536,10 +538,10 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
     } while (++k < a.n_elems);
     if (a.flags & art::kFlagReadout) {
       // Fused detector read-out of the last bundle (art_trace_chain_readout): the ray is still in registers.  X, Y, opl
-      // of dead rays are dropped by the range check.  Statistics: one partial per WAVE (wave_reduce24), written row by
-      // row (row_of_slot) into ro.scratch -- no barrier and no load down here: a __syncthreads() or a trailing load
-      // would make every wave wait for the acknowledgement of its 36 outstanding stores (vmcnt counts loads and
-      // stores in one queue) instead of retiring as soon as they are issued, which cost 35 %.
+      // of dead rays are dropped by the range check.  Statistics: per wave wave_reduce24, per workgroup one partial,
+      // written row by row (row_of_slot) into ro.scratch -- no __syncthreads() and no load down here: either would make
+      // every wave wait for the acknowledgement of its 36 outstanding stores (vmcnt counts loads and stores in one queue)
+      // instead of retiring as soon as they are issued, which cost 35 %.
       double acc[kReadoutSlots];
       double Ix, Iy, Iz, x = 0.0, y = 0.0, o = 0.0;
       if (ok) art::detector_ray(a.ro.det, r, Ix, Iy, Iz, x, y, o);
@@ -554,8 +556,6 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
       // (flags has no bit 30), so that the value is neither kept in a register nor spilled
       readout_single(acc, ok, x, y, o, s_w[lane ^ ((unsigned)a.flags >> 30)], a.ro.w != nullptr, a.ro.cx, a.ro.cy,
                      a.ro.co);
-      const int64_t nparts = (int64_t)gridDim.x * (kBlock / 64);
-      const int64_t part = (int64_t)blockIdx.x * (kBlock / 64) + (lane >> 6);
       double tot[3];
 #ifdef ART_DIAG_RO_NOREDUCE  // ... without the wave reduction, ...
       tot[0] = acc[0] + acc[1] + acc[6] + acc[7] + acc[8] + acc[9] + acc[10] + acc[11];
@@ -564,100 +564,122 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
 #else
       wave_reduce24(acc, s_red + (lane >> 6) * (8 * kTileStride), lane & 63, tot);
 #endif
+      // One partial per WORKGROUP (round 3; per wave before): the four wave totals meet in LDS behind a bare s_barrier --
+      // __syncthreads() would also wait for the acknowledgement of the stores in flight -- and threads 0..21 fold them in
+      // wave order and store row `thread` (= pass * 8 + stat, row_of_slot) of the scratch area.  A quarter of the partials:
+      // the fold that follows reads 7.5 MB instead of 30 MB per 1e7 rays and fits ONE launch (launch_fold_*).
+      if ((lane & 7) == 0) {
+        const int stat = (lane & 63) >> 3, w = lane >> 6;
+        s_part[w][stat] = tot[0];
+        s_part[w][8 + stat] = tot[1];
+        if (stat < 6) s_part[w][16 + stat] = tot[2];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #ifdef ART_DIAG_RO_NOSCRATCH  // ... without the partial-statistics stores
       if (tot[0] + tot[1] + tot[2] == -1.2345e300) {
 #else
-      if ((lane & 7) == 0) {
+      if (lane < kUsedSlots) {
 #endif
-        const int stat = (lane & 63) >> 3;
-        double* dst = a.ro.scratch + part;
-        dst[(int64_t)stat * nparts] = tot[0];            // row = pass * 8 + stat (row_of_slot)
-        dst[(int64_t)(8 + stat) * nparts] = tot[1];
-        if (stat < 6) dst[(int64_t)(16 + stat) * nparts] = tot[2];
+        double v = s_part[0][lane];
+#pragma unroll
+        for (int j = 1; j < kBlock / 64; ++j) {
+          const double q = s_part[j][lane];
+          v = (lane < 16) ? v + q : (lane < 19 ? fmin(v, q) : fmax(v, q));    // rows 16-18: minima, 19-21: maxima
+        }
+        a.ro.scratch[(int64_t)lane * gridDim.x + blockIdx.x] = v;
       }
     }
     i0 += stride;
   } while (DEFECT && kDefectLoop && i0 < n);
 }
 
-// Fold of the fused read-out's per-wave partials (row-major: scratch[row_of_slot(slot) * nparts + part], 1.6e5 parts
-// per 1e7 rays) in two tiny launches, both in a fixed order: kFoldChunks workgroups per statistic each fold one contiguous
-// chunk of its row into mid[slot * kFoldChunks + chunk] (mid = the tail of the scratch area), then one workgroup per
-// statistic folds the chunks.  (A single workgroup per statistic walking the whole 1.25 MB row took 0.2 ms -- as long
-// as a third of the trace.)  Grids: (24, chunks, chains) and (24, 1, chains).
+// Fold of the fused read-out's per-WORKGROUP partials (row-major: scratch[row_of_slot(slot) * nparts + part], 39 063
+// parts per 1e7 rays), always in a fixed order (deterministic).  ONE launch up to kFoldDirect partials (1.67e7 rays):
+// a 1024-thread workgroup per statistic folds its whole row (312 KB at 1e7 rays: thread t takes parts t, t + 1024, ...,
+// ~40 independent loads, then a shuffle tree and 16 wave totals through LDS).  Round 2 left one partial per WAVE and
+// folded the four-times-longer rows in two launches (64 chunks per statistic, then one workgroup per statistic): 8 + 5 us
+// behind every relay4 trace, 18 us behind C2's 11 chains; that two-stage form remains for longer rows.
+// Grids: (24, 1, chains) direct; (24, chunks, chains) + (24, 1, chains) beyond.
 constexpr int kFoldChunks = 64;
+constexpr int kFoldBlock = 1024;
+constexpr int64_t kFoldDirect = 65536;
+__device__ __forceinline__ double fold_op(const double a, const double b, const int op_k) {
+  return (op_k == RSUM) ? a + b : (op_k == RMIN ? fmin(a, b) : fmax(a, b));
+}
+// every thread of the workgroup (blockDim.x threads, a multiple of 64) calls this; thread 0 stores the result
 __device__ __forceinline__ void fold_range(const double* row, const int64_t lo, const int64_t hi, const int op_k,
                                            double* out) {
-  const int op[1] = {op_k};
-  double acc[1] = {(op_k == RSUM) ? 0.0 : (op_k == RMIN ? INFINITY : -INFINITY)};
-  for (int64_t p = lo + threadIdx.x; p < hi; p += kBlock) {
-    const double v = row[p];
-    acc[0] = (op_k == RSUM) ? acc[0] + v : (op_k == RMIN ? fmin(acc[0], v) : fmax(acc[0], v));
+  __shared__ double s[kFoldBlock / 64];
+  double acc = (op_k == RSUM) ? 0.0 : (op_k == RMIN ? INFINITY : -INFINITY);
+  for (int64_t p = lo + threadIdx.x; p < hi; p += blockDim.x) acc = fold_op(acc, row[p], op_k);
+  acc = wave_reduce(acc, op_k);
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double v = s[0];
+    for (int j = 1; j < (int)(blockDim.x >> 6); ++j) v = fold_op(v, s[j], op_k);
+    *out = v;
   }
-  block_reduce_store<1>(acc, op, out);
 }
 __device__ __forceinline__ double* fold_mid(double* scratch, const int64_t nparts) {
   return scratch + (int64_t)kReadoutSlots * nparts;
 }
-constexpr int kUsedSlots = 22;   // slots 22, 23 of the statistics are reserved (always 0): the tail writes no partials for them
+__device__ __forceinline__ int fold_row_of(const int slot) {
+  int row = 0;
+#pragma unroll
+  for (int k = 0; k < kUsedSlots; ++k) row = (slot == k) ? row_of_slot(k) : row;
+  return row;
+}
 __device__ __forceinline__ void fold_stage1(double* scratch, const int64_t nparts) {
   if (blockIdx.x >= kUsedSlots) return;
   const int ops[kReadoutSlots] = ART_READOUT_OPS;
   const int64_t per = (nparts + kFoldChunks - 1) / kFoldChunks;
   const int64_t lo = (int64_t)blockIdx.y * per, hi = (lo + per < nparts) ? lo + per : nparts;
-  int row = 0;
-#pragma unroll
-  for (int k = 0; k < kUsedSlots; ++k) row = ((int)blockIdx.x == k) ? row_of_slot(k) : row;
-  fold_range(scratch + (int64_t)row * nparts, lo, hi, ops[blockIdx.x],
+  fold_range(scratch + (int64_t)fold_row_of(blockIdx.x) * nparts, lo, hi, ops[blockIdx.x],
              fold_mid(scratch, nparts) + blockIdx.x * kFoldChunks + blockIdx.y);
 }
-// Small bundles (<= kFoldDirect per-wave partials, i.e. <= 5e5 rays): ONE launch, every statistic's workgroup folds its
-// whole row -- at 1e5 rays the step is three ~5-us graph nodes, and the middle one is pure launch latency.
-constexpr int64_t kFoldDirect = 8192;
 __device__ __forceinline__ void fold_stage2(double* scratch, const int64_t nparts, double* out24, const int direct) {
   if (blockIdx.x >= kUsedSlots) {
     if (threadIdx.x == 0) out24[blockIdx.x] = 0.0;
     return;
   }
   const int ops[kReadoutSlots] = ART_READOUT_OPS;
-  if (direct) {
-    int row = 0;
-#pragma unroll
-    for (int k = 0; k < kUsedSlots; ++k) row = ((int)blockIdx.x == k) ? row_of_slot(k) : row;
-    fold_range(scratch + (int64_t)row * nparts, 0, nparts, ops[blockIdx.x], out24 + blockIdx.x);
+  if (direct) {   // nparts == 0 (an empty bundle): the fold of nothing leaves the identities
+    fold_range(scratch + (int64_t)fold_row_of(blockIdx.x) * nparts, 0, nparts, ops[blockIdx.x], out24 + blockIdx.x);
     return;
   }
-  // nparts == 0 (an empty bundle): no chunk was written, the fold of nothing leaves the identities
-  fold_range(fold_mid(scratch, nparts) + blockIdx.x * kFoldChunks, 0, nparts > 0 ? kFoldChunks : 0, ops[blockIdx.x],
-             out24 + blockIdx.x);
+  fold_range(fold_mid(scratch, nparts) + blockIdx.x * kFoldChunks, 0, kFoldChunks, ops[blockIdx.x], out24 + blockIdx.x);
 }
-__global__ __launch_bounds__(kBlock) void k_chain_readout_fold1(const ChainArgs* __restrict__ tab, const int64_t nparts) {
+__global__ __launch_bounds__(kFoldBlock) void k_chain_readout_fold1(const ChainArgs* __restrict__ tab, const int64_t nparts) {
   fold_stage1(tab[blockIdx.z].ro.scratch, nparts);
 }
-__global__ __launch_bounds__(kBlock) void k_chain_readout_fold2(const ChainArgs* __restrict__ tab, const int64_t nparts,
-                                                                const int direct) {
+__global__ __launch_bounds__(kFoldBlock) void k_chain_readout_fold2(const ChainArgs* __restrict__ tab, const int64_t nparts,
+                                                                    const int direct) {
   fold_stage2(tab[blockIdx.z].ro.scratch, nparts, tab[blockIdx.z].ro.out24, direct);
 }
-__global__ __launch_bounds__(kBlock) void k_chain_readout_fold1_one(double* scratch, const int64_t nparts) {
+__global__ __launch_bounds__(kFoldBlock) void k_chain_readout_fold1_one(double* scratch, const int64_t nparts) {
   fold_stage1(scratch, nparts);
 }
-__global__ __launch_bounds__(kBlock) void k_chain_readout_fold2_one(double* scratch, double* out24, const int64_t nparts,
-                                                                    const int direct) {
+__global__ __launch_bounds__(kFoldBlock) void k_chain_readout_fold2_one(double* scratch, double* out24, const int64_t nparts,
+                                                                        const int direct) {
   fold_stage2(scratch, nparts, out24, direct);
 }
 
-// launch the fold (host side)
+// launch the fold (host side): ONE launch up to kFoldDirect partials; a short row does not need 1024 threads
+inline int fold_threads(int64_t nparts) { return nparts <= 4096 ? kBlock : kFoldBlock; }
 inline void launch_fold_one(double* scratch, double* out24, int64_t nparts, hipStream_t s) {
   const int direct = nparts <= kFoldDirect;
-  if (nparts > 0 && !direct)
-    hipLaunchKernelGGL(k_chain_readout_fold1_one, dim3(kReadoutSlots, kFoldChunks), dim3(kBlock), 0, s, scratch, nparts);
-  hipLaunchKernelGGL(k_chain_readout_fold2_one, dim3(kReadoutSlots), dim3(kBlock), 0, s, scratch, out24, nparts, direct);
+  if (!direct)
+    hipLaunchKernelGGL(k_chain_readout_fold1_one, dim3(kReadoutSlots, kFoldChunks), dim3(kFoldBlock), 0, s, scratch, nparts);
+  hipLaunchKernelGGL(k_chain_readout_fold2_one, dim3(kReadoutSlots), dim3(direct ? fold_threads(nparts) : kBlock), 0, s, scratch,
+                     out24, nparts, direct);
 }
 inline void launch_fold_scene(const ChainArgs* seg, int n_chains, int64_t nparts, hipStream_t s) {
   const int direct = nparts <= kFoldDirect;
-  if (nparts > 0 && !direct)
-    hipLaunchKernelGGL(k_chain_readout_fold1, dim3(kReadoutSlots, kFoldChunks, n_chains), dim3(kBlock), 0, s, seg, nparts);
-  hipLaunchKernelGGL(k_chain_readout_fold2, dim3(kReadoutSlots, 1, n_chains), dim3(kBlock), 0, s, seg, nparts, direct);
+  if (!direct)
+    hipLaunchKernelGGL(k_chain_readout_fold1, dim3(kReadoutSlots, kFoldChunks, n_chains), dim3(kFoldBlock), 0, s, seg, nparts);
+  hipLaunchKernelGGL(k_chain_readout_fold2, dim3(kReadoutSlots, 1, n_chains), dim3(direct ? fold_threads(nparts) : kBlock), 0, s,
+                     seg, nparts, direct);
 }
 
 template <bool DEFECT, int WAVES>
@@ -1383,7 +1405,7 @@ static int trace_chain_impl(const ArtElementDesc* elems, int32_t n_elems, const 
       else
         hipLaunchKernelGGL((k_trace_chain<false, 5>), g, b, chain_dyn_lds(), s, a, cnt, xm);
       if (tail)
-        launch_fold_one(ro->scratch, ro->out24, (int64_t)g.x * (kBlock / 64), s);
+        launch_fold_one(ro->scratch, ro->out24, (int64_t)g.x, s);
       cur = a.out[m - 1];
     }
   }
@@ -1400,9 +1422,9 @@ int art_trace_chain(const ArtElementDesc* elems, int32_t n_elems, const ArtBundl
 int64_t art_chain_readout_scratch_doubles(int64_t n) {
   if (n < 0) n = 0;
   if (n > kMaxRaysPerLaunchHw) n = kMaxRaysPerLaunchHw;
-  // one 24-slot partial per WAVE of the fused launch (its grid may be rounded up by the tile mapping) + the chunk
+  // one 24-slot partial per WORKGROUP of the fused launch (its grid may be rounded up by the tile mapping) + the chunk
   // totals of the two-stage fold behind them
-  return (((n + kBlock - 1) / kBlock + 1024) * (kBlock / 64) + kFoldChunks) * kReadoutSlots;
+  return (((n + kBlock - 1) / kBlock + 1024) + kFoldChunks) * kReadoutSlots;
 }
 
 int art_trace_chain_readout(const ArtElementDesc* elems, int32_t n_elems, const ArtBundleView* in,
@@ -1465,7 +1487,7 @@ int art_trace_scene(const void* image_dev, const void* image_host, int64_t n, vo
       else
         hipLaunchKernelGGL((k_trace_scene<false, 5>), g, b, 0, s, seg, off, cnt, xm);
       if ((flags & art::kFlagReadout) && sg == S - 1)
-        launch_fold_scene(seg, n_chains, (int64_t)g.x * (kBlock / 64), s);
+        launch_fold_scene(seg, n_chains, (int64_t)g.x, s);
     }
   }
   hipError_t err = hipGetLastError();

@@ -101,6 +101,38 @@ def launch_workers(n, argv):
     return 0
 
 
+# =========================================================================================== box state (read-only sysfs queries)
+SMI_ARGS = ["rocm-smi", "--showclocks", "--showperflevel", "--showpower", "--showmaxpower", "--showmemorypartition",
+            "--showcomputepartition", "--showtemp", "--json"]
+
+
+def smi_start():
+    """Start one rocm-smi query (clocks, power, power cap, partition modes); it reads sysfs and touches no queue."""
+    try:
+        return subprocess.Popen(SMI_ARGS, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    except OSError:
+        return None
+
+
+def smi_result(p, card):
+    """Compact dict of the query's fields for device `card` (clock levels, power, partitions), or None."""
+    if p is None:
+        return None
+    try:
+        out = p.communicate(timeout=20)[0].decode(errors="replace")
+        j = json.loads(out[out.index("{"):])
+        c = j.get(f"card{card}", next(iter(j.values())))
+        keep = {}
+        for k, v in c.items():
+            kl = k.lower()
+            if any(t in kl for t in ("clock", "power", "partition", "performance", "temperature (sensor junction)",
+                                     "temperature (sensor memory)")):
+                keep[k] = v
+        return keep
+    except Exception as e:    # noqa: BLE001 -- a diagnostic must never cost the result line
+        return {"error": repr(e)[:200]}
+
+
 # =========================================================================================== scenes
 def build_scene(n_mirrors, small_n=1000):
     """relay<M>: element poses through the product's own OEPlacement (1-ray alignment traces on the GPU)."""
@@ -318,9 +350,13 @@ class _HostTables:
 def profiled_traffic(config, kernel_prefix, rays):
     """HBM bytes per launch of the kernel whose name starts with `kernel_prefix`, from the newest committed rocprofv3
     PMC summary of this workload (profiles/rNN_<config>*.json, written by tools/summarize_profile.py from separate
-    --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 read correction).  None when no matching profile exists."""
+    --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 read correction) THAT WAS TAKEN ON THIS BUILD: a profile whose
+    `source_hash` (csrc/* + include/art_hip.h at profiling time) differs from the tree's is dropped, and the line says so.
+    -> (bytes, file, kernel) or None, and a note."""
     import glob
-    best = None
+    from tools.source_hash import source_hash
+    here = source_hash()
+    best, dropped = None, []
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{config}.json")))    # newest round last
     for f in files:
         try:
@@ -329,8 +365,14 @@ def profiled_traffic(config, kernel_prefix, rays):
             continue
         hits = [k for k in j.get("per_launch", {}) if k.startswith(kernel_prefix)]
         if j.get("rays_per_gpu") == rays and hits:
+            if j.get("source_hash") != here:
+                dropped.append(f"{os.path.relpath(f, ROOT)} (sources {j.get('source_hash', 'unrecorded')} != {here})")
+                continue
             best = (j["per_launch"][hits[0]]["total_bytes"], os.path.relpath(f, ROOT), hits[0])
-    return best
+    note = None
+    if best is None and dropped:
+        note = "no PMC profile of THIS build: dropped " + "; ".join(dropped)
+    return best, note
 
 
 # =========================================================================================== worker
@@ -375,6 +417,8 @@ def worker(args):
     def sync():
         if on_gpu:
             torch.cuda.synchronize()
+
+    smi_idle = smi_start() if (on_gpu and rank == 0) else None      # the box before this run loads it
 
     def barrier():
         if use_dist:
@@ -440,8 +484,9 @@ def worker(args):
         outs0 = [mp.RayTracingCalculation(src, element_lists[0], IgnoreDefects=ignore_defects, mode=mode)]
     # Rank 0 places them (its shard holds the innermost rays of the Vogel spiral, so it always has survivors) and
     # broadcasts the poses: every rank reads out on the same detector planes, as a single-process run would.
-    dets, entering, surv_last = [], 0, []
+    dets, entering, surv_last, live = [], 0, [], []
     for els, out in zip(element_lists, outs0):
+        live.append([len(o) for o in out])         # survivors after every element of this chain (rank-local)
         det = mdet.Detector(np.asarray(els[-1].position, dtype=float))
         if rank == 0:
             det.autoplace(out[-1], det_dist)
@@ -583,6 +628,18 @@ def worker(args):
         saved_w, args.warmup = args.warmup, 0
         dt_sus, _, o, r = timed(False, args.steps)
         args.warmup = saved_w
+    # Box state UNDER LOAD (VERDICT r2 #5b: boxes of the pool differ by up to 20 % on this access pattern): one rocm-smi
+    # query runs while the device keeps tracing; clocks, power and partition modes go on the line beside the numbers.
+    box = None
+    if on_gpu and rank == 0 and not use_dist:
+        box = {"idle_before_run": smi_result(smi_idle, local)}
+        q = smi_start()
+        t_end = time.perf_counter() + 10.0
+        while q is not None and q.poll() is None and time.perf_counter() < t_end:
+            for _ in range(50):
+                step(False)
+            sync()
+        box["under_load"] = smi_result(q, local)
     stats_host = (state["stats"] if use_dist else r[-1]["stats_dev"]).cpu().numpy()
     assert stats_host[0] == surv_last_job and np.isfinite(stats_host[1]), (stats_host[0], surv_last_job)
 
@@ -640,6 +697,7 @@ def worker(args):
             "value_full_gather": None if dt_full is None else inter_per_step_job * args.steps / dt_full,
             "ms_per_step_full_gather": None if dt_full is None else dt_full / args.steps * 1e3,
             "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
+            "box": box,
         }
         if on_gpu:
             inter_per_launch = inter_per_step_rank / launches
@@ -655,33 +713,61 @@ def worker(args):
             auto_fuse = True
             base = f"relay{args.mirrors}" if cfg == "relay4" else cfg        # (profiles exist for the 4-mirror headline)
             pkey = base if fuse == auto_fuse else base + ("_fused" if fuse else "_separate")
-            tr = profiled_traffic(pkey, kprefix, n)
+            tr, tr_note = profiled_traffic(pkey, kprefix, n)
             # 128 B per intersection, + 88 B per ray of read-out when that rides on the same launch
             algo_bytes = ALGO_BYTES_PER_INTERSECTION * inter_per_launch + (ALGO_BYTES_READOUT * n * n_chains / launches if fuse else 0.0)
             algo = algo_bytes / (kernel_ms * 1e-3) / 1e9
+            # What the launch(es) of one step MUST move, computed here from the run's own survivor counts (no profile): every
+            # chain reads its source once -- 7 fp64 streams + the alive byte = 57 B per slot, + 8 B of weight with a fused
+            # read-out -- and writes, per element, 64 B per LIVE slot (8 fp64 streams; pairs of dead slots are dropped by
+            # the range check) + the alive byte of every slot; a fused read-out adds 24 B per surviving ray and 22 doubles
+            # per workgroup of partial statistics.  Per-element launches (--mode element) re-read every bundle.
+            has_w = fuse and src.intensity is not None
+            comp = 0.0
+            for lv in live:
+                if mode == "chain" or program is not None:
+                    comp += n * (57.0 + (8.0 if has_w else 0.0)) + sum(64.0 * x + n for x in lv)
+                else:
+                    comp += sum(57.0 * n + 64.0 * x + n for x in lv)
+                if fuse:
+                    comp += 24.0 * lv[-1] + 176.0 * ((n + 255) // 256)
+            comp /= launches
+            compulsory = comp / (kernel_ms * 1e-3) / 1e9
             # what the kernel moves by construction: every chain reads its source once (57 B/slot) and writes 65 B per
             # slot and element (dead slots: only the alive byte) -- the PMC counters agree with it to 0.1 % on relay4
             counted = None if tr is None else tr[0] / (kernel_ms * 1e-3) / 1e9
+            basis = "counted" if counted is not None else "compulsory"
             res["roofline"] = {
                 "bound": "hbm", "kernel": tr[2] if tr else kprefix + "...>",
-                # `achieved`/`frac`: COUNTED HBM bytes (rocprofv3 PMC, committed profile) / live kernel time / peak -- what
-                # the memory system really delivers.  The fused kernel reads a ray once per chain, so it moves fewer
+                # `achieved`/`frac`: COUNTED HBM bytes (rocprofv3 PMC, committed profile OF THIS BUILD) / live kernel time /
+                # peak -- what the memory system really delivers; without such a profile, the compulsory bytes computed in
+                # this run (`frac_basis` says which).  The fused kernel reads a ray once per chain, so it moves fewer
                 # bytes than the 128 B/intersection of SURVEY 8(d): that algorithmic figure is kept beside it.
-                "achieved": counted, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": None if counted is None else counted / HBM_PEAK_GBS,
+                "achieved": counted if counted is not None else compulsory, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (counted if counted is not None else compulsory) / HBM_PEAK_GBS, "frac_basis": basis,
                 "traffic": None if tr is None else tr[0],
-                "traffic_source": None if tr is None else tr[1] + " (rocprofv3 PMC, bytes per launch)",
+                "traffic_source": (tr_note or None) if tr is None else tr[1] + " (rocprofv3 PMC, bytes per launch)",
+                "compulsory_bytes": comp, "achieved_compulsory": compulsory, "frac_compulsory": compulsory / HBM_PEAK_GBS,
+                "compulsory_formula": "per chain: n (57 + 8 w) read + sum_k (64 live_k + n) written + fused read-out 24 live_last + "
+                                      "176 B per workgroup; from this run's survivor counts",
+                "counted_over_compulsory": None if tr is None else tr[0] / comp,
                 "achieved_algorithmic": algo, "frac_algorithmic": algo / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_intersection": ALGO_BYTES_PER_INTERSECTION,
                 "algorithmic_bytes_per_read_out_ray": ALGO_BYTES_READOUT if fuse else None,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_ms": kernel_ms, "launches_per_step": launches, "intersections_per_launch": inter_per_launch,
-                "frac_of_achievable_6300": None if counted is None else counted / 6300.0,
+                "frac_of_achievable_6300": (counted if counted is not None else compulsory) / 6300.0,
+                "source_hash": __import__("tools.source_hash", fromlist=["source_hash"]).source_hash(),
             }
-            sq = os.path.join(ROOT, "profiles", "r02_relay4_sq.json")
-            if cfg == "relay4" and fuse and n == 10_000_000 and args.mirrors == 4 and os.path.exists(sq):
-                # the kernel's OTHER roof: SQ counters of this very workload (tools/prof_sq.sh), committed
-                res["roofline"]["second_bound"] = dict(json.load(open(sq)), source="profiles/r02_relay4_sq.md")
+            if cfg == "relay4" and fuse and n == 10_000_000 and args.mirrors == 4:
+                # the kernel's OTHER roof: SQ counters of this very workload and BUILD (tools/prof_sq.sh + summarize_sq.py)
+                import glob
+                for sq in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_relay4_sq.json")), reverse=True):
+                    jsq = json.load(open(sq))
+                    if jsq.get("source_hash") == res["roofline"]["source_hash"]:
+                        jsq.pop("counters", None)
+                        res["roofline"]["second_bound"] = dict(jsq, source=os.path.relpath(sq, ROOT))
+                        break
             if readout_ms is None:
                 res["roofline_readout"] = {
                     "fused": True, "kernel": res["roofline"]["kernel"],
@@ -689,7 +775,7 @@ def worker(args):
                             "24 B/ray of outputs and the per-workgroup partial statistics are part of that kernel's "
                             "traffic and time; `--readout separate` launches k_detector_readout instead"}
             else:
-                tro = profiled_traffic(pkey, "k_detector_readout", n)
+                tro, _ = profiled_traffic(pkey, "k_detector_readout", n)
                 algo_ro = ALGO_BYTES_READOUT * n / (readout_ms * 1e-3) / 1e9
                 counted_ro = None if tro is None else tro[0] / (readout_ms * 1e-3) / 1e9
                 res["roofline_readout"] = {

@@ -13,12 +13,46 @@ import csv
 import glob
 import json
 import os
+import re
+import subprocess
 import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from source_hash import source_hash  # noqa: E402
+
+
+def code_object_registers():
+    """{kernel: (next_free_vgpr, next_free_sgpr, LDS bytes, scratch bytes)} from the compiler's metadata of the tree's
+    sources (hipcc -S, no GPU needed).  rocprofv3's VGPR_Count column is NOT the allocation (it printed 48 for the
+    92-VGPR fused kernel): the tables below quote the code object."""
+    src = os.path.join(ROOT, "attosecondraytracing_amd", "csrc", "art_kernels.hip")
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "art.s")
+            subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, src],
+                                  stderr=subprocess.DEVNULL)
+            s = open(out).read()
+    except Exception:
+        return {}
+    res = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", s, re.S):
+        g = lambda key: int(re.search(r"\.amdhsa_%s (\d+)" % key, m.group(2)).group(1))
+        dem = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
+        res[short(dem)] = (g("next_free_vgpr"), g("next_free_sgpr"), g("group_segment_fixed_size"), g("private_segment_fixed_size"))
+    return res
 
 
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     return name.split("(")[0]
+
+
+def profiled_hash(src):
+    """The hash tools/prof.sh recorded on the GPU box beside the passes (the build that ran); the tree's otherwise."""
+    f = os.path.join(src, "source_hash.txt")
+    return open(f).read().strip() if os.path.exists(f) else source_hash()
 
 
 def main():
@@ -46,8 +80,11 @@ def main():
     for r in rows:
         byk[short(r["Kernel_Name"])].append((int(r["Grid_Size_X"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]),
                                             r.get("VGPR_Count", ""), r.get("SGPR_Count", ""), r.get("LDS_Block_Size", "")))
+    regs = code_object_registers()
     out += ["## kernel trace (`rocprofv3 --kernel-trace --stats`), full-size launches only", "",
-            "| kernel | launches | avg us | min us | max us | grid threads | VGPR | SGPR | LDS B |", "|---|---:|---:|---:|---:|---:|---:|---:|---:|"]
+            "(VGPR / SGPR / LDS / scratch: `next_free_vgpr` etc. of the code object built from these sources, source hash "
+            + profiled_hash(src) + "; rocprofv3's own VGPR_Count column is not the allocation)", "",
+            "| kernel | launches | avg us | min us | max us | grid threads | VGPR | SGPR | LDS B | scratch B |", "|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|"]
     tot = 0
     stat = {}
     for k, v in sorted(byk.items(), key=lambda kv: -sum(x[1] for x in kv[1])):
@@ -57,7 +94,8 @@ def main():
         stat[k] = (len(d), sum(d) / len(d))
         if sum(d) < 20000:
             continue
-        out.append(f"| {k} | {len(d)} | {sum(d)/len(d)/1e3:.1f} | {min(d)/1e3:.1f} | {max(d)/1e3:.1f} | {g} | {big[0][2]} | {big[0][3]} | {big[0][4]} |")
+        rg = regs.get(k, ("?", "?", big[0][4], "?"))
+        out.append(f"| {k} | {len(d)} | {sum(d)/len(d)/1e3:.1f} | {min(d)/1e3:.1f} | {max(d)/1e3:.1f} | {g} | {rg[0]} | {rg[1]} | {rg[2]} | {rg[3]} |")
     out.append("")
     # the timed steps of bench.py are the LAST `steps` launches of the trace kernel (the ones before are scene set-up
     # and warm-up): their average is what bench.py's roofline.kernel_ms measures with HIP events
@@ -107,8 +145,15 @@ def main():
     out.append("")
     traffic = {k: {"read_bytes": 2.0 * fe[k], "write_bytes": wr.get(k, 0.0), "total_bytes": 2.0 * fe[k] + wr.get(k, 0.0),
                    "avg_us_trace_pass": stat[k][1] / 1e3} for k in fe if k in stat and fe[k] + wr.get(k, 0) >= 5e6}
+    box = None
+    bs = os.path.join(src, "box_state.txt")
+    if os.path.exists(bs):
+        out += ["## box state (tools/box_state.sh, before the passes)", "", "```"] + [l.rstrip() for l in open(bs) if re.search(
+            r"clock level|Power|Partition|MAX_CLK|SOCKET_POWER|MEM_|mclk|fclk|IFWI|VERSION: 0", l)][:40] + ["```", ""]
+        box = os.path.basename(bs)
     json.dump({"source": os.path.basename(src), "rays_per_gpu": n, "fetch_calibration": cal_r, "write_calibration": cal_w,
-               "per_launch": traffic}, open(os.path.splitext(dst)[0] + ".json", "w"), indent=1)
+               "source_hash": profiled_hash(src), "source_hash_files": "csrc/art_device.h, art_kernels.hip, art_scene.h, include/art_hip.h",
+               "box_state": box, "per_launch": traffic}, open(os.path.splitext(dst)[0] + ".json", "w"), indent=1)
     open(dst, "w").write("\n".join(out) + "\n")
     print("\n".join(out))
 
