@@ -264,11 +264,16 @@ class DeformedMirror(_Mirror):
         self.DeformationList = list(DeformationList)
         self.type = Mirror.type
         self.support = self.Mirror.support
-        if len(self.DeformationList) > _abi.ART_MAX_DEFECTS:
-            raise NotImplementedError(f"at most {_abi.ART_MAX_DEFECTS} defects per mirror are supported")
         for d in self.DeformationList:
             if not (hasattr(d, "_abi_table") or hasattr(d, "_abi_grid")):
                 raise NotImplementedError(f"defect type {type(d).__name__} has no device implementation yet")
+        # Any number of Zernike defects: offsets and slopes of defects with the same normalisation radius add up
+        # (ART/ModuleMirror.py:952-980), so they are merged into ONE table per radius (_zernike_groups).  What stays
+        # limited is the number of tables per mirror: distinct radii, and gridded height maps.
+        if len(self._zernike_groups()) > _abi.ART_MAX_DEFECTS:
+            raise NotImplementedError(f"Zernike defects with more than {_abi.ART_MAX_DEFECTS} different normalisation radii on one mirror")
+        if len(self._grid_defects()) > _abi.ART_MAX_DEFECTS:
+            raise NotImplementedError(f"at most {_abi.ART_MAX_DEFECTS} gridded defects per mirror are supported")
 
     @property
     def _abi_kind(self):
@@ -283,8 +288,24 @@ class DeformedMirror(_Mirror):
     def _grid_defects(self):
         return [d for d in self.DeformationList if hasattr(d, "_abi_grid")]
 
+    def _zernike_groups(self):
+        """{R: summed coefficient dict} of the Zernike defects, by normalisation radius, in order of first appearance."""
+        groups = {}
+        for d in self._zernike_defects():
+            g = groups.setdefault(float(d.R), {})
+            for k, c in d.coefficients.items():
+                g[k] = g.get(k, 0.0) + c
+        return groups
+
     def _abi_defect_table(self):
-        return np.concatenate([d._abi_table() for d in self._zernike_defects()])
+        """(device table of all Zernike groups, number of tables, recurrence layout?) -- see ModuleDefects.zernike_table.
+        One group above order 16 puts all of the mirror's tables into the recurrence layout, padded to one order."""
+        from .ModuleDefects import zernike_table
+        groups = self._zernike_groups()
+        top = max(max(k[0] for k in g) for g in groups.values())
+        rec = top > _abi.ART_ZERN_MAX_ORDER
+        return (np.concatenate([zernike_table(R, g, recurrence=rec, order=max(2, top)) for R, g in groups.items()]),
+                len(groups), rec)
 
     def get_normal(self, PointMirror):
         """Normal of the deformed surface at ONE point, host side (ART/ModuleMirror.py:952-961): the base normal

@@ -80,10 +80,13 @@ def _build_descriptor(oe, IgnoreDefects, backend):
             # same outcome as the reference: DeformedMirror.get_normal -> Fourrier.get_normal raises
             grids[0].get_normal(None)
         if zern:
-            t = be.from_numpy(optic._abi_defect_table())
+            table, n_tables, recurrence = optic._abi_defect_table()
+            t = be.from_numpy(table)
             keep.append(t)
             d.zern = t.data_ptr()
-            d.n_defects = len(zern)
+            d.n_defects = n_tables
+            if recurrence:
+                d.flags |= _abi.ART_FLAG_ZERN_RECURRENCE
         if grids:
             arr = (_abi.ArtGridDefect * len(grids))()
             rect = np.asarray(optic.support._CircumRect(), dtype=float)
@@ -105,7 +108,7 @@ def _build_descriptor(oe, IgnoreDefects, backend):
             d.grid = t.data_ptr()
             d.n_grid = len(grids)
         if not IgnoreDefects:
-            d.flags = _abi.ART_FLAG_PERTURBED_NORMAL
+            d.flags |= _abi.ART_FLAG_PERTURBED_NORMAL
     return d, keep
 
 
@@ -153,6 +156,8 @@ def RayTracingCalculation(source_rays, optical_elements, IgnoreDefects=True, mod
         descs.append(d)
         keep.append(k)
     mode = mode or DEFAULT_TRACE_MODE
+    if any(d.flags & _abi.ART_FLAG_ZERN_RECURRENCE for d in descs):
+        mode = "element"      # Zernike orders above 16 run the recurrences per ray: a kernel of its own, one element per launch
     bad = next((k for k, d in enumerate(descs) if d.nonfinite), None)
     if bad is not None:
         # The reference meets a mirror with NaN/inf parameters in np.roots (ART/ModuleGeometry.py:84, :99), which
@@ -236,7 +241,8 @@ def RayTracingCalculationMany(source_rays_list, optical_elements_list, IgnoreDef
             descs.append(d)
             keep.append(k)
     uniform = (m > 0 and n > 0 and all(len(els) == m for els in optical_elements_list)
-               and all(s.n_slots == n and s.backend is be for s in sources) and not any(d.nonfinite for d in descs))
+               and all(s.n_slots == n and s.backend is be for s in sources) and not any(d.nonfinite for d in descs)
+               and not any(d.flags & _abi.ART_FLAG_ZERN_RECURRENCE for d in descs))
     if detectors is not None and len(detectors) != c:
         raise ValueError("need one detector per chain")
     # Common prefix: a loop list varies ONE entry of one list (OEPlacement), so its chains start from equal sources and

@@ -15,6 +15,8 @@ ART_PLANE, ART_SPHERE, ART_PARABOLA, ART_TORUS, ART_ELLIPSOID, ART_CYLINDER, ART
 ART_SUP_ROUND, ART_SUP_ROUNDHOLE, ART_SUP_RECT, ART_SUP_RECTHOLE, ART_SUP_RECTRECTHOLE = range(5)
 
 ART_FLAG_PERTURBED_NORMAL = 1
+ART_FLAG_ZERN_RECURRENCE = 2
+ART_ZERN_RECURRENCE_MAX_ORDER = 64
 
 ART_ZERN_MAX_ORDER = 16
 ART_ZERN_DIM = ART_ZERN_MAX_ORDER + 1

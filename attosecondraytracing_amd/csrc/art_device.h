@@ -345,6 +345,73 @@ ART_HD void zernike_slopes(TP tab, double px, double py, double& gX, double& gY)
   return zernike_slopes_t<16>(tab, px, py, gX, gY);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Zernike surfaces of ANY order (ART_FLAG_ZERN_RECURRENCE; orders above ART_ZERN_MAX_ORDER): the Cartesian recurrences of
+// ART/recursive_zernike_generator.py:51-246 themselves, per ray.  The monomial expansion the Horner evaluators above use
+// is exact but ill-conditioned (integer coefficients reach 1e8 at order 20 and 5e17 at order 40, i.e. 4e-10 and 1e-2 of
+// cancellation error relative to the polynomial), the recurrences are stable (3e-15 at order 40).  Row n needs rows
+// n - 1 and n - 2 of the values and, for the derivatives, row n - 2 of each derivative: three rotating rows of
+// Z, dZ/dx, dZ/dy live in per-lane arrays (private memory on the GPU: this path has its own kernel, so that the
+// register-resident kernels stay free of scratch).  Table layout (include/art_hip.h): [R, N, c(0,0), c(1,0), c(1,1),
+// c(2,0), ...] with c(n, m) at 2 + n (n + 1) / 2 + m, absent terms 0.
+#define ART_ZGEN_MAX_ORDER 64
+ART_HD constexpr int zgen_stride(int N) { return 2 + (N + 1) * (N + 2) / 2; }
+
+ART_HD void zernike_recurrence(const double* tab, double px, double py, bool want_grad, double& h, double& gX, double& gY) {
+  const int N = (int)tab[1];
+  const double iR = 1.0 / tab[0];
+  const double x = px * iR, y = py * iR;
+  const double* c = tab + 2;
+  double Z[3][ART_ZGEN_MAX_ORDER + 1], GX[3][ART_ZGEN_MAX_ORDER + 1], GY[3][ART_ZGEN_MAX_ORDER + 1];
+  // rows 0 and 1 (:51-62)
+  Z[0][0] = 1.0; GX[0][0] = 0.0; GY[0][0] = 0.0;
+  Z[1][0] = y; GX[1][0] = 0.0; GY[1][0] = 1.0;
+  Z[1][1] = x; GX[1][1] = 1.0; GY[1][1] = 0.0;
+  double s = c[0] + c[1] * y + c[2] * x, sx = c[2], sy = c[1];
+  for (int n = 2; n <= N; ++n) {
+    const int a = n % 3, b = (n + 2) % 3, d = (n + 1) % 3;      // rows n, n - 1, n - 2
+    const double* Zb = Z[b];
+    const double* Zd = Z[d];
+    const double fn = (double)n;
+    const double* cn = c + n * (n + 1) / 2;
+    for (int m = 0; m <= n; ++m) {
+      double z, gx, gy;
+      if (m == 0) {                                  // :79-95
+        z = x * Zb[0] + y * Zb[n - 1];
+        gx = fn * Zb[0];
+        gy = fn * Zb[n - 1];
+      } else if (m == n) {                           // :97-110
+        z = x * Zb[n - 1] - y * Zb[0];
+        gx = fn * Zb[n - 1];
+        gy = -1.0 * fn * Zb[0];
+      } else if ((n & 1) && 2 * m == n - 1) {        // :112-145
+        z = y * Zb[n - 1 - m] + x * Zb[m - 1] - y * Zb[n - m] - Zd[m - 1];
+        gx = fn * Zb[m - 1] + GX[d][m - 1];
+        gy = fn * Zb[n - 1 - m] - fn * Zb[n - m] + GY[d][m - 1];
+      } else if ((n & 1) && 2 * m == n + 1) {        // :147-177
+        z = x * Zb[m] + y * Zb[n - 1 - m] + x * Zb[m - 1] - Zd[m - 1];
+        gx = fn * Zb[m] + fn * Zb[m - 1] + GX[d][m - 1];
+        gy = fn * Zb[n - 1 - m] + GY[d][m - 1];
+      } else if (!(n & 1) && 2 * m == n) {           // :179-209
+        z = 2.0 * x * Zb[m] + 2.0 * y * Zb[m - 1] - Zd[m - 1];
+        gx = 2.0 * fn * Zb[m] + GX[d][m - 1];
+        gy = 2.0 * fn * Zb[n - 1 - m] + GY[d][m - 1];
+      } else {                                       // :211-246
+        z = x * Zb[m] + y * Zb[n - 1 - m] + x * Zb[m - 1] - y * Zb[n - m] - Zd[m - 1];
+        gx = fn * Zb[m] + fn * Zb[m - 1] + GX[d][m - 1];
+        gy = fn * Zb[n - 1 - m] - fn * Zb[n - m] + GY[d][m - 1];
+      }
+      Z[a][m] = z; GX[a][m] = gx; GY[a][m] = gy;
+      const double cm = cn[m];
+      s = fma(cm, z, s);
+      if (want_grad) { sx = fma(cm, gx, sx); sy = fma(cm, gy, sy); }
+    }
+  }
+  h = s;
+  gX = sx * iR;
+  gY = sy * iR;
+}
+
 // Gridded height map: bilinear lookup (ART/ModuleDefects.py:131-137; SciPy RegularGridInterpolator, linear)
 ART_HD double grid_offset(const ArtGridDefect& g, double px, double py) {
   // Cell coordinates clamped to the grid BEFORE the integer conversion (a NaN or huge coordinate must not reach the
@@ -694,7 +761,7 @@ ART_HD void base_normal_k(const ArtElementDesc& e, double x, double y, double z,
 // Returns false when the ray is lost (missed the optic / blocked by the mask).
 // `zern`: the element's dense Zernike tables (n_defects x ART_ZERN_STRIDE doubles) -- e.zern itself (device memory,
 // read through scalar loads) or, in the -DART_ZERN_LDS build, their copy in LDS.
-template <int KIND, bool DEFECT>
+template <int KIND, bool DEFECT, bool ZGEN = false>
 ART_HD bool trace_ray(const ArtElementDesc& e, const double* zern, Ray& r) {
   // lab -> optic frame (:289-295)
   double Ax, Ay, Az, ux, uy, uz;
@@ -721,8 +788,17 @@ ART_HD bool trace_ray(const ArtElementDesc& e, const double* zern, Ray& r) {
       // DeformedMirror._get_intersection, ModuleMirror.py:969-980: slide the hit point along the ray by
       // h / cos(alpha), h = summed defect offsets at (P - centre), alpha = angle(-u, base normal)
       double h = 0.0;
-      for (int d = 0; d < e.n_defects; ++d)
-        h += zernike_offset(ART_ZUNI(zern + d * ART_ZERN_STRIDE), Px - e.centre[0], Py - e.centre[1]);
+      if (ZGEN) {       // tables in the recurrence layout, all of one order (padded by the host)
+        const int zs = zgen_stride((int)zern[1]);
+        for (int d = 0; d < e.n_defects; ++d) {
+          double hd, g1, g2;
+          zernike_recurrence(zern + d * zs, Px - e.centre[0], Py - e.centre[1], false, hd, g1, g2);
+          h += hd;
+        }
+      } else {
+        for (int d = 0; d < e.n_defects; ++d)
+          h += zernike_offset(ART_ZUNI(zern + d * ART_ZERN_STRIDE), Px - e.centre[0], Py - e.centre[1]);
+      }
       for (int d = 0; d < e.n_grid; ++d) h += grid_offset(e.grid[d], Px - e.centre[0], Py - e.centre[1]);
       const double cosa = -dot3(ux, uy, uz, nx, ny, nz);
       const double s = div_full(h, cosa);
@@ -736,7 +812,12 @@ ART_HD bool trace_ray(const ArtElementDesc& e, const double* zern, Ray& r) {
         double gXs = -nx * inz, gYs = -ny * inz;
         for (int d = 0; d < e.n_defects; ++d) {
           double gX, gY;
-          zernike_slopes(ART_ZUNI(zern + d * ART_ZERN_STRIDE), Px - e.centre[0], Py - e.centre[1], gX, gY);
+          if (ZGEN) {
+            double hd;
+            zernike_recurrence(zern + d * zgen_stride((int)zern[1]), Px - e.centre[0], Py - e.centre[1], true, hd, gX, gY);
+          } else {
+            zernike_slopes(ART_ZUNI(zern + d * ART_ZERN_STRIDE), Px - e.centre[0], Py - e.centre[1], gX, gY);
+          }
           gXs += gX; gYs += gY;
         }
         const double inv = rsqrt_full(fma(gXs, gXs, fma(gYs, gYs, 1.0)));
@@ -773,6 +854,10 @@ ART_HD bool trace_ray(const ArtElementDesc& e, const double* zern, Ray& r) {
 // has to satisfy six inlined copies of the unrolled Zernike evaluators at once.
 template <bool DEFECT>
 ART_HD bool trace_ray_dyn(const ArtElementDesc& e, const double* zern, Ray& r) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+  // (host twin: one entry point for everything; on the device the recurrence path has its own kernel)
+  if (DEFECT && (e.flags & ART_FLAG_ZERN_RECURRENCE)) return trace_ray<ART_KIND_DYN, true, true>(e, zern, r);
+#endif
   if (DEFECT) return trace_ray<ART_KIND_DYN, true>(e, zern, r);
   switch (e.kind) {
     case ART_PLANE: return trace_ray<ART_PLANE, false>(e, zern, r);

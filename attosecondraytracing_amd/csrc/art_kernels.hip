@@ -423,6 +423,24 @@ __global__ __launch_bounds__(kBlock) void k_trace_element(const ElemArg ea, cons
   } while (DEFECT && kDefectLoop && i < n);
 }
 
+// Elements whose Zernike tables are in the recurrence layout (ART_FLAG_ZERN_RECURRENCE: orders above 16): the
+// reference's recurrences per ray, three rotating rows of values and derivatives in per-lane arrays (private memory).
+// A kernel of its own, so that the register-resident kernels above stay free of scratch; any optic kind (run-time
+// switch), one ray per thread.
+__global__ __launch_bounds__(kBlock) void k_trace_element_zrec(const ElemArg ea, const ArtBundleView in,
+                                                               const ArtBundleView out, const int64_t n) {
+  const ArtElementDesc& e = ea.e[blockIdx.y];
+  const BundleRsrc bi = make_rsrc(in, n), bo = make_rsrc(out, n);
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  art::Ray r;
+  r.inc = 0.0;
+  uint8_t a;
+  load_slot(bi, i, r, a);
+  bool ok = a != 0;
+  if (ok) ok = art::trace_ray<ART_KIND_DYN, true, true>(e, e.zern, r);
+  store_slot(bo, i, r, ok);
+}
+
 using art::ChainArgs;
 using art::kChainMax;
 
@@ -593,6 +611,94 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
   } while (DEFECT && kDefectLoop && i0 < n);
 }
 
+// ---- two rays per lane (round-3 experiment, ART_CHAIN_RPL=2) -----------------------------------------------------------
+// A lane owns the two NEIGHBOURING slots 2p, 2p + 1: every stream is then read and written with 16 bytes per lane (1 KiB
+// per wave instruction) straight from registers -- no LDS staging tile, no workgroup barrier between the elements (the
+// one-ray-per-lane body needs two per element to regroup its 8-byte values into 16-byte stores), per-row descriptors and
+// hardware range checks as before (a pair of dead rays is dropped by its offset, the odd tail by the per-dword check).
+// The two rays of a lane are traced one after the other; a wave carries 128 rays.
+template <bool DEFECT>
+__device__ __forceinline__ void chain_body2(const ChainArgs& a, const int64_t first, const int64_t n, const int xmap) {
+  __shared__ double s_w[2][kBlock];   // per-lane parking slots of the two weights (no barrier: a lane reads what it wrote)
+  __shared__ __attribute__((aligned(16))) double s_red[(kBlock / 64) * 8 * kTileStride];   // wave-private tiles of wave_reduce24
+  __shared__ double s_part[kBlock / 64][kReadoutSlots];
+  const int64_t tile = tile_of(blockIdx.x, gridDim.x, xmap);
+  const BundleRsrc bi = make_rsrc(a.in, n, first);
+  unsigned pair = (unsigned)(tile * kBlock + threadIdx.x);
+  asm volatile("" : "+v"(pair));                      // ONE register identifies the lane (see chain_body)
+  const unsigned lane = pair & (kBlock - 1);
+  const unsigned o16 = pair * 16u, o2 = pair * 2u;
+  art::Ray r[2];
+  bool ok[2];
+  {
+    const D2 ox = ld_2f64(bi.ox, o16), oy = ld_2f64(bi.oy, o16), oz = ld_2f64(bi.oz, o16);
+    const D2 dx = ld_2f64(bi.dx, o16), dy = ld_2f64(bi.dy, o16), dz = ld_2f64(bi.dz, o16);
+    const D2 pa = ld_2f64(bi.path, o16);
+    // two byte loads: a 16-bit load straddling the end of an odd-length array is dropped as a whole
+    ok[0] = __builtin_amdgcn_raw_buffer_load_b8(bi.alive, (int)o2, 0, ART_LD_AUX) != 0;
+    ok[1] = __builtin_amdgcn_raw_buffer_load_b8(bi.alive, (int)o2 + 1, 0, ART_LD_AUX) != 0;
+    const D2 wv = ld_2f64(rsrc_of(const_cast<double*>(a.ro.w) + first,
+                                  ((a.flags & art::kFlagReadout) && a.ro.w) ? (unsigned)(n * 8) : 0u), o16);
+    s_w[0][lane] = wv.a; s_w[1][lane] = wv.b;
+    r[0].ox = ox.a; r[0].oy = oy.a; r[0].oz = oz.a; r[0].dx = dx.a; r[0].dy = dy.a; r[0].dz = dz.a; r[0].path = pa.a;
+    r[1].ox = ox.b; r[1].oy = oy.b; r[1].oz = oz.b; r[1].dx = dx.b; r[1].dy = dy.b; r[1].dz = dz.b; r[1].path = pa.b;
+    r[0].inc = 0.0; r[1].inc = 0.0;
+  }
+  int k = 0;
+  do {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      if (ok[h]) ok[h] = art::trace_ray_dyn<DEFECT>(a.e[k], a.e[k].zern, r[h]);
+    const ArtBundleView& v = a.out[k];
+    const unsigned nb = (unsigned)(v.alive != nullptr ? n : 0);     // no history view: every store is dropped
+    const unsigned off = (ok[0] || ok[1]) ? o16 : kDropOffset;
+    st_2f64(rsrc_of(v.ox + first, nb * 8u), off, r[0].ox, r[1].ox);
+    st_2f64(rsrc_of(v.oy + first, nb * 8u), off, r[0].oy, r[1].oy);
+    st_2f64(rsrc_of(v.oz + first, nb * 8u), off, r[0].oz, r[1].oz);
+    st_2f64(rsrc_of(v.dx + first, nb * 8u), off, r[0].dx, r[1].dx);
+    st_2f64(rsrc_of(v.dy + first, nb * 8u), off, r[0].dy, r[1].dy);
+    st_2f64(rsrc_of(v.dz + first, nb * 8u), off, r[0].dz, r[1].dz);
+    st_2f64(rsrc_of(v.path + first, nb * 8u), off, r[0].path, r[1].path);
+    st_2f64(rsrc_of(v.incidence + first, nb * 8u), off, r[0].inc, r[1].inc);
+    const __amdgpu_buffer_rsrc_t ra = rsrc_of(v.alive + first, nb);
+    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(ok[0] ? 1 : 0), ra, (int)o2, 0, ART_ST_AUX);
+    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(ok[1] ? 1 : 0), ra, (int)o2 + 1, 0, ART_ST_AUX);
+  } while (++k < a.n_elems);
+  if (a.flags & art::kFlagReadout) {
+    double acc[kReadoutSlots];
+    double Ix, Iy, Iz, x[2] = {0.0, 0.0}, y[2] = {0.0, 0.0}, o[2] = {0.0, 0.0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      if (ok[h]) art::detector_ray(a.ro.det, r[h], Ix, Iy, Iz, x[h], y[h], o[h]);
+    const unsigned nb8 = (unsigned)(n * 8);
+    const unsigned off = (ok[0] || ok[1]) ? o16 : kDropOffset;
+    st_2f64(rsrc_of(a.ro.X + first, a.ro.X ? nb8 : 0u), off, x[0], x[1]);
+    st_2f64(rsrc_of(a.ro.Y + first, a.ro.Y ? nb8 : 0u), off, y[0], y[1]);
+    st_2f64(rsrc_of(a.ro.opl + first, a.ro.opl ? nb8 : 0u), off, o[0], o[1]);
+    const unsigned li = lane ^ ((unsigned)a.flags >> 30);     // an index the compiler cannot prove equal to the parking one
+    readout_single(acc, ok[0], x[0], y[0], o[0], s_w[0][li], a.ro.w != nullptr, a.ro.cx, a.ro.cy, a.ro.co);
+    readout_accumulate(acc, ok[1], x[1], y[1], o[1], s_w[1][li], a.ro.w != nullptr, a.ro.cx, a.ro.cy, a.ro.co);
+    double tot[3];
+    wave_reduce24(acc, s_red + (lane >> 6) * (8 * kTileStride), lane & 63, tot);
+    if ((lane & 7) == 0) {
+      const int stat = (lane & 63) >> 3, w = lane >> 6;
+      s_part[w][stat] = tot[0];
+      s_part[w][8 + stat] = tot[1];
+      if (stat < 6) s_part[w][16 + stat] = tot[2];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (lane < kUsedSlots) {
+      double t = s_part[0][lane];
+#pragma unroll
+      for (int j = 1; j < kBlock / 64; ++j) {
+        const double q = s_part[j][lane];
+        t = (lane < 16) ? t + q : (lane < 19 ? fmin(t, q) : fmax(t, q));
+      }
+      a.ro.scratch[(int64_t)lane * gridDim.x + blockIdx.x] = t;
+    }
+  }
+}
+
 // Fold of the fused read-out's per-WORKGROUP partials (row-major: scratch[row_of_slot(slot) * nparts + part], 39 063
 // parts per 1e7 rays), always in a fixed order (deterministic).  ONE launch up to kFoldDirect partials (1.67e7 rays):
 // a 1024-thread workgroup per statistic folds its whole row (312 KB at 1e7 rays: thread t takes parts t, t + 1024, ...,
@@ -691,6 +797,17 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain(const ChainArgs, 
   // whole 3.3 KB copied to scratch at entry and 452 vector loads from there.
   typedef const ChainArgs __attribute__((address_space(4)))* kernarg_t;
   chain_body<DEFECT>(*(const ChainArgs*)(kernarg_t)__builtin_amdgcn_kernarg_segment_ptr(), 0, n, xmap, s_dyn);
+}
+
+template <bool DEFECT, int WAVES>
+__global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain2(const ChainArgs, const int64_t n, const int xmap) {
+  typedef const ChainArgs __attribute__((address_space(4)))* kernarg_t;
+  chain_body2<DEFECT>(*(const ChainArgs*)(kernarg_t)__builtin_amdgcn_kernarg_segment_ptr(), 0, n, xmap);
+}
+template <bool DEFECT, int WAVES>
+__global__ __launch_bounds__(kBlock, WAVES) void k_trace_scene2(const ChainArgs* __restrict__ tab, const int64_t first,
+                                                                const int64_t n, const int xmap) {
+  chain_body2<DEFECT>(tab[blockIdx.y], first, n, xmap);
 }
 
 // Many chains in one launch: blockIdx.y = chain, descriptors in the device-resident scene table (art_scene.h).
@@ -1218,6 +1335,7 @@ int check_elem(const ArtElementDesc* e) {
   if (e->n_grid < 0 || e->n_grid > ART_MAX_DEFECTS) return fail(ART_ERR_UNSUPPORTED, "too many gridded defects on one mirror");
   if (e->n_grid > 0 && e->kind == ART_MASK) return fail(ART_ERR_BAD_ARG, "a mask cannot carry defects");
   if (e->n_grid > 0 && !e->grid) return fail(ART_ERR_BAD_ARG, "n_grid > 0 but grid table is NULL");
+  if ((e->flags & ART_FLAG_ZERN_RECURRENCE) && e->n_defects == 0) return fail(ART_ERR_BAD_ARG, "recurrence flag without Zernike tables");
   return ART_OK;
 }
 
@@ -1273,6 +1391,12 @@ int art_trace_element(const ArtElementDesc* e, const ArtBundleView* in, const Ar
   for (int64_t off = 0; off < n; off += chunk) {
     const int64_t m = (n - off < chunk) ? n - off : chunk;
     const ArtBundleView vi = view_at(*in, off), vo = view_at(*out, off);
+    if (ec.flags & ART_FLAG_ZERN_RECURRENCE) {
+      ElemArg ea;
+      ea.e[0] = ec;
+      hipLaunchKernelGGL(k_trace_element_zrec, dim3(grid_stream(m)), dim3(kBlock), 0, s, ea, vi, vo, m);
+      continue;
+    }
     switch (ec.kind) {
       case ART_PLANE: launch_element<ART_PLANE>(ec, vi, vo, m, s); break;
       case ART_SPHERE: launch_element<ART_SPHERE>(ec, vi, vo, m, s); break;
@@ -1317,6 +1441,14 @@ inline int chain_waves() {
   const char* wv = getenv("ART_CHAIN_WAVES");
   return wv ? atoi(wv) : 5;
 }
+// ART_CHAIN_RPL=2: the two-rays-per-lane body (chain_body2) for chains without defects
+inline int chain_rpl() {
+  static const int v = [] {
+    const char* e = getenv("ART_CHAIN_RPL");
+    return (e && atoi(e) == 2) ? 2 : 1;
+  }();
+  return v;
+}
 // ART_CHAIN_DYN_LDS=<bytes>: unused dynamic LDS per workgroup of the fused kernel, i.e. FEWER resident workgroups per CU
 // (20 KB static + 20480 -> 4, + 33000 -> 3).  An experiment knob: the bare access pattern gains 3-7 % of bandwidth with 2-3
 // instead of 8 workgroups per CU (tools/stream_floor.hip); the kernel needs its waves to hide latency.
@@ -1339,6 +1471,8 @@ static int trace_chain_impl(const ArtElementDesc* elems, int32_t n_elems, const 
   for (int k = 0; k < n_elems; ++k) {
     int rc = check_elem(&elems[k]);
     if (rc) return rc;
+    if (elems[k].flags & ART_FLAG_ZERN_RECURRENCE)
+      return fail(ART_ERR_UNSUPPORTED, "an element carries Zernike tables in the recurrence layout: trace it with art_trace_element");
   }
   hipStream_t s = (hipStream_t)stream;
   if (ro) {
@@ -1396,10 +1530,17 @@ static int trace_chain_impl(const ArtElementDesc* elems, int32_t n_elems, const 
       if (lds > 64 * 1024) return fail(ART_ERR_UNSUPPORTED, "ART_ZERN_LDS build: Zernike tables of one fused launch exceed 64 KiB");
 #endif
       const int xm = xcd_map();
-      const dim3 g(grid_stream_mapped(cnt, xm)), b(kBlock);
+      const bool two = chain_rpl() == 2 && !(a.flags & art::kFlagDefects);
+      const dim3 g(grid_stream_mapped(two ? (cnt + 1) / 2 : cnt, xm)), b(kBlock);
       if (a.flags & art::kFlagDefects)
         hipLaunchKernelGGL((k_trace_chain<true, 4>), dim3(kDefectLoop ? grid_for(cnt) : grid_stream_mapped(cnt, xm)), b, lds,
                            s, a, cnt, kDefectLoop ? 0 : xm);
+      else if (two && waves == 5)
+        hipLaunchKernelGGL((k_trace_chain2<false, 5>), g, b, chain_dyn_lds(), s, a, cnt, xm);
+      else if (two && waves == 3)
+        hipLaunchKernelGGL((k_trace_chain2<false, 3>), g, b, chain_dyn_lds(), s, a, cnt, xm);
+      else if (two)
+        hipLaunchKernelGGL((k_trace_chain2<false, 4>), g, b, chain_dyn_lds(), s, a, cnt, xm);
       else if (waves == 6)
         hipLaunchKernelGGL((k_trace_chain<false, 6>), g, b, chain_dyn_lds(), s, a, cnt, xm);
       else
@@ -1477,11 +1618,16 @@ int art_trace_scene(const void* image_dev, const void* image_host, int64_t n, vo
   for (int64_t off = 0; off < n; off += chunk) {
     const int64_t cnt = (n - off < chunk) ? n - off : chunk;
     const int xm = xcd_map();
-    const dim3 g(grid_stream_mapped(cnt, xm), n_chains), b(kBlock);
+    const bool two = chain_rpl() == 2 && !(flags & 1);
+    const dim3 g(grid_stream_mapped(two ? (cnt + 1) / 2 : cnt, xm), n_chains), b(kBlock);
     for (int sg = 0; sg < S; ++sg) {
       const ChainArgs* seg = tab + (int64_t)sg * n_chains;
       if (flags & 1)
         hipLaunchKernelGGL((k_trace_scene<true, 4>), g, b, 0, s, seg, off, cnt, xm);
+      else if (two && waves == 5)
+        hipLaunchKernelGGL((k_trace_scene2<false, 5>), g, b, 0, s, seg, off, cnt, xm);
+      else if (two)
+        hipLaunchKernelGGL((k_trace_scene2<false, 4>), g, b, 0, s, seg, off, cnt, xm);
       else if (waves == 6)
         hipLaunchKernelGGL((k_trace_scene<false, 6>), g, b, 0, s, seg, off, cnt, xm);
       else

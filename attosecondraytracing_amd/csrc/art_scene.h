@@ -88,6 +88,7 @@ inline int scene_pack(const ArtElementDesc* elems, int n_chains, int n_elems, co
         }
         if ((e.n_defects > 0 || e.n_grid > 0) && e.kind == ART_MASK) { *err = "a mask cannot carry defects"; return ART_ERR_BAD_ARG; }
         if ((e.n_defects > 0 && !e.zern) || (e.n_grid > 0 && !e.grid)) { *err = "defect count > 0 but its table is NULL"; return ART_ERR_BAD_ARG; }
+        if (e.flags & ART_FLAG_ZERN_RECURRENCE) { *err = "an element carries Zernike tables in the recurrence layout: trace it with art_trace_element"; return ART_ERR_UNSUPPORTED; }
         a.e[k] = e;
         prepare_element(a.e[k]);
         if (e.n_defects > 0 || e.n_grid > 0) { a.flags |= kFlagDefects; h.flags |= kFlagDefects; }

@@ -132,7 +132,8 @@ class SceneProgram:
         if len(element_lists) != self.c or any(len(e) != self.m for e in element_lists):
             return False
         descs = [self._mp.element_descriptor(oe, self.IgnoreDefects, self.be)[0] for els in element_lists for oe in els]
-        return self._structure(element_lists, descs) == self._signature and not any(d.nonfinite for d in descs)
+        return (self._structure(element_lists, descs) == self._signature
+                and not any(d.nonfinite or (d.flags & self._abi.ART_FLAG_ZERN_RECURRENCE) for d in descs))
 
     def update(self, element_lists):
         """New poses / parameters for the same optics: re-pack the table and copy it over the device image."""
@@ -142,6 +143,9 @@ class SceneProgram:
                 d, k = self._mp.element_descriptor(oe, self.IgnoreDefects, self.be)
                 if d.nonfinite:
                     raise ValueError("an element has non-finite parameters")
+                if d.flags & self._abi.ART_FLAG_ZERN_RECURRENCE:
+                    raise ValueError("a Zernike defect above order 16 is traced element by element (RayTracingCalculation): "
+                                     "it cannot be part of a SceneProgram")
                 descs.append(d)
                 keep.append(k)
         sig = self._structure(element_lists, descs)

@@ -57,6 +57,7 @@ enum ArtSupportKind {
 
 /* element flags */
 #define ART_FLAG_PERTURBED_NORMAL 1u /* IgnoreDefects=False: reflect off the defect-perturbed normal (ModuleMirror.py:933-936) */
+#define ART_FLAG_ZERN_RECURRENCE 2u  /* the element's Zernike tables are in the RECURRENCE layout (any order, below)      */
 
 /* Zernike defect table (ART/ModuleDefects.py:149-174), a DEVICE array of doubles per element.  The polynomials
  * of ART/recursive_zernike_generator.py have integer monomial coefficients; the host expands
@@ -69,6 +70,14 @@ enum ArtSupportKind {
  *   [base+2            + p*ART_ZERN_DIM + q] = A[p][q]        coefficient of x^p y^q of h
  *   [base+2 +   DIM^2  + p*ART_ZERN_DIM + q] = dA/dx [p][q]   = (p+1) A[p+1][q]
  *   [base+2 + 2*DIM^2  + p*ART_ZERN_DIM + q] = dA/dy [p][q]   = (q+1) A[p][q+1]                        */
+/* Orders above ART_ZERN_MAX_ORDER (and any order, if the caller prefers): set ART_FLAG_ZERN_RECURRENCE and hand over, per
+ * defect, the coefficients themselves -- [R, N, c(0,0), c(1,0), c(1,1), c(2,0), ...], c(n,m) at 2 + n(n+1)/2 + m, absent
+ * terms 0, every table of one element padded to the same N <= ART_ZERN_RECURRENCE_MAX_ORDER (stride 2 + (N+1)(N+2)/2).
+ * The kernels then run the reference's recurrences per ray (the monomial form is exact but loses 4e-10 of the polynomial
+ * to cancellation at order 20 and everything at order 40; the recurrences stay at 1e-15).  Such elements are traced by
+ * art_trace_element only (a kernel of its own, with per-lane row storage); art_trace_chain / art_scene_pack return
+ * ART_ERR_UNSUPPORTED for them.                                                                                          */
+#define ART_ZERN_RECURRENCE_MAX_ORDER 64
 #define ART_ZERN_MAX_ORDER 16
 #define ART_ZERN_DIM (ART_ZERN_MAX_ORDER + 1)                      /* 17 */
 #define ART_ZERN_STRIDE (2 + 3 * ART_ZERN_DIM * ART_ZERN_DIM)      /* 869 */

@@ -704,3 +704,11 @@ def test_gpu_dropped_store_pairs_touch_nothing(hip):
         lost += int(dead_pair.sum())
         assert bool((b.data[:, dead_pair].view(torch.int64) == sentinel.view(torch.int64)).all()), k
     assert lost > 10_000        # the mask stops a third of the rays: whole pairs among them
+
+
+def test_gpu_zernike_any_order_and_any_number_of_defects(hip):
+    """Order 16 (unrolled Horner tables), orders 20 / 30 / 48 (the recurrence kernel, private-memory rows), a recurrence
+    element inside a chain, seven defects on one mirror: against the oracle and the long-double truth."""
+    import zernike_cases
+    for name, w in zernike_cases.run_high_order().items():
+        report(f"[zernike {name}, local error vs long-double truth] " + "  ".join(f"{k} {v:.1e}" for k, v in w.items()))

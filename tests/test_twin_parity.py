@@ -66,35 +66,12 @@ def test_twin_edge_cases(twin):
 
 
 def test_twin_zernike_high_order_vs_oracle(twin):
-    """Zernike defects up to the kernels' maximum order (16): polynomial-table evaluation vs the oracle's recurrences."""
-    import ART.ModuleDefects as mdef
-    import ART.ModuleMirror as mmirror
-    import ART.ModuleSupport as msupp
-    import ART.ModuleOpticalElement as moe
-    import ART.ModuleProcessing as mp
-    from attosecondraytracing_amd.bundle import RayBundle
-    from oracle import art_oracle as orc
-    rng = np.random.default_rng(42)
-    S = msupp.SupportRound(20)
-    coeffs = {(16, 5): 2e-5, (15, 15): -1e-5, (14, 0): 3e-5, (13, 6): 1e-5, (9, 4): -2e-5, (2, 1): 1e-4}
-    Z = mdef.Zernike(S, coeffs)
-    M = mmirror.MirrorSpherical(500, S)
-    oe = moe.OpticalElement(mmirror.DeformedMirror(M, [Z]), np.array([0.0, 0.0, 100.0]), np.array([0.1, 0.0, -1.0]),
-                            np.array([1.0, 0.0, 0.1]))
-    n = 500
-    pts = np.stack([rng.uniform(-10, 10, n), rng.uniform(-10, 10, n), np.zeros(n)], axis=1)
-    vec = np.stack([rng.normal(0, 0.02, n), rng.normal(0, 0.02, n), np.ones(n)], axis=1)
-    for ign in (True, False):
-        out = mp.RayTracingCalculation(RayBundle.from_arrays(pts, vec, np.arange(n), np.ones(n)), [oe], IgnoreDefects=ign)[0]
-        O = orc.Optic("sphere", orc.Support("round", [20]), {"R": 500.0}, [orc.ZernikeDefect(coeffs, Z.R)], M.type)
-        ref = orc.ray_tracing_calculation(orc.make_bundle(pts, vec, np.arange(n), np.ones(n)),
-                                          [orc.Element(O, oe.position, oe.normal, oe.majoraxis)], IgnoreDefects=ign)[0]
-        assert np.array_equal(out.numbers(), ref.number) and len(ref) > 400
-        assert np.abs(out.points() - ref.point).max() <= 1e-10 * 100
-        assert np.abs(out.vectors() - ref.vector).max() <= 1e-10
-        assert np.abs(out.paths_total() - ref.path.sum(axis=1)).max() <= 1e-10 * 100
-    with pytest.raises(NotImplementedError):
-        mdef.Zernike(S, {(17, 3): 1e-5})
+    """Zernike defects at order 16 (unrolled Horner tables) and at orders 20, 30, 48 (the recurrences per ray), any number of
+    defects per mirror: against the oracle's recurrences and the long-double truth."""
+    import zernike_cases
+    from conftest import report
+    for name, w in zernike_cases.run_high_order().items():
+        report(f"[zernike {name}, local error vs long-double truth] " + "  ".join(f"{k} {v:.1e}" for k, v in w.items()))
 
 
 def test_twin_batched_loop_lists_match_reference(twin):

@@ -1,0 +1,92 @@
+"""Zernike defects beyond the register-resident evaluators (shared by the CPU-twin and the GPU suite): orders above 16
+run the reference's recurrences per ray (ART/recursive_zernike_generator.py:51-246) in a kernel of their own, and any
+number of Zernike defects per mirror is merged into one table per normalisation radius."""
+import numpy as np
+import pytest
+
+from oracle import art_oracle as orc
+
+
+def _scene(coeff_dicts, support_R=20.0):
+    import ART.ModuleDefects as mdef
+    import ART.ModuleMirror as mmirror
+    import ART.ModuleSupport as msupp
+    import ART.ModuleOpticalElement as moe
+    S = msupp.SupportRound(support_R)
+    Zs = [mdef.Zernike(S, c) for c in coeff_dicts]
+    M = mmirror.MirrorSpherical(500, S)
+    oe = moe.OpticalElement(mmirror.DeformedMirror(M, Zs), np.array([0.0, 0.0, 100.0]), np.array([0.1, 0.0, -1.0]),
+                            np.array([1.0, 0.0, 0.1]))
+    O = orc.Optic("sphere", orc.Support("round", [support_R]), {"R": 500.0}, [orc.ZernikeDefect(c, Z.R) for c, Z in zip(coeff_dicts, Zs)],
+                  M.type)
+    return oe, orc.Element(O, oe.position, oe.normal, oe.majoraxis)
+
+
+def _compare(oe, Eo, n=600, seed=42, second=None):
+    """Product vs oracle (1e-10) and vs the long-double truth (local bars of the fuzz harness) for both IgnoreDefects."""
+    import ART.ModuleProcessing as mp
+    import fuzz_common as fz
+    import truth_common as T
+    from attosecondraytracing_amd.bundle import RayBundle
+    rng = np.random.default_rng(seed)
+    pts = np.stack([rng.uniform(-10, 10, n), rng.uniform(-10, 10, n), np.zeros(n)], axis=1)
+    vec = np.stack([rng.normal(0, 0.02, n), rng.normal(0, 0.02, n), np.ones(n)], axis=1)
+    vec /= np.linalg.norm(vec, axis=1)[:, None]
+    worst = {}
+    for ign in (True, False):
+        els = [oe] + ([second[0]] if second else [])
+        outs = mp.RayTracingCalculation(RayBundle.from_arrays(pts, vec, np.arange(n), np.ones(n)), els, IgnoreDefects=ign)
+        refs = orc.ray_tracing_calculation(orc.make_bundle(pts, vec, np.arange(n), np.ones(n)),
+                                           [Eo] + ([second[1]] if second else []), IgnoreDefects=ign)
+        for out, ref in zip(outs, refs):
+            assert np.array_equal(out.numbers(), ref.number) and len(ref) > 0.7 * n
+            assert np.abs(out.points() - ref.point).max() <= 1e-10 * 100
+            assert np.abs(out.vectors() - ref.vector).max() <= 1e-10
+            assert np.abs(out.paths_total() - ref.path.sum(axis=1)).max() <= 1e-10 * 100
+        if T.HAVE_LD:
+            out = outs[0]
+            P, v, t, inc = T.element_truth(Eo, pts[out.numbers()], vec[out.numbers()], out.path_segments()[:, -1], ign)
+            e = {"pos": float(np.abs(out.points() - P).max() / 100), "dir": float(np.abs(out.vectors() - v).max()),
+                 "seg": float(np.abs(out.path_segments()[:, -1] - t).max() / 100), "inc": float(np.abs(out.incidences() - inc).max())}
+            for k, val in e.items():
+                assert val <= fz.LOCAL_TOL[k], (k, val, ign)
+                worst[k] = max(worst.get(k, 0.0), val)
+    return worst
+
+
+def run_high_order():
+    import ART.ModuleDefects as mdef
+    import ART.ModuleSupport as msupp
+    from attosecondraytracing_amd import _abi
+    res = {}
+    # order 16: the unrolled Horner evaluators (register-resident)
+    c16 = {(16, 5): 2e-5, (15, 15): -1e-5, (14, 0): 3e-5, (13, 6): 1e-5, (9, 4): -2e-5, (2, 1): 1e-4}
+    res["order 16"] = _compare(*_scene([c16]))
+    # orders 20, 30 and 48: the recurrence kernel
+    c20 = {(20, 7): 2e-5, (19, 19): -1e-5, (18, 0): 3e-5, (17, 6): 1e-5, (9, 4): -2e-5, (2, 1): 1e-4}
+    c30 = {(30, 11): 1e-5, (29, 0): -2e-5, (24, 24): 1e-5, (21, 10): 2e-5, (4, 2): 5e-5}
+    c48 = {(48, 20): 1e-6, (40, 3): -2e-6, (33, 16): 2e-6, (3, 1): 5e-5}
+    for name, c in (("order 20", c20), ("order 30", c30), ("order 48", c48)):
+        oe, Eo = _scene([c])
+        d, _ = __import__("ART.ModuleProcessing", fromlist=["x"]).element_descriptor(oe, True)
+        assert d.flags & _abi.ART_FLAG_ZERN_RECURRENCE and d.n_defects == 1
+        res[name] = _compare(oe, Eo)
+    # a recurrence element inside a longer chain (the chain falls back to element-by-element launches)
+    import ART.ModuleMirror as mmirror
+    import ART.ModuleOpticalElement as moe
+    S2 = msupp.SupportRound(40)
+    plane = moe.OpticalElement(mmirror.MirrorPlane(S2), np.array([0.0, 0.0, 40.0]), np.array([0.0, 0.05, 1.0]), np.array([1.0, 0.0, 0.0]))
+    plane_o = orc.Element(orc.Optic("plane", orc.Support("round", [40.0]), {}, [], "Plane Mirror"), plane.position, plane.normal,
+                          plane.majoraxis)
+    oe, Eo = _scene([c20])
+    _compare(oe, Eo, second=(plane, plane_o))
+    # seven Zernike defects on one mirror (more than ART_MAX_DEFECTS tables): merged into one table, both layouts
+    many = [{(2 + k, k % 3): 1e-5 * (k + 1), (5, 2): -3e-6} for k in range(7)]
+    oe, Eo = _scene(many)
+    d, _ = __import__("ART.ModuleProcessing", fromlist=["x"]).element_descriptor(oe, False)
+    assert d.n_defects == 1 and not (d.flags & _abi.ART_FLAG_ZERN_RECURRENCE)
+    res["7 defects"] = _compare(oe, Eo)
+    res["7 defects, one above order 16"] = _compare(*_scene(many + [{(18, 4): 1e-5}]))
+    with pytest.raises(NotImplementedError):
+        mdef.Zernike(msupp.SupportRound(20), {(_abi.ART_ZERN_RECURRENCE_MAX_ORDER + 1, 3): 1e-5})
+    return res
