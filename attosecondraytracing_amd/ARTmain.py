@@ -118,7 +118,9 @@ def make_plots(OpticalChain, RayListAnalysed, Detector, SourceProperties, Detect
 
 def run_ART(OpticalChain, SourceProperties, DetectorOptions, AnalysisOptions, loop=False):
     """One chain: trace, transmission, detector, summary, plots (ARTmain.py:248-300)."""
-    output_rays = OpticalChain.get_output_rays()
+    # ONE bundle of the history is analysed: trace it alone; any other entry of `output_rays` (a plot of another
+    # element, Ray.path tuples, an archive) is materialised bit-identically on first access (mp.LazyHistory)
+    output_rays = OpticalChain.get_output_rays(history="lazy", want=DetectorOptions["ReflectionNumber"])
     RayListAnalysed = output_rays[DetectorOptions["ReflectionNumber"]]
     ETransmission = mplots.getETransmission(OpticalChain.source_rays, RayListAnalysed)
     if AnalysisOptions["verbose"]:
@@ -160,7 +162,7 @@ def main(OpticalChainList, SourceProperties, DetectorOptions, AnalysisOptions, s
     if loop and len(OpticalChainList) > 1:
         # the whole loop list in ONE launch (chains that differ only in poses share a device-resident scene table);
         # run_ART below then finds every chain's result cached
-        moc.trace_chain_list(OpticalChainList)
+        moc.trace_chain_list(OpticalChainList, history="lazy", want=DetectorOptions["ReflectionNumber"])
     for i, chain in enumerate(OpticalChainList):
         print("Optical Chain " + str(i) + "/" + str(len(OpticalChainList)) + " ", end="", flush=True)
         results = run_ART(chain, SourceProperties, DetectorOptions, AnalysisOptions, loop)

@@ -21,11 +21,14 @@ def trace_chain_list(chains, **kwargs):
     ART/ARTmain.py:304-342) find their result ready.  A list as `OEPlacement` returns it -- chains that differ only in
     poses -- shares one scene table; anything else falls back to one launch per chain."""
     stale = [ch for ch in chains if ch._cache_key(kwargs) != ch._last_key and getattr(ch, "_program", None) is None]
-    if len(stale) > 1:
+    lazy = kwargs.get("history") == "lazy"
+    if len(stale) > 1 and not (lazy and kwargs.get("want", -1) not in (-1, len(stale[0].optical_elements) - 1)):
+        kw = {k: v for k, v in kwargs.items() if k not in ("history", "want")}
         outs = mp.RayTracingCalculationMany([ch.source_rays for ch in stale], [ch.optical_elements for ch in stale],
-                                            **kwargs)
+                                            history=not lazy, **kw)
         for ch, o in zip(stale, outs):
-            ch._output_rays = o
+            # lazy: only the last bundle of every chain was written; the rest appears on first access (mp.LazyHistory)
+            ch._output_rays = mp.LazyHistory(ch.source_rays, ch.optical_elements, first=o[-1], **kw) if lazy else o
             ch._last_key = ch._cache_key(kwargs)
     return [ch.get_output_rays(**kwargs) for ch in chains]
 
@@ -97,10 +100,16 @@ class OpticalChain:
         return OpticalChain(self.source_rays, self.optical_elements, self.description)
 
     def _cache_key(self, kwargs):
-        return (hash(self.source_rays), mp._hash_list_of_objects(self.optical_elements), tuple(sorted(kwargs.items())))
+        # a lazy history holds the same content as a full one: `history="lazy"` / `want` are not part of the identity
+        kw = {k: v for k, v in kwargs.items() if k != "want" and not (k == "history" and v in ("lazy", True))}
+        return (hash(self.source_rays), mp._hash_list_of_objects(self.optical_elements), tuple(sorted(kw.items())))
 
     def get_output_rays(self, **kwargs):
         """List of ray bundles after each optical element; recomputed only when something changed.
+
+        `history="lazy"` (+ `want=k`, default the last element): only bundle k is written by the trace, the others are
+        materialised -- bit-identically, by ONE re-trace with the full history -- the first time they are accessed
+        (mp.LazyHistory).  What ARTmain uses: it analyses one bundle per chain (ART/ARTmain.py:254-255).
 
         A chain that was `compile()`d re-traces by rewriting its device-resident scene table and replaying a captured
         HIP graph; the bundles it returns are then always the SAME objects (their arrays are overwritten by the next
@@ -108,13 +117,18 @@ class OpticalChain:
         key = self._cache_key(kwargs)
         if key != self._last_key:
             prog = getattr(self, "_program", None)
-            if prog is not None and prog.matches([self.source_rays], [self.optical_elements], kwargs):
+            plain = {k: v for k, v in kwargs.items() if k != "want" and not (k == "history" and v in ("lazy", True))}
+            if prog is not None and prog.matches([self.source_rays], [self.optical_elements], plain):
                 prog.update([self.optical_elements])
                 self._output_rays = prog.run()[0]
             else:
                 self._program = None
                 print("...ray-tracing...", end="", flush=True)
-                self._output_rays = mp.RayTracingCalculation(self.source_rays, self.optical_elements, **kwargs)
+                if kwargs.get("history") == "lazy":
+                    kw = {k: v for k, v in kwargs.items() if k != "history"}
+                    self._output_rays = mp.LazyHistory(self.source_rays, self.optical_elements, **kw)
+                else:
+                    self._output_rays = mp.RayTracingCalculation(self.source_rays, self.optical_elements, **kwargs)
                 print("\r\033[K", end="", flush=True)
             self._last_key = key
         return self._output_rays

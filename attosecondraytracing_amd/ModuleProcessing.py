@@ -11,6 +11,7 @@ from datetime import datetime
 from time import perf_counter
 
 import numpy as np
+import torch
 
 from . import _abi
 from . import _lib
@@ -144,6 +145,10 @@ def RayTracingCalculation(source_rays, optical_elements, IgnoreDefects=True, mod
     last bundle (ART/ModuleDetector.py:191-279) is then computed in the same launch, while every ray is still in
     registers (art_trace_chain_readout): `detector.readout(outs[-1])` and the `get_*` methods find it ready instead of
     re-reading the bundle.  Same values as the separate read-out (statistics to rounding: another summation order)."""
+    if isinstance(history, str):
+        if history != "lazy":
+            raise ValueError("history must be True, False or 'lazy'")
+        return LazyHistory(source_rays, optical_elements, IgnoreDefects, mode, detector, path_centre)
     src = _as_bundle(source_rays)
     be = src.backend
     n = src.n_slots
@@ -215,6 +220,82 @@ def RayTracingCalculation(source_rays, optical_elements, IgnoreDefects=True, mod
     else:
         raise ValueError("mode must be 'chain' or 'element'")
     return outs
+
+
+class LazyHistory:
+    """`output_rays` with the per-element history materialised ON DEMAND (`history="lazy"`).
+
+    `ARTmain.run_ART` analyses ONE bundle of the list `RayTracingCalculation` returns
+    (`output_rays[ReflectionNumber]`, ART/ARTmain.py:254-255), yet a full trace writes one 65-byte record per ray and
+    element -- for the write-bound kernels that IS the time.  A lazy history traces the chain once WITHOUT the
+    intermediate bundles (the wanted bundle + the fused read-out of a known detector) and behaves like the reference's
+    list of bundles: the first access to any other entry -- or to anything that needs the parents of the wanted bundle
+    (`Ray.path` tuples) -- re-traces the chain with the full history, once, and checks that the bundle handed out
+    earlier is bit-identical to the one of the full trace (same kernels, same inputs: by construction)."""
+
+    def __init__(self, source, elements, IgnoreDefects=True, mode=None, detector=None, path_centre=0.0, want=-1, first=None):
+        self._src, self._els = _as_bundle(source), list(elements)
+        self._opts = (bool(IgnoreDefects), mode, path_centre)
+        m = len(self._els)
+        self._bundles = [None] * m
+        self._full = m <= 1
+        self.retraces = 0
+        if m == 0:
+            return
+        self._want = want % m
+        if first is None:
+            first = RayTracingCalculation(self._src, self._els[:self._want + 1], IgnoreDefects, mode, False,
+                                          detector if self._want == m - 1 else None, path_centre)[-1]
+        self._bundles[self._want] = first
+        if not self._full:
+            first._parent_resolver = self._materialise
+
+    def _materialise(self):
+        if self._full:
+            return
+        self._full = True
+        ign, mode, pc_ = self._opts
+        full = RayTracingCalculation(self._src, self._els, ign, mode, True, None, pc_)
+        self.retraces += 1
+        for k, b in enumerate(full):
+            have = self._bundles[k]
+            if have is None:
+                self._bundles[k] = b
+            else:
+                # the bundle handed out before stays THE bundle (callers hold it); the full trace must reproduce it
+                live = b.alive.bool()
+                assert torch.equal(have.alive, b.alive) and torch.equal(have.data[:, live].view(torch.int64), b.data[:, live].view(torch.int64)), \
+                    "lazy history: the re-trace differs from the bundle handed out earlier"
+                have.parent = self._src if k == 0 else self._bundles[k - 1]
+        for k in range(1, len(full)):
+            if self._bundles[k] is full[k]:
+                self._bundles[k].parent = self._bundles[k - 1]
+
+    def __len__(self):
+        return len(self._bundles)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            self._materialise()
+            return self._bundles[i]
+        m = len(self._bundles)
+        if not -m <= i < m:
+            raise IndexError("list index out of range")
+        if self._bundles[i % m] is None:
+            self._materialise()
+        return self._bundles[i % m]
+
+    def __iter__(self):
+        self._materialise()
+        return iter(self._bundles)
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        for b in st["_bundles"]:
+            if b is not None and b._parent_resolver is not None:      # an archive holds plain bundles
+                self._materialise()
+                return dict(self.__dict__)
+        return st
 
 
 def RayTracingCalculationMany(source_rays_list, optical_elements_list, IgnoreDefects=True, history=True,

@@ -29,7 +29,8 @@ class RayBundle:
         self.number = number          # torch int64 [n] or None (= slot index)
         self.intensity = intensity    # torch float64 [n] or None
         self.wavelength = wavelength  # float or None (uniform, as every reference source produces)
-        self.parent = parent          # bundle this one was traced from (for Ray.path tuples)
+        self._parent = parent         # bundle this one was traced from (for Ray.path tuples); see `parent`
+        self._parent_resolver = None  # lazy history (ModuleProcessing.LazyHistory): called once, sets the real parent
         self._backend = backend or _lib.get_backend()
         self._index = None
         self._count = None
@@ -40,6 +41,26 @@ class RayBundle:
         self.path_head = None
         self._fused_readout = None    # (detector key, version, result) of a read-out computed in the tracing launch
         self._content = None          # (key, version it was valid for): see content_key()
+
+    # ------------------------------------------------------------------ parent link
+    @property
+    def parent(self):
+        """The bundle this one was traced from.  A bundle handed out by a lazy history was traced WITHOUT its
+        intermediate bundles; the first look at its parent (Ray.path tuples, path_segments) materialises them."""
+        if self._parent_resolver is not None:
+            resolve, self._parent_resolver = self._parent_resolver, None
+            resolve()
+        return self._parent
+
+    @parent.setter
+    def parent(self, value):
+        self._parent = value
+        self._parent_resolver = None
+
+    def _share_parent(self, other):
+        """`other` (a view / copy of this bundle) has this bundle's parent -- also when that is still to be materialised."""
+        if self._parent_resolver is not None:
+            other._parent_resolver = lambda o=other, s=self: setattr(o, "_parent", s.parent)
 
     # ------------------------------------------------------------------ backend / persistence
     @property
@@ -67,6 +88,7 @@ class RayBundle:
         t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a))
         self.data, self.alive = t(st["data"]), t(st["alive"])
         self.number, self.intensity = t(st["number"]), t(st["intensity"])
+        self._parent_resolver = None
         self.wavelength, self.parent, self.version = st["wavelength"], st["parent"], st["version"]
         self.path_head = st.get("path_head")
         self._backend = None
@@ -306,7 +328,8 @@ class RayBundle:
         pos = torch.as_tensor(np.asarray(positions, dtype=np.int64), device=self.backend.device)
         alive = torch.zeros_like(self.alive)
         alive[idx.index_select(0, pos)] = 1
-        out = RayBundle(self.data, alive, self.number, self.intensity, self.wavelength, self.parent, self.backend)
+        out = RayBundle(self.data, alive, self.number, self.intensity, self.wavelength, self._parent, self.backend)
+        self._share_parent(out)
         out.path_head = self.path_head
         return out
 
@@ -314,7 +337,8 @@ class RayBundle:
         """Affine map of the whole bundle on the device (art_transform_bundle): point' = M point + T (or
         point + T), vector' = normalize(M vector).  Scene-manipulation helper, not on the tracing path."""
         out = RayBundle.allocate(self.n_slots, like=self, backend=self.backend)
-        out.parent = self.parent
+        out._parent = self._parent
+        self._share_parent(out)
         out.path_head = self.path_head
         self.backend.transform_bundle(M, T, rotate_points, self.view(), out.view(), self.n_slots)
         return out
@@ -323,7 +347,8 @@ class RayBundle:
         data, alive = self._rows(self.n_slots, self.data.device)
         data.copy_(self.data)
         alive.copy_(self.alive)
-        out = RayBundle(data, alive, self.number, self.intensity, self.wavelength, self.parent, self.backend)
+        out = RayBundle(data, alive, self.number, self.intensity, self.wavelength, self._parent, self.backend)
+        self._share_parent(out)
         out.path_head = self.path_head
         out.tag_content(self.content_key())        # a copy is bit-identical to its original
         return out

@@ -55,7 +55,7 @@ class SceneProgram:
 
     Results are bit-identical to `RayTracingCalculation`; the returned bundles are overwritten by the next `run()`."""
 
-    def __init__(self, sources, element_lists, IgnoreDefects=True, post=None, capture=True, detectors=None):
+    def __init__(self, sources, element_lists, IgnoreDefects=True, post=None, capture=True, detectors=None, history=True):
         from . import ModuleProcessing as mp
         from . import _abi
         from .bundle import RayBundle
@@ -69,14 +69,22 @@ class SceneProgram:
             raise ValueError("SceneProgram needs at least one chain, one element and one ray")
         if any(len(e) != self.m for e in element_lists) or any(s.n_slots != self.n for s in self.sources):
             raise ValueError("all chains of a SceneProgram share the element count and the ray count")
-        self.outputs = RayBundle.allocate_grid(self.n, self.c, self.m, self.sources, self.be)
+        # history=False: only every chain's LAST bundle is written (the others are None) -- what a caller that analyses the
+        # final bundle needs (ARTmain's lazy history); chains of at most 8 elements (one fused launch, no hand-over bundle)
+        if history:
+            self.outputs = RayBundle.allocate_grid(self.n, self.c, self.m, self.sources, self.be)
+        else:
+            if self.m > 8:
+                raise ValueError("SceneProgram(history=False) covers chains of at most 8 elements")
+            self.outputs = [[None] * (self.m - 1) + [RayBundle.allocate(self.n, like=s, backend=self.be)] for s in self.sources]
         for ci, outs in enumerate(self.outputs):
             prev = self.sources[ci]
             for b in outs:
-                b.parent = prev
-                prev = b
+                if b is not None:
+                    b.parent = prev
+                    prev = b
         self._views_in = [s.view() for s in self.sources]
-        self._views_out = [b.view() for outs in self.outputs for b in outs]
+        self._views_out = [b.view() if b is not None else _abi.ArtBundleView() for outs in self.outputs for b in outs]
         self.detectors, self.readouts = None, None
         if detectors is not None and self.n <= self.be.MAX_FUSED_READOUT_RAYS:
             if len(detectors) != self.c:
@@ -159,13 +167,15 @@ class SceneProgram:
         self._keep = keep
         for outs in self.outputs:
             for b in outs:
-                b.touch()
+                if b is not None:
+                    b.touch()
 
     def _mark(self):
         """The output arrays have new contents: drop cached survivor lists, re-attach the fused read-outs."""
         for ci, outs in enumerate(self.outputs):
             for b in outs:
-                b.touch()
+                if b is not None:
+                    b.touch()
             if self.readouts is not None:
                 self.readouts[ci].pop("stats", None)
                 self._mp._attach_readout(outs[-1], self.detectors[ci], 0.0, self.readouts[ci])

@@ -523,6 +523,21 @@ def worker(args):
         program = SceneProgram([src] * n_chains, element_lists, IgnoreDefects=ignore_defects,
                                post=readouts, capture=use_graph, detectors=dets if fuse else None)
 
+    # the same step WITHOUT the intermediate bundles (what ARTmain's lazy history traces: the analysed bundle + its
+    # read-out; the rest of the history only when somebody looks at it) -- reported beside `value`, never as `value`
+    program_lazy = None
+    if (batched or use_graph) and n_elems <= 8 and world == 1:
+        program_lazy = SceneProgram([src] * n_chains, element_lists, IgnoreDefects=ignore_defects, post=readouts,
+                                    capture=use_graph, detectors=dets if fuse else None, history=False)
+
+    def trace_and_readout_lazy():
+        if program_lazy is not None:
+            o = program_lazy.run()
+            return o, program_lazy.post_result
+        o = [mp.RayTracingCalculation(src, element_lists[0], IgnoreDefects=ignore_defects, mode=mode, history=False,
+                                      detector=dets[0] if fuse else None)]
+        return o, readouts(o)
+
     def trace_and_readout():
         if program is not None:
             o = program.run()
@@ -640,6 +655,22 @@ def worker(args):
                 step(False)
             sync()
         box["under_load"] = smi_result(q, local)
+    dt_lazy = None
+    if on_gpu and not use_dist and (program is None or program_lazy is not None):
+        for _ in range(args.warmup):
+            ol, rl = trace_and_readout_lazy()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ol, rl = trace_and_readout_lazy()
+        sync()
+        dt_lazy = time.perf_counter() - t0
+        # the analysed bundle and its read-out are the full-history step's, bit for bit
+        assert torch.equal(ol[-1][-1].alive, o[-1][-1].alive)
+        lv_ = o[-1][-1].alive.bool()
+        assert torch.equal(ol[-1][-1].data[:, lv_].view(torch.int64), o[-1][-1].data[:, lv_].view(torch.int64))
+        assert torch.equal(rl[-1]["stats_dev"].view(torch.int64), r[-1]["stats_dev"].view(torch.int64))
+        del ol, rl
     stats_host = (state["stats"] if use_dist else r[-1]["stats_dev"]).cpu().numpy()
     assert stats_host[0] == surv_last_job and np.isfinite(stats_host[1]), (stats_host[0], surv_last_job)
 
@@ -694,6 +725,13 @@ def worker(args):
             "sustained_note": None if dt_sus is None else
             f"the same {args.steps} steps timed again after the device had been busy for {SETTLE_SECONDS} s more "
             f"(sustained clocks); `value` is the contract's region, {args.warmup} warm-up steps after an idle device",
+            "value_lazy_history": None if dt_lazy is None else inter_per_step_job * args.steps / dt_lazy,
+            "ms_per_step_lazy_history": None if dt_lazy is None else dt_lazy / args.steps * 1e3,
+            "lazy_history_note": None if dt_lazy is None else
+            "the same intersections with only the analysed (last) bundle and its read-out written -- the product's lazy "
+            "history mode (get_output_rays(history='lazy'), what ARTmain.run_ART uses); the analysed bundle and the 24 "
+            "statistics are bit-identical to the full-history step's (asserted in this run); NOT the headline: `value` "
+            "writes every per-element bundle",
             "value_full_gather": None if dt_full is None else inter_per_step_job * args.steps / dt_full,
             "ms_per_step_full_gather": None if dt_full is None else dt_full / args.steps * 1e3,
             "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,

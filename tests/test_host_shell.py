@@ -245,3 +245,42 @@ def test_zernike_gradient_module_matches_reference():
         assert np.abs(GX[(n, m)][0][1] - a["gx"][k]).max() <= 1e-13 * scale
         assert np.abs(GY[(n, m)][0][1] - a["gy"][k]).max() <= 1e-13 * scale
     assert (1, 1) in zernike_gradient(a["x"], a["y"], 0)[0] and (2, 2) in zernike_gradient(a["x"], a["y"], 0)[0]
+
+
+def test_lazy_history_is_bit_identical_and_traces_once(twin):
+    """`history="lazy"`: the wanted bundle is traced alone; every other entry (and the Ray.path tuples of the wanted
+    one, which need its parents) appears after ONE re-trace with the full history, bit-identical to a plain trace."""
+    import ART.ModuleProcessing as mp
+    import ART.ModuleOpticalChain as moc
+    scene, a = load_golden("c3_twisted_chain04")
+    els = pc.build_elements(scene, a)
+    src = pc.source_bundle(a, scene)
+    full = mp.RayTracingCalculation(src, els)
+    lazy = mp.RayTracingCalculation(src, els, history="lazy")
+    assert isinstance(lazy, mp.LazyHistory) and len(lazy) == 3 and lazy.retraces == 0
+    last = lazy[-1]
+    assert lazy.retraces == 0 and lazy[2] is last
+    assert np.array_equal(last.numbers(), full[-1].numbers()) and np.array_equal(last.points(), full[-1].points())
+    assert np.array_equal(last.paths_total(), full[-1].paths_total()) and lazy.retraces == 0
+    segs = last.path_segments()                         # needs the parents: one re-trace
+    assert lazy.retraces == 1 and np.array_equal(segs, full[-1].path_segments())
+    assert last[0].path == full[-1][0].path and len(last[0].path) == 4
+    for k in range(3):
+        assert np.array_equal(lazy[k].points(), full[k].points()) and np.array_equal(lazy[k].numbers(), full[k].numbers())
+    assert lazy.retraces == 1 and lazy[-1] is last and [len(b) for b in lazy] == [len(b) for b in full]
+    # want = an inner bundle; slices; archives
+    inner = mp.LazyHistory(src, els, want=1)
+    assert inner.retraces == 0 and np.array_equal(inner[1].vectors(), full[1].vectors())
+    assert [len(b) for b in inner[0:2]] == [len(full[0]), len(full[1])] and inner.retraces == 1
+    import pickle
+    again = pickle.loads(pickle.dumps(mp.RayTracingCalculation(src, els, history="lazy")))
+    assert [b.alive.sum().item() for b in again._bundles] == [len(b) for b in full]
+    # through the chain cache: a lazy result serves the plain call, ARTmain-style
+    chain = moc.OpticalChain(src, els)
+    o1 = chain.get_output_rays(history="lazy", want=-1)
+    assert isinstance(o1, mp.LazyHistory) and chain.get_output_rays() is o1
+    many = moc.trace_chain_list([moc.OpticalChain(src, els), moc.OpticalChain(src, els)], history="lazy")
+    assert all(isinstance(o, mp.LazyHistory) and o.retraces == 0 for o in many)
+    assert np.array_equal(many[1][-1].points(), full[-1].points()) and np.array_equal(many[0][0].points(), full[0].points())
+    with pytest.raises(ValueError):
+        mp.RayTracingCalculation(src, els, history="sometimes")
