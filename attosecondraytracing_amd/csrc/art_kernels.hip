@@ -634,9 +634,12 @@ __device__ __forceinline__ void chain_body2(const ChainArgs& a, const int64_t fi
     const D2 ox = ld_2f64(bi.ox, o16), oy = ld_2f64(bi.oy, o16), oz = ld_2f64(bi.oz, o16);
     const D2 dx = ld_2f64(bi.dx, o16), dy = ld_2f64(bi.dy, o16), dz = ld_2f64(bi.dz, o16);
     const D2 pa = ld_2f64(bi.path, o16);
-    // two byte loads: a 16-bit load straddling the end of an odd-length array is dropped as a whole
-    ok[0] = __builtin_amdgcn_raw_buffer_load_b8(bi.alive, (int)o2, 0, ART_LD_AUX) != 0;
-    ok[1] = __builtin_amdgcn_raw_buffer_load_b8(bi.alive, (int)o2 + 1, 0, ART_LD_AUX) != 0;
+    // The two alive bytes with ONE 16-bit load.  A 16-bit access straddling the end of an odd-length array is dropped as a
+    // whole: for odd n (wave-uniform) the lane that holds the last slot fetches its byte separately.
+    unsigned al2 = __builtin_amdgcn_raw_buffer_load_b16(bi.alive, (int)o2, 0, ART_LD_AUX);
+    if (n & 1) al2 |= __builtin_amdgcn_raw_buffer_load_b8(bi.alive, (o2 + 1u == (unsigned)n) ? (int)o2 : (int)kDropOffset, 0, ART_LD_AUX);
+    ok[0] = (al2 & 0xffu) != 0;
+    ok[1] = (al2 & 0xff00u) != 0;
     const D2 wv = ld_2f64(rsrc_of(const_cast<double*>(a.ro.w) + first,
                                   ((a.flags & art::kFlagReadout) && a.ro.w) ? (unsigned)(n * 8) : 0u), o16);
     s_w[0][lane] = wv.a; s_w[1][lane] = wv.b;
@@ -661,8 +664,9 @@ __device__ __forceinline__ void chain_body2(const ChainArgs& a, const int64_t fi
     st_2f64(rsrc_of(v.path + first, nb * 8u), off, r[0].path, r[1].path);
     st_2f64(rsrc_of(v.incidence + first, nb * 8u), off, r[0].inc, r[1].inc);
     const __amdgpu_buffer_rsrc_t ra = rsrc_of(v.alive + first, nb);
-    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(ok[0] ? 1 : 0), ra, (int)o2, 0, ART_ST_AUX);
-    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(ok[1] ? 1 : 0), ra, (int)o2 + 1, 0, ART_ST_AUX);
+    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)((ok[0] ? 1u : 0u) | (ok[1] ? 0x100u : 0u)), ra, (int)o2, 0, ART_ST_AUX);
+    if (n & 1)      // odd n: the 16-bit store of the pair that holds the last slot was dropped by the range check
+      __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(ok[0] ? 1 : 0), ra, (o2 + 1u == (unsigned)n) ? (int)o2 : (int)kDropOffset, 0, ART_ST_AUX);
   } while (++k < a.n_elems);
   if (a.flags & art::kFlagReadout) {
     double acc[kReadoutSlots];
@@ -1442,12 +1446,9 @@ inline int chain_waves() {
   return wv ? atoi(wv) : 5;
 }
 // ART_CHAIN_RPL=2: the two-rays-per-lane body (chain_body2) for chains without defects
-inline int chain_rpl() {
-  static const int v = [] {
-    const char* e = getenv("ART_CHAIN_RPL");
-    return (e && atoi(e) == 2) ? 2 : 1;
-  }();
-  return v;
+inline int chain_rpl() {   // read at every call: tools/ab_kernel.py alternates the variants inside one process
+  const char* e = getenv("ART_CHAIN_RPL");
+  return (e && atoi(e) == 2) ? 2 : 1;
 }
 // ART_CHAIN_DYN_LDS=<bytes>: unused dynamic LDS per workgroup of the fused kernel, i.e. FEWER resident workgroups per CU
 // (20 KB static + 20480 -> 4, + 33000 -> 3).  An experiment knob: the bare access pattern gains 3-7 % of bandwidth with 2-3
