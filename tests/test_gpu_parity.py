@@ -712,3 +712,40 @@ def test_gpu_zernike_any_order_and_any_number_of_defects(hip):
     import zernike_cases
     for name, w in zernike_cases.run_high_order().items():
         report(f"[zernike {name}, local error vs long-double truth] " + "  ".join(f"{k} {v:.1e}" for k, v in w.items()))
+
+
+def test_gpu_two_rays_per_lane_body(hip, monkeypatch):
+    """The experiment body of the fused kernels (ART_CHAIN_RPL=2, read by the library at every launch: two neighbouring
+    slots per lane, 16-byte accesses straight from registers, no LDS staging) gives the shipped body's results bit for bit:
+    golden chains, an odd ray count (16-bit alive accesses at the tail), the scene launch and the fused read-out."""
+    import torch
+    import bench
+    import ART.ModuleProcessing as mp
+    import ART.ModuleDetector as mdet
+    element_lists, _, _ = bench.scene_c3()
+    for n in (100_001, 4096, 77):
+        src = bench.device_source(n, 0, n, hip, ("point", 0.025))
+        D = None
+        outs = {}
+        for rpl in ("1", "2"):
+            monkeypatch.setenv("ART_CHAIN_RPL", rpl)
+            plain = mp.RayTracingCalculation(src, element_lists[2])
+            if D is None:
+                D = mdet.Detector(np.asarray(element_lists[2][-1].position, dtype=float))
+                D.autoplace(plain[-1], 600.0)
+            fused = mp.RayTracingCalculation(src, element_lists[2], detector=D)
+            ro = D.readout(fused[-1], sync=False)
+            many = mp.RayTracingCalculationMany([src, src], [element_lists[2], element_lists[7]], detectors=[D, D])
+            outs[rpl] = (plain, fused, ro, many)
+            torch.cuda.synchronize()
+        a, b = outs["1"], outs["2"]
+        for x, y in list(zip(a[0], b[0])) + list(zip(a[1], b[1])) + [(p, q) for ca, cb in zip(a[3], b[3]) for p, q in zip(ca, cb)]:
+            assert torch.equal(x.alive, y.alive)
+            live = x.alive.bool()
+            assert torch.equal(x.data[:, live].view(torch.int64), y.data[:, live].view(torch.int64))
+        live = a[1][-1].alive.bool()
+        for k in ("X", "Y", "opl"):
+            assert torch.equal(a[2][k][live].view(torch.int64), b[2][k][live].view(torch.int64))
+        sa, sb = a[2]["stats_dev"].cpu().numpy(), b[2]["stats_dev"].cpu().numpy()
+        assert sa[0] == sb[0] and all(sa[k] == sb[k] for k in (2, 3, 4, 5, 12, 13))
+        assert np.abs(sa - sb).max() <= 1e-11 * max(1.0, np.abs(sa).max())

@@ -35,6 +35,25 @@ __global__ __launch_bounds__(kB) void k_soa(const double* __restrict__ in, const
   }
 }
 
+// the same pattern from workgroups of WG threads (WG rays): fewer, larger workgroups narrow the window of addresses in
+// flight per CU at the same number of resident waves
+template <int E, int WG>
+__global__ __launch_bounds__(WG) void k_soa_wg(const double* __restrict__ in, const uint8_t* __restrict__ ain, double* __restrict__ out,
+                                               uint8_t* __restrict__ aout, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x;
+  if (i >= n) return;
+  double v[8];
+#pragma unroll
+  for (int f = 0; f < 7; ++f) v[f] = __builtin_nontemporal_load(in + f * n + i);
+  v[7] = (double)ain[i];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+#pragma unroll
+    for (int f = 0; f < 8; ++f) __builtin_nontemporal_store(v[f] + e, out + ((int64_t)e * 8 + f) * n + i);
+    __builtin_nontemporal_store((uint8_t)1, aout + (int64_t)e * n + i);
+  }
+}
+
 template <int E, int TILE>
 __global__ __launch_bounds__(kB) void k_tile(const double* __restrict__ in, const uint8_t* __restrict__ ain, double* __restrict__ out,
                                              uint8_t* __restrict__ aout, int64_t n) {
@@ -51,6 +70,27 @@ __global__ __launch_bounds__(kB) void k_tile(const double* __restrict__ in, cons
     for (int f = 0; f < 8; ++f) __builtin_nontemporal_store(v[f] + e, out + (int64_t)e * 8 * n + (t * 8 + f) * TILE + l);
     __builtin_nontemporal_store((uint8_t)1, aout + (int64_t)e * n + i);
   }
+}
+
+// the pattern of the FUSED kernel (trace + detector read-out in one launch): + one 8-byte weight stream in, + three 8-byte
+// read-out streams out (X, Y, optical path): 65 B read + (65 E + 24) B written per ray
+template <int E>
+__global__ __launch_bounds__(kB) void k_soa_ro(const double* __restrict__ in, const uint8_t* __restrict__ ain, double* __restrict__ out,
+                                               uint8_t* __restrict__ aout, double* __restrict__ ro, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
+  if (i >= n) return;
+  double v[8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f) v[f] = __builtin_nontemporal_load(in + f * n + i);     // 7 state streams + the weight
+  v[7] += (double)ain[i];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+#pragma unroll
+    for (int f = 0; f < 8; ++f) __builtin_nontemporal_store(v[f] + e, out + ((int64_t)e * 8 + f) * n + i);
+    __builtin_nontemporal_store((uint8_t)1, aout + (int64_t)e * n + i);
+  }
+#pragma unroll
+  for (int f = 0; f < 3; ++f) __builtin_nontemporal_store(v[f] + 9.0, ro + (int64_t)f * n + i);
 }
 
 // variants of the 8-byte pattern that take it apart: MODE 0 = loads only (the 7 + 1 input streams, one dummy store per
@@ -184,7 +224,8 @@ template <int E>
 static int run(int64_t n) {
   const int64_t nb = (n + kB - 1) / kB;
   n = nb * kB;                                   // whole tiles, so that the tiled variants need no tail
-  double *in, *out; uint8_t *ain, *aout;
+  double *in, *out, *ro; uint8_t *ain, *aout;
+  CK(hipMalloc(&ro, 3 * n * 8));
   const int64_t kMaxPad = 1 << 22;   // doubles of extra row pitch tried below (<= 32 MB per row)
   CK(hipMalloc(&in, 8 * (n + kMaxPad) * 8)); CK(hipMalloc(&out, (size_t)E * 8 * (n + kMaxPad) * 8)); CK(hipMalloc(&ain, n)); CK(hipMalloc(&aout, (size_t)E * n));
   CK(hipMemset(in, 0, 8 * n * 8)); CK(hipMemset(ain, 1, n));
@@ -193,6 +234,7 @@ static int run(int64_t n) {
   auto line = [&](const char* name, float ms, double b) { printf("%-34s E=%d  %8.4f ms  %7.3f TB/s  (%.3f GB)\n", name, E, ms, b / ms * 1e-9, b * 1e-9); fflush(stdout); };
   line("soa  nt stores", timeit([&] { k_soa<E, true><<<nb, kB>>>(in, ain, out, aout, n, n); }, reps), bytes);
   line("soa  plain stores", timeit([&] { k_soa<E, false><<<nb, kB>>>(in, ain, out, aout, n, n); }, reps), bytes);
+  line("soa  nt + read-out streams (fused)", timeit([&] { k_soa_ro<E><<<nb, kB>>>(in, ain, out, aout, ro, n); }, reps), bytes + 32.0 * n);
   // the same rows further apart: does the relative placement of the 8E + 7 streams in the channel / bank interleave matter?
   const int64_t pads[] = {64, 512, 8192 + 64, 131072 + 512, 1 << 18, 1 << 19, 1 << 20, (1 << 20) + (1 << 19), 1 << 21, (1 << 21) + 512,
                           3 << 20, kMaxPad};
@@ -207,6 +249,11 @@ static int run(int64_t n) {
     snprintf(name, sizeof name, "soa  nt, %d workgroups per CU", 160 * 1024 / lds);
     line(name, timeit([&] { k_soa<E, true><<<nb, kB, lds>>>(in, ain, out, aout, n, n); }, reps), bytes);
   }
+  // 1024-thread workgroups: 16 waves per workgroup; 2 / 1 of them per CU through the LDS limiter
+  line("soa  nt, 1024-thread WGs", timeit([&] { k_soa_wg<E, 1024><<<(n + 1023) / 1024, 1024>>>(in, ain, out, aout, n); }, reps), bytes);
+  line("soa  nt, 1024-thread WGs, 1 per CU", timeit([&] { k_soa_wg<E, 1024><<<(n + 1023) / 1024, 1024, 100 * 1024>>>(in, ain, out, aout, n); }, reps), bytes);
+  line("soa  nt, 512-thread WGs, 2 per CU", timeit([&] { k_soa_wg<E, 512><<<(n + 511) / 512, 512, 70 * 1024>>>(in, ain, out, aout, n); }, reps), bytes);
+  line("soa  nt, 512-thread WGs, 1 per CU", timeit([&] { k_soa_wg<E, 512><<<(n + 511) / 512, 512, 100 * 1024>>>(in, ain, out, aout, n); }, reps), bytes);
   for (int64_t pad : pads) {
     char name[64];
     snprintf(name, sizeof name, "soa  nt, row pitch + %lld B", (long long)pad * 8);
@@ -231,7 +278,7 @@ static int run(int64_t n) {
   }
   CK(hipGetLastError());
   CK(hipDeviceSynchronize());
-  hipFree(in); hipFree(out); hipFree(ain); hipFree(aout);
+  hipFree(in); hipFree(out); hipFree(ain); hipFree(aout); hipFree(ro);
   return 0;
 }
 
