@@ -1445,10 +1445,16 @@ inline int chain_waves() {
   const char* wv = getenv("ART_CHAIN_WAVES");
   return wv ? atoi(wv) : 5;
 }
-// ART_CHAIN_RPL=2: the two-rays-per-lane body (chain_body2) for chains without defects
-inline int chain_rpl() {   // read at every call: tools/ab_kernel.py alternates the variants inside one process
+// Which body traces a chain without defects: chain_body (one ray per lane, outputs regrouped through LDS) or chain_body2
+// (two rays per lane, no staging).  Measured A/B inside one process (tools/ab_kernel.py, profiles/r03_experiments.md): the
+// two-ray body is 4-7 % faster on chains behind a MASK (C2, C3: a third to a half of the slots are dead -- it skips a
+// dead pair with one branch and two dropped offsets, where the one-ray body still stages, synchronises and issues the
+// workgroup's stores) and -3 ... +9 % elsewhere, box-dependent; so it is the default exactly where a mask is part of the
+// launch.  ART_CHAIN_RPL=1|2 overrides (read at every call: the A/B tool alternates the variants inside one process).
+inline int chain_rpl(const bool has_mask) {
   const char* e = getenv("ART_CHAIN_RPL");
-  return (e && atoi(e) == 2) ? 2 : 1;
+  if (e && (atoi(e) == 1 || atoi(e) == 2)) return atoi(e);
+  return has_mask ? 2 : 1;
 }
 // ART_CHAIN_DYN_LDS=<bytes>: unused dynamic LDS per workgroup of the fused kernel, i.e. FEWER resident workgroups per CU
 // (20 KB static + 20480 -> 4, + 33000 -> 3).  An experiment knob: the bare access pattern gains 3-7 % of bandwidth with 2-3
@@ -1531,16 +1537,14 @@ static int trace_chain_impl(const ArtElementDesc* elems, int32_t n_elems, const 
       if (lds > 64 * 1024) return fail(ART_ERR_UNSUPPORTED, "ART_ZERN_LDS build: Zernike tables of one fused launch exceed 64 KiB");
 #endif
       const int xm = xcd_map();
-      const bool two = chain_rpl() == 2 && !(a.flags & art::kFlagDefects);
+      bool has_mask = false;
+      for (int k = 0; k < m; ++k) has_mask = has_mask || a.e[k].kind == ART_MASK;
+      const bool two = !(a.flags & art::kFlagDefects) && chain_rpl(has_mask) == 2;
       const dim3 g(grid_stream_mapped(two ? (cnt + 1) / 2 : cnt, xm)), b(kBlock);
       if (a.flags & art::kFlagDefects)
         hipLaunchKernelGGL((k_trace_chain<true, 4>), dim3(kDefectLoop ? grid_for(cnt) : grid_stream_mapped(cnt, xm)), b, lds,
                            s, a, cnt, kDefectLoop ? 0 : xm);
-      else if (two && waves == 5)
-        hipLaunchKernelGGL((k_trace_chain2<false, 5>), g, b, chain_dyn_lds(), s, a, cnt, xm);
-      else if (two && waves == 3)
-        hipLaunchKernelGGL((k_trace_chain2<false, 3>), g, b, chain_dyn_lds(), s, a, cnt, xm);
-      else if (two)
+      else if (two)       // 107 VGPRs: 4 waves per SIMD (3 and 5 measured the same or worse, tools/ab_kernel.py)
         hipLaunchKernelGGL((k_trace_chain2<false, 4>), g, b, chain_dyn_lds(), s, a, cnt, xm);
       else if (waves == 6)
         hipLaunchKernelGGL((k_trace_chain<false, 6>), g, b, chain_dyn_lds(), s, a, cnt, xm);
@@ -1598,7 +1602,7 @@ int art_trace_scene(const void* image_dev, const void* image_host, int64_t n, vo
   if (h.magic != art::kSceneMagic) return fail(ART_ERR_BAD_ARG, "host image was not written by art_scene_pack");
   const int32_t n_chains = h.n_chains, n_elems = h.n_elems, flags = h.flags;
   if (n_chains <= 0 || n_chains > 65535 || n_elems <= 0 || h.n_segments != art::scene_segments(n_elems) ||
-      (flags & ~(art::kFlagDefects | art::kFlagReadout)))
+      (flags & ~(art::kFlagDefects | art::kFlagReadout | art::kFlagMask)))
     return fail(ART_ERR_BAD_ARG, "scene header is corrupt");
   if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
 #ifdef ART_ZERN_LDS
@@ -1619,14 +1623,12 @@ int art_trace_scene(const void* image_dev, const void* image_host, int64_t n, vo
   for (int64_t off = 0; off < n; off += chunk) {
     const int64_t cnt = (n - off < chunk) ? n - off : chunk;
     const int xm = xcd_map();
-    const bool two = chain_rpl() == 2 && !(flags & 1);
+    const bool two = !(flags & 1) && chain_rpl((flags & art::kFlagMask) != 0) == 2;
     const dim3 g(grid_stream_mapped(two ? (cnt + 1) / 2 : cnt, xm), n_chains), b(kBlock);
     for (int sg = 0; sg < S; ++sg) {
       const ChainArgs* seg = tab + (int64_t)sg * n_chains;
       if (flags & 1)
         hipLaunchKernelGGL((k_trace_scene<true, 4>), g, b, 0, s, seg, off, cnt, xm);
-      else if (two && waves == 5)
-        hipLaunchKernelGGL((k_trace_scene2<false, 5>), g, b, 0, s, seg, off, cnt, xm);
       else if (two)
         hipLaunchKernelGGL((k_trace_scene2<false, 4>), g, b, 0, s, seg, off, cnt, xm);
       else if (waves == 6)

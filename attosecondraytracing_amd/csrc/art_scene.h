@@ -30,6 +30,7 @@ struct ChainArgs {
   int32_t flags;                 // bit 0: some element carries Zernike or gridded defects; bit 1: `ro` is set
 };
 constexpr int kFlagDefects = 1, kFlagReadout = 2;
+constexpr int kFlagMask = 4;     // scene header only: some chain contains a mask (selects the body of the launch)
 
 inline bool readout_ok(const ArtChainReadout& r) {
   const int outs = (r.X != nullptr) + (r.Y != nullptr) + (r.opl != nullptr);
@@ -92,6 +93,7 @@ inline int scene_pack(const ArtElementDesc* elems, int n_chains, int n_elems, co
         a.e[k] = e;
         prepare_element(a.e[k]);
         if (e.n_defects > 0 || e.n_grid > 0) { a.flags |= kFlagDefects; h.flags |= kFlagDefects; }
+        if (e.kind == ART_MASK) h.flags |= kFlagMask;
         const ArtBundleView& o = outs[(int64_t)c * n_elems + k0 + k];
         if (o.alive != nullptr && !scene_view_ok(o)) { *err = "history view partially NULL"; return ART_ERR_BAD_ARG; }
         a.out[k] = o;

@@ -61,6 +61,20 @@ def test_fused_chain_kernel_occupancy(kernels):
         assert not [l for l in k["code"] if re.search(r"scratch_(load|store)|Folded (Spill|Reload)", l)], name
 
 
+def test_two_rays_per_lane_body(kernels):
+    """The body chains with a mask are traced by (two neighbouring slots per lane): 4 waves per SIMD without scratch, ONE
+    barrier (the read-out tail's), 16-byte accesses for all fp64 streams, and -- like the one-ray body -- no wait on vmcnt
+    and no load after its first store."""
+    for name in ("k_trace_chain2<false, 4>", "k_trace_scene2<false, 4>"):
+        k = kernels[name]
+        assert k["vgpr"] <= 128 and k["scratch"] == 0 and k["lds"] <= 32 * 1024, (name, k["vgpr"], k["scratch"], k["lds"])
+        code = k["code"]
+        assert sum("s_barrier" in l for l in code) == 1, name
+        assert sum("buffer_store_dwordx4" in l for l in code) == 11 and sum("buffer_load_dwordx4" in l for l in code) == 8, name
+        assert not _after_first_store(code, r"s_waitcnt.*vmcnt"), name
+        assert not _after_first_store(code, r"\b(buffer_load|global_load|flat_load|scratch_load)\b"), name
+
+
 def test_no_wait_for_store_acknowledgements(kernels):
     for name in ("k_trace_chain<false, 5>", "k_trace_scene<false, 5>"):
         waits = _after_first_store(kernels[name]["code"], r"s_waitcnt.*vmcnt")
