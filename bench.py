@@ -474,8 +474,12 @@ def worker(args):
     # one resident source shard shared by all chains (OEPlacement gives every chain of a loop list the same source)
     src = device_source(n, first, n_total, be, src_kind, wl, step=stride)
     batched = n_chains > 1
-    # small bundles are launch-bound: replay the whole step (trace + read-outs) from a HIP graph
-    use_graph = on_gpu and (args.graph == "on" or (args.graph == "auto" and (batched or n <= 2_000_000)))
+    # The whole step (trace + read-outs) is replayed from a HIP graph (graph.SceneProgram, the product's compiled-scene
+    # path): small bundles are launch-bound without it, and at 1e7 rays -- where the eager step is GPU-bound on a quiet
+    # host (0.09 ms of Python per 0.65-ms step) -- it takes the host out of the measurement: on a box whose host was busy
+    # the eager relay4 step took 1.25 ms for a 0.72-ms kernel (host_enqueue_ms_per_step 0.67; profiles/r03_experiments.md).
+    # `--graph off` issues eager launches.
+    use_graph = on_gpu and args.graph in ("on", "auto") and mode == "chain"
 
     # detectors: placed once (untimed) from the mean ray of each chain's last bundle, like ARTmain.setup_detector
     if batched:
@@ -643,34 +647,6 @@ def worker(args):
         saved_w, args.warmup = args.warmup, 0
         dt_sus, _, o, r = timed(False, args.steps)
         args.warmup = saved_w
-    # Box state UNDER LOAD (VERDICT r2 #5b: boxes of the pool differ by up to 20 % on this access pattern): one rocm-smi
-    # query runs while the device keeps tracing; clocks, power and partition modes go on the line beside the numbers.
-    box = None
-    if on_gpu and rank == 0 and not use_dist:
-        box = {"idle_before_run": smi_result(smi_idle, local)}
-        q = smi_start()
-        t_end = time.perf_counter() + 10.0
-        while q is not None and q.poll() is None and time.perf_counter() < t_end:
-            for _ in range(50):
-                step(False)
-            sync()
-        box["under_load"] = smi_result(q, local)
-    dt_lazy = None
-    if on_gpu and not use_dist and (program is None or program_lazy is not None):
-        for _ in range(args.warmup):
-            ol, rl = trace_and_readout_lazy()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            ol, rl = trace_and_readout_lazy()
-        sync()
-        dt_lazy = time.perf_counter() - t0
-        # the analysed bundle and its read-out are the full-history step's, bit for bit
-        assert torch.equal(ol[-1][-1].alive, o[-1][-1].alive)
-        lv_ = o[-1][-1].alive.bool()
-        assert torch.equal(ol[-1][-1].data[:, lv_].view(torch.int64), o[-1][-1].data[:, lv_].view(torch.int64))
-        assert torch.equal(rl[-1]["stats_dev"].view(torch.int64), r[-1]["stats_dev"].view(torch.int64))
-        del ol, rl
     stats_host = (state["stats"] if use_dist else r[-1]["stats_dev"]).cpu().numpy()
     assert stats_host[0] == surv_last_job and np.isfinite(stats_host[1]), (stats_host[0], surv_last_job)
 
@@ -696,6 +672,37 @@ def worker(args):
         if ro_ev:
             readout_ms = float(np.mean([a.elapsed_time(b) for a, b in ro_ev]))  # one read-out (kernel + 24-slot fold)
 
+    # (Everything below runs AFTER the timed regions and the event-bracketed passes: the load loop of the box-state query
+    # keeps the device at its 1400-W power cap for about a second, after which the clocks are throttled -- kernel times
+    # measured behind it read 10 % high.)
+    dt_lazy = None
+    if on_gpu and not use_dist and (program is None or program_lazy is not None):
+        for _ in range(args.warmup):
+            ol, rl = trace_and_readout_lazy()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ol, rl = trace_and_readout_lazy()
+        sync()
+        dt_lazy = time.perf_counter() - t0
+        # the analysed bundle and its read-out are the full-history step's, bit for bit
+        assert torch.equal(ol[-1][-1].alive, o[-1][-1].alive)
+        lv_ = o[-1][-1].alive.bool()
+        assert torch.equal(ol[-1][-1].data[:, lv_].view(torch.int64), o[-1][-1].data[:, lv_].view(torch.int64))
+        assert torch.equal(rl[-1]["stats_dev"].view(torch.int64), r[-1]["stats_dev"].view(torch.int64))
+        del ol, rl
+    # Box state UNDER LOAD (VERDICT r2 #5b: boxes of the pool differ by up to 20 % on this access pattern): one rocm-smi
+    # query runs while the device keeps tracing; clocks, power and partition modes go on the line beside the numbers.
+    box = None
+    if on_gpu and rank == 0 and not use_dist:
+        box = {"idle_before_run": smi_result(smi_idle, local)}
+        q = smi_start()
+        t_end = time.perf_counter() + 10.0
+        while q is not None and q.poll() is None and time.perf_counter() < t_end:
+            for _ in range(50):
+                step(False)
+            sync()
+        box["under_load"] = smi_result(q, local)
     if rank == 0:
         value = inter_per_step_job * args.steps / dt
         res = {
@@ -864,8 +871,7 @@ def main(argv=None):
     ap.add_argument("--mirrors", type=int, default=4, help="relay4 only: number of toroidal mirrors")
     ap.add_argument("--mode", default=None, choices=[None, "chain", "element"])
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                    help="replay the step from a HIP graph (auto: for the multi-chain configurations and for bundles of "
-                         "at most 2e6 rays, where eager launches are host-bound)")
+                    help="replay the step from a HIP graph (auto = on); off: eager launches")
     ap.add_argument("--shard", default="blocks", choices=["blocks", "strided"],
                     help="N > 1: contiguous index ranges per rank (default) or rank r traces rays r, r + N, ...")
     ap.add_argument("--readout", default="auto", choices=["auto", "fused", "separate"],
