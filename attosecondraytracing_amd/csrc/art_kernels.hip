@@ -321,10 +321,16 @@ __device__ __forceinline__ void fold_slot(const double* scratch, const int nbloc
                                           double* out) {
   const int k = blockIdx.x;
   const int op[1] = {op_k};
-  double acc[1] = {(op_k == RSUM) ? 0.0 : (op_k == RMIN ? INFINITY : -INFINITY)};
-  for (int blk = threadIdx.x; blk < nblocks; blk += kBlock) {
-    const double v = scratch[(int64_t)blk * ns + k];
-    acc[0] = (op_k == RSUM) ? acc[0] + v : (op_k == RMIN ? fmin(acc[0], v) : fmax(acc[0], v));
+  const double ident = (op_k == RSUM) ? 0.0 : (op_k == RMIN ? INFINITY : -INFINITY);
+  double acc[1] = {ident};
+  constexpr int kU = 8;     // loads in flight per thread (one at a time they are that many memory latencies in a row)
+  for (int blk = threadIdx.x; blk < nblocks; blk += kBlock * kU) {
+    double v[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) v[u] = (blk + u * kBlock < nblocks) ? scratch[(int64_t)(blk + u * kBlock) * ns + k] : ident;
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+      acc[0] = (op_k == RSUM) ? acc[0] + v[u] : (op_k == RMIN ? fmin(acc[0], v[u]) : fmax(acc[0], v[u]));
   }
   block_reduce_store<1>(acc, op, out + k);
 }
@@ -720,8 +726,21 @@ __device__ __forceinline__ double fold_op(const double a, const double b, const 
 __device__ __forceinline__ void fold_range(const double* row, const int64_t lo, const int64_t hi, const int op_k,
                                            double* out) {
   __shared__ double s[kFoldBlock / 64];
-  double acc = (op_k == RSUM) ? 0.0 : (op_k == RMIN ? INFINITY : -INFINITY);
-  for (int64_t p = lo + threadIdx.x; p < hi; p += blockDim.x) acc = fold_op(acc, row[p], op_k);
+  const double ident = (op_k == RSUM) ? 0.0 : (op_k == RMIN ? INFINITY : -INFINITY);
+  double acc = ident;
+  // eight loads in flight per thread before the first is folded (a thread's ~40 values one load at a time are 40 memory
+  // latencies in a row: 17 us per 1e7 rays, measured); the fold order stays fixed: p, p + B, p + 2B, ...
+  constexpr int kU = 8;
+  for (int64_t p = lo + threadIdx.x; p < hi; p += (int64_t)blockDim.x * kU) {
+    double v[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int64_t q = p + (int64_t)u * blockDim.x;
+      v[u] = (q < hi) ? row[q] : ident;
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) acc = fold_op(acc, v[u], op_k);
+  }
   acc = wave_reduce(acc, op_k);
   if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
   __syncthreads();

@@ -101,36 +101,75 @@ def launch_workers(n, argv):
     return 0
 
 
-# =========================================================================================== box state (read-only sysfs queries)
+# =========================================================================================== box state (read-only queries)
 SMI_ARGS = ["rocm-smi", "--showclocks", "--showperflevel", "--showpower", "--showmaxpower", "--showmemorypartition",
             "--showcomputepartition", "--showtemp", "--json"]
-
-
-def smi_start():
-    """Start one rocm-smi query (clocks, power, power cap, partition modes); it reads sysfs and touches no queue."""
+_SMI_HELPER = r"""
+import subprocess, sys
+for line in sys.stdin:
     try:
-        return subprocess.Popen(SMI_ARGS, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
-    except OSError:
-        return None
+        out = subprocess.run(%r, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=30).stdout.decode(errors="replace")
+    except Exception as e:
+        out = "{}"
+    sys.stdout.write(out.replace("\n", " ") + "\n")
+    sys.stdout.flush()
+""" % (SMI_ARGS,)
 
 
-def smi_result(p, card):
-    """Compact dict of the query's fields for device `card` (clock levels, power, partitions), or None."""
-    if p is None:
-        return None
-    try:
-        out = p.communicate(timeout=20)[0].decode(errors="replace")
-        j = json.loads(out[out.index("{"):])
-        c = j.get(f"card{card}", next(iter(j.values())))
-        keep = {}
-        for k, v in c.items():
-            kl = k.lower()
-            if any(t in kl for t in ("clock", "power", "partition", "performance", "temperature (sensor junction)",
-                                     "temperature (sensor memory)")):
-                keep[k] = v
-        return keep
-    except Exception as e:    # noqa: BLE001 -- a diagnostic must never cost the result line
-        return {"error": repr(e)[:200]}
+class BoxState:
+    """rocm-smi queries (clocks, power, power cap, partition modes: sysfs reads, no queue touched) through a helper
+    process that is started BEFORE this process initialises the GPU: nothing is ever exec'ed from a GPU-initialised
+    process (a rule of the pool).  Under rocprofv3 the profiler's preloaded library has initialised the GPU before main()
+    runs, so no helper is started there: tools/prof.sh records the box state beside the passes itself."""
+
+    def __init__(self):
+        self.p = None
+        if "rocprof" in os.environ.get("LD_PRELOAD", "") or "ROCP_TOOL_LIBRARIES" in os.environ:
+            return
+        try:
+            self.p = subprocess.Popen([sys.executable, "-c", _SMI_HELPER], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                      stderr=subprocess.DEVNULL)
+        except OSError:
+            self.p = None
+
+    def ask(self):
+        """Start one query; returns immediately (read it with `answer`)."""
+        if self.p is None:
+            return False
+        try:
+            self.p.stdin.write(b"q\n")
+            self.p.stdin.flush()
+            return True
+        except OSError:
+            self.p = None
+            return False
+
+    def ready(self):
+        import select
+        return self.p is None or bool(select.select([self.p.stdout], [], [], 0)[0])
+
+    def answer(self, card):
+        """Compact dict of the pending query's fields for device `card` (clock levels, power, partitions), or None."""
+        if self.p is None:
+            return None
+        try:
+            out = self.p.stdout.readline().decode(errors="replace")
+            j = json.loads(out[out.index("{"):])
+            c = j.get(f"card{card}", next(iter(j.values())))
+            return {k: v for k, v in c.items()
+                    if any(t in k.lower() for t in ("clock", "power", "partition", "performance", "temperature (sensor junction)",
+                                                    "temperature (sensor memory)"))}
+        except Exception as e:    # noqa: BLE001 -- a diagnostic must never cost the result line
+            return {"error": repr(e)[:200]}
+
+    def close(self):
+        if self.p is not None:
+            try:
+                self.p.stdin.close()
+                self.p.wait(timeout=5)
+            except Exception:     # noqa: BLE001
+                pass
+            self.p = None
 
 
 # =========================================================================================== scenes
@@ -389,6 +428,9 @@ def worker(args):
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # started before anything below touches the GPU; the first query describes the box before this run loads it
+    boxq = BoxState() if (rank == 0 and os.environ.get("ART_BENCH_BACKEND_HOOK") is None) else None
+    box_idle_pending = boxq.ask() if boxq else False
     # ART_BENCH_BACKEND_HOOK="module:function" (TEST HOOK, tests/test_bench_launcher.py): install another backend
     # before the workload starts, so that the launcher and the distributed logic of this file can be exercised by CPU
     # ranks over gloo.  Never set on a GPU box; the product itself has no such switch (attosecondraytracing_amd/_lib.py).
@@ -418,7 +460,6 @@ def worker(args):
         if on_gpu:
             torch.cuda.synchronize()
 
-    smi_idle = smi_start() if (on_gpu and rank == 0) else None      # the box before this run loads it
 
     def barrier():
         if use_dist:
@@ -694,15 +735,17 @@ def worker(args):
     # Box state UNDER LOAD (VERDICT r2 #5b: boxes of the pool differ by up to 20 % on this access pattern): one rocm-smi
     # query runs while the device keeps tracing; clocks, power and partition modes go on the line beside the numbers.
     box = None
-    if on_gpu and rank == 0 and not use_dist:
-        box = {"idle_before_run": smi_result(smi_idle, local)}
-        q = smi_start()
-        t_end = time.perf_counter() + 10.0
-        while q is not None and q.poll() is None and time.perf_counter() < t_end:
-            for _ in range(50):
-                step(False)
-            sync()
-        box["under_load"] = smi_result(q, local)
+    if on_gpu and rank == 0 and not use_dist and boxq is not None and boxq.p is not None:
+        box = {"idle_before_run": boxq.answer(local) if box_idle_pending else None}
+        if boxq.ask():
+            t_end = time.perf_counter() + 10.0
+            while not boxq.ready() and time.perf_counter() < t_end:
+                for _ in range(50):
+                    step(False)
+                sync()
+            box["under_load"] = boxq.answer(local)
+    if boxq is not None:
+        boxq.close()
     if rank == 0:
         value = inter_per_step_job * args.steps / dt
         res = {
