@@ -1,6 +1,7 @@
 """Rays sharded over the GPUs of one node (one process per GPU, RCCL): every rank generates and traces its own index
-range of one big point source; per step the ranks exchange their read-out statistics and a sample of the read-out in
-one all-gather (sharding.Exchange); rank 0 prints the global result.
+range of one big point source; the ranks exchange their read-out statistics and a sample of the read-out in one
+all-gather (sharding.Exchange), then rank 0 gathers the surviving rays' (number, X, Y, optical path) records -- 28 bytes
+per survivor, one collective (sharding.SurvivorGather) -- and prints the global result.
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \\
         examples/sharded_trace.py [total_rays]
@@ -55,8 +56,17 @@ det.autoplace(chain.get_output_rays()[-1], focal)
 ro = det.readout(out[-1], sync=False)
 exchange = sharding.Exchange(be, hi - lo, sample=20000)
 stats, sample = exchange(ro["stats_dev"], ro["X"], ro["Y"], ro["opl"], out[-1].alive)
+# every SURVIVING ray's read-out to rank 0, in global ray order
+specs = [sharding.shard_spec(n_total, rk, world) for rk in range(world)]
+gather = sharding.SurvivorGather(be, hi - lo, world, rank, dst=0, buffers=1, specs=specs)
+sent = gather.start(0, ro["X"], ro["Y"], ro["opl"], out[-1].alive)
+gather.drain()
 s = stats.cpu().numpy()
 if rank == 0:
+    number, X, Y, path = gather.assemble(0)
+    assert number.numel() == int(s[0]) and bool((number[1:] > number[:-1]).all())
+    delays_fs = (path - path.mean()) / mdet.LightSpeed * 1e15           # Detector.get_Delays, ART/ModuleDetector.py:272-279
+    print(f"gathered {number.numel()} survivor records ({sent} B per rank): delay std {float(delays_fs.std()):.4f} fs")
     count, mean_path = s[0], s[1] / s[0]
     var_x = s[16] / count - (s[6] / count) ** 2
     var_y = s[17] / count - (s[7] / count) ** 2

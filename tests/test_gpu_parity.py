@@ -582,6 +582,7 @@ def test_gpu_scene_program_replays(hip):
     """graph.SceneProgram: pose updates rewrite the device-resident table, the captured HIP graph is replayed."""
     import scene_cases
     scene_cases.run_program_updates()
+    scene_cases.run_program_history_off()
     scene_cases.run_chain_list_cache()
 
 

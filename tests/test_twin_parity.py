@@ -90,6 +90,7 @@ def test_twin_batched_variants(twin):
 def test_twin_scene_program(twin):
     import scene_cases
     scene_cases.run_program_updates()
+    scene_cases.run_program_history_off()
     scene_cases.run_chain_list_cache()
 
 
