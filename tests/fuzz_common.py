@@ -167,9 +167,23 @@ def pose_noise(e):
 # on the product's OWN incoming rays: relative to the scene scale for positions and segment lengths, absolute for
 # directions (unit vectors) and incidence angles (rad).  The bars do NOT grow along a chain -- a 1e-11-level regression
 # of any intersector, normal or reflection fails here whatever the conditioning of the scene.
-# Measured over 6 000 random scenes on the CPU twin: pos <= 2.2e-13, segment <= 2.5e-13, dir <= 5.7e-12 (strongly curved
-# optics: a hit-point error dP turns the normal by dP / rc), incidence <= 2.4e-12.
-LOCAL_TOL = {"pos": 1e-12, "dir": 2e-11, "seg": 1e-12, "inc": 2e-11}
+# Measured over 6 000 random scenes on the CPU twin and 20 000 on the GPU: pos <= 1.1e-12 (a toroid with r = 37 mm under
+# grazing incidence in a 1 300-mm scene: 1.5e-9 mm, the torus solver's stopping criterion), segment <= 8e-13.  Direction
+# and incidence follow the hit point: an error dP turns the normal of a surface with curvature radius rc by dP / rc and
+# the reflected direction by twice that, so their bar is 5e-12 + 4 dP / rc with the MEASURED dP of the same element
+# (local_dir_tol below): a direction error without a hit-point error behind it fails at 5e-12.
+LOCAL_TOL = {"pos": 3e-12, "dir": 5e-12, "seg": 3e-12, "inc": 5e-12}
+
+
+def curvature_radius(e):
+    """Smallest curvature radius (mm) of an optic's surface, None for flat ones."""
+    return {"sphere": e.get("R"), "cylinder": e.get("R"), "torus": e.get("r"), "parabola": e.get("p"),
+            "ellipsoid": (e.get("b", 0) ** 2 / e["a"]) if "a" in e else None}.get(e["kind"])
+
+
+def local_dir_tol(e, loc, scale):
+    rc = curvature_radius(e)
+    return LOCAL_TOL["dir"] + (4.0 * max(loc["pos"], loc["seg"]) * scale / rc if rc else 0.0)
 STRICT_TOL = {"pos": pc.REL_TOL, "dir": pc.REL_TOL, "path": pc.REL_TOL, "inc": 1e-9}    # product vs oracle, no allowances
 
 
@@ -241,7 +255,7 @@ def run_differential(seeds, modes=("chain", "element"), n_rays=1500, stats=None)
                     loc = _local_truth_errors(els_o[k], prev, out, scale, scene["IgnoreDefects"], well)
                     if loc is not None:
                         for key, v in loc.items():
-                            lim = LOCAL_TOL[key] + noise[k]
+                            lim = (local_dir_tol(e, loc, scale) if key in ("dir", "inc") else LOCAL_TOL[key]) + noise[k]
                             assert v <= lim, (f"{tag}, mode {mode}, element {k}: LOCAL {key} error {v:.3e} > {lim:.1e} "
                                               f"against the long-double truth")
                             stats["local_worst"][key] = max(stats["local_worst"][key], v)

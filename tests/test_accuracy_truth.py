@@ -120,8 +120,10 @@ def check_every_element_against_truth(name):
         ref_prev = (num, a[f"out{k}_point"], a[f"out{k}_vector"])
         our_prev = (num, outs[k].points(), outs[k].vectors())
     noise = sum(fz.pose_noise(e) for e in scene["elements"])
+    rcs = [fz.curvature_radius(e) for e in scene["elements"]]
+    curv = 4.0 * max(worst["product"]["pos"], worst["product"]["seg"]) * scale / min([r for r in rcs if r] or [np.inf])
     for key, lim in fz.LOCAL_TOL.items():
-        assert worst["product"][key] <= lim + noise, (name, key, worst["product"][key])
+        assert worst["product"][key] <= lim + noise + (curv if key in ("dir", "inc") else 0.0), (name, key, worst["product"][key])
         assert worst["reference"][key] <= 1e-10 + noise, (name, key, worst["reference"][key])     # the reference's own accuracy
     return worst
 

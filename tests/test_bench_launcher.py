@@ -87,3 +87,25 @@ def test_launcher_ends_all_ranks_when_one_fails():
     assert p.returncode != 0 and time.time() - t0 < 120
     assert "rank 1 fails on purpose" in p.stderr and "worker exit codes" in p.stderr
     assert not [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+
+
+def test_profile_of_another_build_is_dropped(monkeypatch):
+    """bench.py quotes counted HBM bytes only from a profile taken on THIS build (source hash of csrc/* + the C header);
+    otherwise the line falls back to the compulsory bytes it computes itself and names the dropped profile."""
+    import glob
+    sys.path.insert(0, ROOT)
+    import bench
+    import tools.source_hash as sh
+    profs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_relay4.json")))
+    assert profs, "no committed relay4 profile"
+    newest = json.load(open(profs[-1]))
+    kernel = next(k for k in newest["per_launch"] if k.startswith("k_trace_"))
+    prefix = kernel.split("<")[0] + "<"
+    monkeypatch.setattr(sh, "source_hash", lambda root=None: newest["source_hash"])
+    hit, note = bench.profiled_traffic("relay4", prefix, newest["rays_per_gpu"])
+    assert hit is not None and hit[1].endswith(os.path.basename(profs[-1])) and note is None
+    monkeypatch.setattr(sh, "source_hash", lambda root=None: "0123456789abcdef")
+    hit, note = bench.profiled_traffic("relay4", prefix, newest["rays_per_gpu"])
+    assert hit is None and "dropped" in note and os.path.basename(profs[-1]) in note
+    # the tree's own hash is a pure function of the four source files
+    assert len(sh.__dict__["FILES"]) == 4 and all(os.path.exists(os.path.join(ROOT, f)) for f in sh.FILES)

@@ -49,7 +49,7 @@ def _compare(oe, Eo, n=600, seed=42, second=None):
             e = {"pos": float(np.abs(out.points() - P).max() / 100), "dir": float(np.abs(out.vectors() - v).max()),
                  "seg": float(np.abs(out.path_segments()[:, -1] - t).max() / 100), "inc": float(np.abs(out.incidences() - inc).max())}
             for k, val in e.items():
-                assert val <= fz.LOCAL_TOL[k], (k, val, ign)
+                assert val <= fz.LOCAL_TOL[k] + (4e-12 * 100 / 500 if k in ("dir", "inc") else 0.0), (k, val, ign)
                 worst[k] = max(worst.get(k, 0.0), val)
     return worst
 

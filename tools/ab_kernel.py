@@ -41,11 +41,12 @@ def main():
         n = args.rays or 10_000_000
     else:
         element_lists, kind, dist = getattr(bench, "scene_" + args.config.lower())()
-        n = args.rays or {"C2": 1_000_000, "C3": 10_000_000, "C4": 12_500_000}[args.config]
-    src = bench.device_source(n, 0, n, be, kind)
+        n = args.rays or {"C2": 1_000_000, "C3": 10_000_000, "C4": 12_500_000, "C5": 10_000_000}[args.config]
+    ign = args.config != "C5"          # C5: Zernike surface with perturbed normals
+    src = bench.device_source(n, 0, n, be, kind, 800e-6 if args.config == "C5" else 50e-6)
     dets = []
     for els in element_lists:
-        out = mp.RayTracingCalculation(src, els)
+        out = mp.RayTracingCalculation(src, els, IgnoreDefects=ign)
         d = mdet.Detector(np.asarray(els[-1].position, dtype=float))
         d.autoplace(out[-1], dist)
         dets.append(d)
@@ -54,9 +55,10 @@ def main():
 
     def launch():
         if many:
-            return mp.RayTracingCalculationMany([src] * len(element_lists), element_lists,
+            return mp.RayTracingCalculationMany([src] * len(element_lists), element_lists, IgnoreDefects=ign,
                                                 detectors=dets if args.readout == "fused" else None)
-        return mp.RayTracingCalculation(src, element_lists[0], detector=dets[0] if args.readout == "fused" else None)
+        return mp.RayTracingCalculation(src, element_lists[0], IgnoreDefects=ign,
+                                        detector=dets[0] if args.readout == "fused" else None)
 
     variants = [v.strip() for v in args.variants.split(";")]
     knobs = sorted({kv.split("=")[0] for v in variants for kv in v.split() if "=" in kv})
