@@ -1558,13 +1558,11 @@ static int trace_chain_impl(const ArtElementDesc* elems, int32_t n_elems, const 
       const int xm = xcd_map();
       bool has_mask = false;
       for (int k = 0; k < m; ++k) has_mask = has_mask || a.e[k].kind == ART_MASK;
-      const char* rpl_env = getenv("ART_CHAIN_RPL");
-      const bool two_def = (a.flags & art::kFlagDefects) && !kDefectLoop && rpl_env && atoi(rpl_env) == 2;   // experiment
-      const bool two = two_def || (!(a.flags & art::kFlagDefects) && chain_rpl(has_mask) == 2);
+      // (chains WITH defects keep the one-ray body: the two-ray one needs 133 VGPRs = 3 waves per SIMD there and measured
+      // +1.6 % on C5 with the read-out, the same without; profiles/r03_experiments.md)
+      const bool two = !(a.flags & art::kFlagDefects) && chain_rpl(has_mask) == 2;
       const dim3 g(grid_stream_mapped(two ? (cnt + 1) / 2 : cnt, xm)), b(kBlock);
-      if (two_def)
-        hipLaunchKernelGGL((k_trace_chain2<true, 3>), g, b, lds, s, a, cnt, xm);
-      else if (a.flags & art::kFlagDefects)
+      if (a.flags & art::kFlagDefects)
         hipLaunchKernelGGL((k_trace_chain<true, 4>), dim3(kDefectLoop ? grid_for(cnt) : grid_stream_mapped(cnt, xm)), b, lds,
                            s, a, cnt, kDefectLoop ? 0 : xm);
       else if (two)       // 107 VGPRs: 4 waves per SIMD (3 and 5 measured the same or worse, tools/ab_kernel.py)
@@ -1646,15 +1644,11 @@ int art_trace_scene(const void* image_dev, const void* image_host, int64_t n, vo
   for (int64_t off = 0; off < n; off += chunk) {
     const int64_t cnt = (n - off < chunk) ? n - off : chunk;
     const int xm = xcd_map();
-    const char* rpl_env = getenv("ART_CHAIN_RPL");
-    const bool two_def = (flags & 1) && !kDefectLoop && rpl_env && atoi(rpl_env) == 2;   // experiment
-    const bool two = two_def || (!(flags & 1) && chain_rpl((flags & art::kFlagMask) != 0) == 2);
+    const bool two = !(flags & 1) && chain_rpl((flags & art::kFlagMask) != 0) == 2;
     const dim3 g(grid_stream_mapped(two ? (cnt + 1) / 2 : cnt, xm), n_chains), b(kBlock);
     for (int sg = 0; sg < S; ++sg) {
       const ChainArgs* seg = tab + (int64_t)sg * n_chains;
-      if (two_def)
-        hipLaunchKernelGGL((k_trace_scene2<true, 3>), g, b, 0, s, seg, off, cnt, xm);
-      else if (flags & 1)
+      if (flags & 1)
         hipLaunchKernelGGL((k_trace_scene<true, 4>), g, b, 0, s, seg, off, cnt, xm);
       else if (two)
         hipLaunchKernelGGL((k_trace_scene2<false, 4>), g, b, 0, s, seg, off, cnt, xm);

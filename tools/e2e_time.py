@@ -10,7 +10,9 @@ import ART.ModuleOpticalChain as moc
 import ARTmain
 
 rays = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
-batched = (sys.argv[2] if len(sys.argv) > 2 else "batched") == "batched"
+how = sys.argv[2] if len(sys.argv) > 2 else "batched"       # batched | lazy (batched, only the analysed bundle written) | loop
+batched = how in ("batched", "lazy")
+kw = {"history": "lazy"} if how == "lazy" else {}
 source = dict(Divergence=25e-3, SourceSize=0, Wavelength=50e-6, DeltaFT=0.5, NumberRays=rays)
 R, r = mmirror.ReturnOptimalToroidalRadii(600, 80)
 toroid = mmirror.MirrorToroidal(R, r, msupp.SupportRectangle(200, 30))
@@ -23,13 +25,13 @@ for rep in range(2):
     chains = mp.OEPlacement(source, [mask, toroid, toroid], [500, 100, 600], [0, 80, -80], [0, 0, np.linspace(-90, 90, 10)], "C3")
     torch.cuda.synchronize(); t1 = time.perf_counter()
     if batched:
-        moc.trace_chain_list(chains)
+        moc.trace_chain_list(chains, **kw)
     else:
         for ch in chains:
             ch.get_output_rays()
     torch.cuda.synchronize(); t2 = time.perf_counter()
     res = [ARTmain.run_ART(ch, SP, DO, AO, True) for ch in chains]
     torch.cuda.synchronize(); t3 = time.perf_counter()
-    print(f"pass {rep} ({'one scene launch' if batched else 'chain by chain'}): construction {1e3*(t1-t0):.1f} ms, trace of 10 chains "
+    print(f"pass {rep} ({'one scene launch' + (', lazy history' if kw else '') if batched else 'chain by chain'}): construction {1e3*(t1-t0):.1f} ms, trace of 10 chains "
           f"{1e3*(t2-t1):.1f} ms, analysis {1e3*(t3-t2):.1f} ms ({1e2*(t3-t2):.2f} ms per chain)", flush=True)
     del chains, res
