@@ -563,6 +563,14 @@ def worker(args):
     # replaces 10-11 small read-out launches), relay4 0.77 vs 0.80 ms, C4 1.56-1.58 vs 1.64-1.66 ms (behind eight
     # elements the tail used to cost more than the saved re-read; since its instruction count went down it wins there too).
     fuse = mode == "chain" and args.readout in ("fused", "auto")
+    # Python's cyclic collector: a full (generation-2) pass walks the ~1e6 objects that importing torch/numpy leaves
+    # behind and stops the host for ~40 ms -- once per run, at an arbitrary step; in a 20-step timed region of 0.8-ms
+    # steps that is the difference between 1.6 and 2.1 ms per step (tools/host_timing.py).  Everything alive now is
+    # moved to the permanent generation; the steps themselves create no reference cycles.  Done HERE, before the step's
+    # programs are built, so that the device is not left idle for those ~50 ms right in front of the warm-up steps.
+    import gc
+    gc.collect()
+    gc.freeze()
     program = None
     if batched or use_graph:
         program = SceneProgram([src] * n_chains, element_lists, IgnoreDefects=ignore_defects,
@@ -621,14 +629,6 @@ def worker(args):
                 state["gather_bytes"] = gather.start(state["step"] % 2, r[-1]["X"], r[-1]["Y"], r[-1]["opl"], o[-1][-1].alive)
                 state["step"] += 1
         return o, r
-
-    # Python's cyclic collector: a full (generation-2) pass walks the ~1e6 objects that importing torch/numpy leaves
-    # behind and stops the host for ~40 ms -- once per run, at an arbitrary step; in a 20-step timed region of 0.8-ms
-    # steps that is the difference between 1.6 and 2.1 ms per step (tools/host_timing.py).  Everything alive now is
-    # moved to the permanent generation; the steps themselves create no reference cycles.
-    import gc
-    gc.collect()
-    gc.freeze()
 
     def timed(full_gather, steps):
         for _ in range(args.warmup):
