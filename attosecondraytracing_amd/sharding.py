@@ -270,7 +270,8 @@ class SurvivorGather:
         # (first, step, n) of every rank's shard: for the implicit numbers of dense shards on the root
         self.specs = specs if specs is not None else [(0, 1, self.n)] * self.world
         dev = backend.device
-        self.cap = backend.survivor_bytes(max(s[2] for s in self.specs) if specs is not None else self.n, False)
+        # capacity of every buffer: the longest shard with every slot alive and explicit numbers (28 B per ray)
+        self.cap = backend.survivor_bytes(max([self.n] + [s[2] for s in self.specs]), False)
         self.send = [torch.empty(self.cap, dtype=torch.uint8, device=dev) for _ in range(buffers)]
         self.recv = [[torch.empty(self.cap, dtype=torch.uint8, device=dev) for _ in range(self.world)]
                      if self.rank == self.dst else None for _ in range(buffers)]
