@@ -6,9 +6,10 @@
 Default workload ("relay4", the headline BASELINE.json's metric is quoted on): a point source (half-angle 20 mrad) of
 1e7 rays per GPU through 4 toroidal mirrors (two f-x-f relays with the C3 scene's toroid: f = 600 mm, 80 deg, 200 x 30 mm),
 then the detector read-out: 4e7 ray-surface intersections per GPU and step, every ray surviving, full per-element
-history written as the API returns it.  `--config` selects the other BASELINE.json configurations (same JSON contract):
+history written as the API returns it; the step is replayed from a HIP graph (graph.SceneProgram; `--graph off`: eager
+launches).  `--config` selects the other BASELINE.json configurations (same JSON contract):
   C2  CONFIG_2toroidals_f-x-f: 11 chains (loop list over the toroid distance) x 1e6 rays x (mask + 2 toroids), traced by
-      ONE launch from a device-resident scene table, + 11 read-outs; the whole step replayed from a HIP graph
+      ONE launch from a device-resident scene table, + 11 read-outs
   C3  CONFIG_2toroidals_twisted: 10 chains (incidence-plane twist) x 1e7 rays x (mask + 2 toroids) + read-outs, one launch
   C4  8-element mixed chain (OAP, plane, 2 toroids, 2 planes, OAP, plane), 1.25e7 rays per GPU (1e8 over 8 GPUs)
   C5  CONFIG_deformed geometry with a 6th-order Zernike defect, IgnoreDefects=False (perturbed normals), 1e7 rays
@@ -23,6 +24,11 @@ A step = one pass of the hot path over resident bundles:
             SURVIVING ray's read-out (number:int32, X, Y, optical path: 28 B per survivor, SURVEY.md 8e -- the gather
             BASELINE.json's north_star names; 24 B where a shard lost nothing and its numbers are implicit) to rank 0 in
             every step, double-buffered behind the next step's tracing -- this is `value_full_gather`.
+Beside `value` (every per-element bundle written) the line carries `value_lazy_history`: the same step with only the
+analysed bundle written, the product's lazy-history mode (what ARTmain uses) -- never the headline.  `roofline.frac` is
+counted HBM bytes (committed rocprofv3 PMC profile of THIS build, matched by source hash) over the launch's duration, or
+the compulsory bytes computed in the run when no such profile exists (`frac_basis`); `box` holds the clocks / power /
+partition mode of the device before the run and under load.
 Inputs are resident in HBM before the timed region; nothing is copied to the host inside a step.  N > 1 is weak scaling:
 every rank traces its own shard (index range of an N x rays source), no collective on the tracing path.
 
