@@ -680,26 +680,11 @@ def worker(args):
             assert S.shape == (world, sample_k, 4)
             own = torch.stack([r[-1]["X"], r[-1]["Y"], r[-1]["opl"]]).index_select(1, exchange.slots).T
             assert torch.equal(S[0][:, 0:3].contiguous().view(torch.int64), own.contiguous().view(torch.int64))   # own part of the sample
-    # The contract's region above starts W steps after an idle device.  An MI355X needs ~40 ms of load to reach its
-    # sustained clocks: 20 timed steps after 5 warm-up steps run at 0.80 ms, after 50 at 0.72, after 200 at 0.69
-    # (tools/r02_exp11.sh).  `value` stays what the contract defines; the SAME K steps timed again once the device has
-    # been busy for SETTLE_SECONDS are reported beside it as `value_sustained`.
-    dt_sus = None
-    if on_gpu:
-        # a step COUNT, derived from the rank-reduced dt: identical on every rank (the steps carry a collective)
-        for _ in range(max(1, int(np.ceil(SETTLE_SECONDS / (dt / args.steps))))):
-            step(False)
-        exchange_drain()
-        sync()
-        saved_w, args.warmup = args.warmup, 0
-        dt_sus, _, o, r = timed(False, args.steps)
-        args.warmup = saved_w
-    stats_host = (state["stats"] if use_dist else r[-1]["stats_dev"]).cpu().numpy()
-    assert stats_host[0] == surv_last_job and np.isfinite(stats_host[1]), (stats_host[0], surv_last_job)
-
     # ------------------------------------------------------------------ kernel durations (HIP events on the launch stream)
-    # Right after the timed region, on the same resident data: EVENT_STEPS more passes of trace + read-out with every
-    # launch bracketed by HIP events recorded on the launch stream.  They are NOT inside the timed region because every
+    # Right after the timed region(s), on the same resident data and in the same clock state (before the sustained-load
+    # region below: on some boxes 0.25 s of continuous load already ends in power throttling -- one run measured 1.00 ms per
+    # step there after 0.73 in the timed region): EVENT_STEPS more passes of trace + read-out with every launch bracketed
+    # by HIP events recorded on the launch stream.  They are NOT inside the timed region because every
     # timing event is a barrier packet that keeps the next kernel from overlapping the previous one's tail: bracketing
     # the timed steps themselves costs 0.09 ms per 0.75-ms step (measured).
     kernel_ms = readout_ms = None
@@ -718,6 +703,23 @@ def worker(args):
         kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in tr_ev]))       # average duration of one trace launch
         if ro_ev:
             readout_ms = float(np.mean([a.elapsed_time(b) for a, b in ro_ev]))  # one read-out (kernel + 24-slot fold)
+
+    # The contract's region above starts W steps after an idle device.  An MI355X needs ~40 ms of load to reach its
+    # sustained clocks: 20 timed steps after 5 warm-up steps run at 0.80 ms, after 50 at 0.72, after 200 at 0.69
+    # (round-2 batch 11; tools/ramp_probe.py).  `value` stays what the contract defines; the SAME K steps timed again once the device has
+    # been busy for SETTLE_SECONDS are reported beside it as `value_sustained`.
+    dt_sus = None
+    if on_gpu:
+        # a step COUNT, derived from the rank-reduced dt: identical on every rank (the steps carry a collective)
+        for _ in range(max(1, int(np.ceil(SETTLE_SECONDS / (dt / args.steps))))):
+            step(False)
+        exchange_drain()
+        sync()
+        saved_w, args.warmup = args.warmup, 0
+        dt_sus, _, o, r = timed(False, args.steps)
+        args.warmup = saved_w
+    stats_host = (state["stats"] if use_dist else r[-1]["stats_dev"]).cpu().numpy()
+    assert stats_host[0] == surv_last_job and np.isfinite(stats_host[1]), (stats_host[0], surv_last_job)
 
     # (Everything below runs AFTER the timed regions and the event-bracketed passes: the load loop of the box-state query
     # keeps the device at its 1400-W power cap for about a second, after which the clocks are throttled -- kernel times
