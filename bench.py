@@ -708,7 +708,7 @@ def worker(args):
     # sustained clocks: 20 timed steps after 5 warm-up steps run at 0.80 ms, after 50 at 0.72, after 200 at 0.69
     # (round-2 batch 11; tools/ramp_probe.py).  `value` stays what the contract defines; the SAME K steps timed again once the device has
     # been busy for SETTLE_SECONDS are reported beside it as `value_sustained`.
-    dt_sus = None
+    dt_sus = kernel_ms_sus = None
     if on_gpu:
         # a step COUNT, derived from the rank-reduced dt: identical on every rank (the steps carry a collective)
         for _ in range(max(1, int(np.ceil(SETTLE_SECONDS / (dt / args.steps))))):
@@ -718,6 +718,16 @@ def worker(args):
         saved_w, args.warmup = args.warmup, 0
         dt_sus, _, o, r = timed(False, args.steps)
         args.warmup = saved_w
+        # ... and the kernel's duration in THAT clock state (round 2 took `kernel_ms` here), reported beside the one above
+        be.trace_events = []
+        for _ in range(EVENT_STEPS):
+            if program is not None:
+                program._launch()
+            else:
+                trace_and_readout()
+        sync()
+        ev_sus, be.trace_events, be.readout_events = be.trace_events, None, None
+        kernel_ms_sus = float(np.mean([a.elapsed_time(b) for a, b in ev_sus]))
     stats_host = (state["stats"] if use_dist else r[-1]["stats_dev"]).cpu().numpy()
     assert stats_host[0] == surv_last_job and np.isfinite(stats_host[1]), (stats_host[0], surv_last_job)
 
@@ -852,6 +862,10 @@ def worker(args):
                 "algorithmic_bytes_per_read_out_ray": ALGO_BYTES_READOUT if fuse else None,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_ms": kernel_ms, "launches_per_step": launches, "intersections_per_launch": inter_per_launch,
+                "kernel_ms_note": f"mean of {EVENT_STEPS} event-bracketed launches (trace kernel + its 9-us fold) right after the "
+                                  "timed region(s), i.e. in their clock state; *_sustained: the same after the sustained-load region",
+                "kernel_ms_sustained": kernel_ms_sus,
+                "frac_sustained": None if kernel_ms_sus is None else (tr[0] if tr else comp) / (kernel_ms_sus * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "frac_of_achievable_6300": (counted if counted is not None else compulsory) / 6300.0,
                 "source_hash": __import__("tools.source_hash", fromlist=["source_hash"]).source_hash(),
             }
