@@ -379,7 +379,7 @@ def RayTracingCalculationMany(source_rays_list, optical_elements_list, IgnoreDef
     host, dev = be.scene_alloc(c, m, transient=True)
     be.scene_pack(descs, [s.view() for s in sources], views, c, m, host, ros)
     be.scene_upload(host, dev)
-    be.trace_scene(dev, host, n)
+    be.trace_scene(dev, host, n, segments=-(-m // 8))
     for ci, outs in enumerate(grid):
         outs[-1]._keepalive = (keep, scratch)
         if ros is not None:

@@ -47,6 +47,9 @@ class HipBackend:
         self.device = torch.device("cuda", torch.cuda.current_device())
         self._scratch = {}
         self._scene_pool, self._scene_uploads = {}, {}
+        # bookkeeping for measurements: launches of the fused kernels over at least `count_from` slots, in issue order
+        # (bench.py reports which of them lie inside its timed region, so that a kernel trace can be cut to it)
+        self.count_from, self.counted_launches = None, 0
         self.trace_events = None   # set to a list to collect (start, end) HIP events around each trace launch
         self.readout_events = None  # likewise around each fused read-out (kernel + final fold)
 
@@ -104,6 +107,8 @@ class HipBackend:
     def trace_chain(self, descs, view_in, views_out, n, readout=None):
         """art_trace_chain, or art_trace_chain_readout when `readout` (from new_chain_readout) is given."""
         m = len(descs)
+        if m > 1 or readout is not None:       # (a one-element chain without read-out is the per-element kernel's)
+            self.note_launches(n, -(-m // 8))
         darr = (_abi.ArtElementDesc * m)(*descs)
         varr = (_abi.ArtBundleView * m)(*views_out)
         sp = self.stream_ptr()
@@ -183,9 +188,14 @@ class HipBackend:
         self._scene_uploads[host_image.data_ptr()] = ev
         return ev
 
-    def trace_scene(self, dev_image, host_image, n):
+    def note_launches(self, n, k=1):
+        if self.count_from is not None and n >= self.count_from:
+            self.counted_launches += k
+
+    def trace_scene(self, dev_image, host_image, n, segments=1):
         """ONE launch (per 8 elements) for every chain of a packed scene; counts and flags come from the host image's
         header (art_scene_pack), of which dev_image is the uploaded copy."""
+        self.note_launches(n, segments)
         sp = self.stream_ptr()
         self.check(self._timed(lambda: self.fn["art_trace_scene"](dev_image.data_ptr(), host_image.data_ptr(), n, sp)),
                    "art_trace_scene")

@@ -181,7 +181,7 @@ class SceneProgram:
                 self._mp._attach_readout(outs[-1], self.detectors[ci], 0.0, self.readouts[ci])
 
     def _launch(self):
-        self.be.trace_scene(self.dev, self.host, self.n)
+        self.be.trace_scene(self.dev, self.host, self.n, segments=-(-self.m // 8))
         self._mark()
         if self.post is not None:
             self.post_result = self.post(self.outputs)
@@ -189,6 +189,8 @@ class SceneProgram:
     def run(self):
         if self.graph is not None:
             self.graph.replay()
+            if hasattr(self.be, "note_launches"):
+                self.be.note_launches(self.n, -(-self.m // 8))      # the captured launches, for measurement bookkeeping
             self._mark()
         else:
             self._launch()

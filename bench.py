@@ -519,6 +519,8 @@ def worker(args):
     assert n_shard == n
     wl = 800e-6 if cfg == "C5" else 50e-6
     # one resident source shard shared by all chains (OEPlacement gives every chain of a loop list the same source)
+    if on_gpu:
+        be.count_from = n // 2          # count the full-size launches of the fused kernels from here on (see timed())
     src = device_source(n, first, n_total, be, src_kind, wl, step=stride)
     batched = n_chains > 1
     # The whole step (trace + read-outs) is replayed from a HIP graph (graph.SceneProgram, the product's compiled-scene
@@ -644,10 +646,12 @@ def worker(args):
             gather.drain()
         barrier()
         sync()
+        li0 = getattr(be, "counted_launches", 0)
         t0 = time.perf_counter()
         for k in range(steps):
             o, r = step(full_gather)
         t_enq = time.perf_counter() - t0     # host time to enqueue all steps (diagnostic: host-bound if ~ dt)
+        state.setdefault("timed_launches", (li0, getattr(be, "counted_launches", 0)))    # of the FIRST timed region
         exchange_drain()                     # the last step's statistics are folded ...
         if gather:
             gather.drain()                   # ... and every gather has landed on rank 0 before the clock stops
@@ -864,6 +868,10 @@ def worker(args):
                 "kernel_ms": kernel_ms, "launches_per_step": launches, "intersections_per_launch": inter_per_launch,
                 "kernel_ms_note": f"mean of {EVENT_STEPS} event-bracketed launches (trace kernel + its 9-us fold) right after the "
                                   "timed region(s), i.e. in their clock state; *_sustained: the same after the sustained-load region",
+                "timed_region_launches": list(state.get("timed_launches", (0, 0))),
+                "timed_region_launches_note": "[first, last) of the full-size fused-kernel launches of this process, in issue "
+                                              "order, that lie inside the timed region: cuts a rocprofv3 kernel trace of the "
+                                              "same command to it (tools/summarize_profile.py)",
                 "kernel_ms_sustained": kernel_ms_sus,
                 "frac_sustained": None if kernel_ms_sus is None else (tr[0] if tr else comp) / (kernel_ms_sus * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "frac_of_achievable_6300": (counted if counted is not None else compulsory) / 6300.0,

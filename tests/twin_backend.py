@@ -146,7 +146,7 @@ class TwinBackend:
     def scene_upload(self, host_image, dev_image):
         return None
 
-    def trace_scene(self, dev_image, host_image, n):
+    def trace_scene(self, dev_image, host_image, n, segments=1):
         f = self.lib.art_cpu_trace_scene
         f.restype, f.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]
         assert f(dev_image.data_ptr(), host_image.data_ptr(), n) == 0

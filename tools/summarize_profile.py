@@ -97,20 +97,25 @@ def main():
         rg = regs.get(k, ("?", "?", big[0][4], "?"))
         out.append(f"| {k} | {len(d)} | {sum(d)/len(d)/1e3:.1f} | {min(d)/1e3:.1f} | {max(d)/1e3:.1f} | {g} | {rg[0]} | {rg[1]} | {rg[2]} | {rg[3]} |")
     out.append("")
-    # the timed steps of bench.py are the LAST `steps` launches of the trace kernel (the ones before are scene set-up
-    # and warm-up): their average is what bench.py's roofline.kernel_ms measures with HIP events
-    steps = 20
-    if "--steps" in extra.split():
-        steps = int(extra.split()[extra.split().index("--steps") + 1])
-    for k, v in byk.items():
-        if k.startswith(("k_trace_chain", "k_trace_element", "k_trace_scene")):
-            g = max(x[0] for x in v)
-            big = [x[1] for x in v if x[0] == g]
-            per_step = 1 if k.startswith(("k_trace_chain", "k_trace_scene")) else max(1, len(big) // (steps + 6))
-            last = big[-steps * per_step:]
-            if len(last) >= steps and sum(big) > 1e6:
-                out.append(f"`{k}`: average over the last {len(last)} launches (the timed steps) = {sum(last)/len(last)/1e3:.1f} us")
-    out.append("")
+    # the timed region: bench.py reports which of its full-size fused-kernel launches lie inside it
+    # (roofline.timed_region_launches, in issue order); cut the trace to them
+    try:
+        bl = json.loads(open(bj).read().strip().splitlines()[-1])
+        lo, hi = bl["roofline"]["timed_region_launches"]
+        fused = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["Grid_Size_X"]))
+                        for r in rows if short(r["Kernel_Name"]).startswith(("k_trace_chain", "k_trace_scene"))), key=lambda t: t[0])
+        gmax = max(t[2] for t in fused)
+        full = [t for t in fused if t[2] >= gmax // 2]     # full-size launches (the two-ray body's grid is half a one-ray grid)
+        cut = [t[1] for t in full[lo:hi]]
+        if cut and hi <= len(full):
+            out.append(f"timed region of this pass (launches {lo}..{hi - 1} of {len(full)} full-size fused launches, "
+                       f"`roofline.timed_region_launches`): average {sum(cut)/len(cut)/1e3:.1f} us, first {cut[0]/1e3:.1f}, "
+                       f"max {max(cut)/1e3:.1f}, last {cut[-1]/1e3:.1f} us -- the clock ramp of the driver's protocol (DESIGN.md 5); "
+                       f"bench.py's own `kernel_ms` of this pass: {bl['roofline']['kernel_ms']*1e3:.1f} us (events right after the "
+                       f"region), `kernel_ms_sustained` {bl['roofline'].get('kernel_ms_sustained', 0)*1e3:.1f} us; average of ALL "
+                       f"full-size launches of the pass: {sum(t[1] for t in full)/len(full)/1e3:.1f} us")
+    except Exception as e:     # noqa: BLE001 -- older bench lines carry no launch indices
+        out.append(f"(no timed-region cut: {e!r})")
     # ---- PMC passes
     def pmc(tag, counter):
         f = glob.glob(os.path.join(src, "pmc_" + tag, "*", "*_counter_collection.csv"))
