@@ -105,8 +105,11 @@ class SceneProgram:
                     self._launch()
             torch.cuda.current_stream().wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
+            counted = getattr(self.be, "counted_launches", 0)
             with torch.cuda.graph(self.graph):
                 self._launch()
+            if hasattr(self.be, "counted_launches"):
+                self.be.counted_launches = counted      # a captured launch has not run
 
     def set_detectors(self, detectors):
         """(Re)place the fused read-outs' detectors; takes effect with the next update().  Only for a program that was
