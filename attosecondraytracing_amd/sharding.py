@@ -251,6 +251,20 @@ class ReadoutGather:
         return torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts])
 
 
+def decode_survivors(buf, count, flags, spec):
+    """One rank's survivor records (the byte layout of art_pack_survivors, include/art_hip.h) -> (number int64 [c], X, Y,
+    path) as views of `buf` (uint8); the numbers of a dense shard (flags bit 0) are generated from its `spec` = (first,
+    step, n)."""
+    c = int(count)
+    f64 = buf[16:16 + 24 * c].view(torch.float64).view(3, c)
+    if flags & 1:
+        first, step, _ = spec
+        num = first + step * torch.arange(c, dtype=torch.int64, device=buf.device)
+    else:
+        num = buf[16 + 24 * c:16 + 28 * c].view(torch.int32).to(torch.int64)
+    return num, f64[0], f64[1], f64[2]
+
+
 class SurvivorGather:
     """The gather of SURVEY.md 8(e) as written: `(number:int32, X, Y, path)` = 28 B per SURVIVING ray from every shard to
     rank `dst` in ONE collective (the consumer, ART/ModuleDetector.py:254-279, sees survivors only; ReadoutGather above
@@ -312,17 +326,7 @@ class SurvivorGather:
         shard are generated).  None elsewhere."""
         if self.recv[b] is None:
             return None
-        out = []
-        for r, buf in enumerate(self.recv[b]):
-            c, flags = self.headers[b][r]
-            f64 = buf[16:16 + 24 * c].view(torch.float64).view(3, c)
-            if flags & 1:
-                first, step, _ = self.specs[r]
-                num = first + step * torch.arange(c, dtype=torch.int64, device=buf.device)
-            else:
-                num = buf[16 + 24 * c:16 + 28 * c].view(torch.int32).to(torch.int64)
-            out.append((num, f64[0], f64[1], f64[2]))
-        return out
+        return [decode_survivors(buf, *self.headers[b][r], self.specs[r]) for r, buf in enumerate(self.recv[b])]
 
     def assemble(self, b):
         """On dst: (number, X, Y, path) of all survivors of the job in global ray order (rank order for contiguous

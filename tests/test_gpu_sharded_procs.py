@@ -42,7 +42,12 @@ def _trace_shard(rank, world, n_total):
     out = mp.RayTracingCalculation(src, chain.optical_elements)
     det = mdet.Detector(np.zeros(3), np.array([1900.0, 30.0, 0.0]), np.array([-0.9, -0.1, 0.2]))
     r = det.readout(out[-1], sync=False)
-    return (torch.stack([r["X"], r["Y"], r["opl"]]).cpu(), out[-1].alive.cpu(), r["stats_dev"].cpu())
+    # the survivor records of this shard, packed by the HIP kernels (art_pack_survivors); they travel over gloo below
+    send = torch.empty(be.survivor_bytes(hi - lo), dtype=torch.uint8, device=be.device)
+    be.pack_survivors(out[-1].alive, r["X"], r["Y"], r["opl"], None, lo, 1, send)
+    hdr = send[:16].view(torch.int64).cpu()
+    used = be.survivor_bytes(int(hdr[0]), bool(int(hdr[1]) & 1))
+    return (torch.stack([r["X"], r["Y"], r["opl"]]).cpu(), out[-1].alive.cpu(), r["stats_dev"].cpu(), hdr, send[:used].cpu())
 
 
 def _worker(rank, world, port, n_total, q):
@@ -51,11 +56,22 @@ def _worker(rank, world, port, n_total, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from attosecondraytracing_amd import sharding
-        XYO, alive, stats = _trace_shard(rank, world, n_total)
+        XYO, alive, stats, hdr, rec = _trace_shard(rank, world, n_total)
         g = sharding.allreduce_stats(stats, torch.device("cpu"))
         full, al = sharding.gather_readout(XYO[0], XYO[1], XYO[2], alive, 0)
+        # the survivor-only gather with the device-packed records: header all-gather, ONE gather of max bytes
+        hdrs = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(hdrs, hdr)
+        nb = max((16 + (24 if int(h[1]) & 1 else 28) * int(h[0]) + 15) // 16 * 16 for h in hdrs)
+        pad = torch.zeros(nb, dtype=torch.uint8)
+        pad[:rec.numel()] = rec
+        recv = [torch.zeros(nb, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
+        dist.gather(pad, recv, dst=0)
         if rank == 0:
-            q.put((g.numpy(), full.numpy(), al.numpy()))
+            specs = [sharding.shard_spec(n_total, k, world) for k in range(world)]
+            parts = [sharding.decode_survivors(recv[k], int(hdrs[k][0]), int(hdrs[k][1]), specs[k]) for k in range(world)]
+            surv = [torch.cat([p[j] for p in parts]).numpy() for j in range(4)]
+            q.put((g.numpy(), full.numpy(), al.numpy(), surv, [int(h[1]) for h in hdrs]))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -63,14 +79,14 @@ def _worker(rank, world, port, n_total, q):
 
 def test_two_processes_one_gpu_match_single_process():
     n_total = 200_003
-    ref_xyo, ref_alive, ref_stats = _trace_shard(0, 1, n_total)
+    ref_xyo, ref_alive, ref_stats, _, _ = _trace_shard(0, 1, n_total)
     ctx = tmp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(rk, 2, port, n_total, q)) for rk in range(2)]
     for p in procs:
         p.start()
-    stats, XYO, alive = q.get(timeout=300)
+    stats, XYO, alive, surv, dense = q.get(timeout=300)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -78,6 +94,10 @@ def test_two_processes_one_gpu_match_single_process():
     m = alive.astype(bool)
     assert 0 < m.sum() < n_total
     assert np.array_equal(XYO[:, m], ref_xyo.numpy()[:, m])
+    # the survivor records, packed on the device by each rank: the single-process read-out of the survivors, numbers included;
+    # rank 0's inner shard passes the mask entirely (dense: no number section), rank 1's does not
+    assert np.array_equal(surv[0], np.nonzero(m)[0]) and np.array_equal(np.stack(surv[1:]), ref_xyo.numpy()[:, m])
+    assert dense == [1, 0], dense
     rs = ref_stats.numpy()
     assert stats[0] == rs[0]
     for k in (2, 3, 4, 5, 12, 13):
