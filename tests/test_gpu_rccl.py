@@ -114,3 +114,34 @@ def test_gpu_survivor_records_refuse_numbers_beyond_int32(hip):
         hip.pack_survivors(alive, z, z, z, None, 2 ** 31 - 5, 1, send)
     with pytest.raises(_lib.ArtError, match="smaller"):
         hip.pack_survivors(alive, z, z, z, None, 0, 1, send[:64])
+
+
+def test_bench_line_contract_single_gpu():
+    """The driver's call (`python bench.py --gpus 1 --steps K --warmup W`), small: ONE JSON line with every field of the
+    contract -- metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline /
+    dtype / data / config.workload, `roofline` (counted or compulsory bytes, stated), `cpu_baseline` (the oracle, one
+    thread, bounded sample), `parity` within 1e-10, the lazy-history rate beside the headline, the box state."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                            "ART_FORCE_DIST")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--rays",
+                        "400000", "--cpu-sample", "20000"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["metric"] == "ray-surface intersections/s" and j["unit"] == "intersections/s" and j["value"] > 1e9
+    assert (j["n_gpus"], j["steps"], j["warmup"]) == (1, 5, 2) and j["higher_is_better"] is True and j["scaling"] == "weak"
+    assert j["vs_baseline"] is None and j["dtype"] == "f64" and j["data"] == "synthetic"
+    assert abs(j["value"] - 400000 * 4 / (j["ms_per_step"] * 1e-3)) <= 1e-6 * j["value"]
+    assert "relay4" in j["config"]["workload"] and j["config"]["hip_graph"] is True
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and r["frac_basis"] in ("counted", "compulsory")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.05 < r["frac_compulsory"] < 1.0
+    assert r["compulsory_bytes"] == 400000 * (65 + 4 * 65 + 24) + 176 * ((400000 + 255) // 256)     # every ray survives the relay
+    assert r["kernel"].startswith("k_trace_scene<false") and r["kernel_ms"] > 0 and len(r["timed_region_launches"]) == 2
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 1e4 and "oracle" in c["sample"]
+    par = j["parity"]
+    assert par["survivor_indices_equal"] and max(par["delay_max_rel_err"], par["position_max_rel_err"], par["path_max_rel_err"]) <= 1e-10
+    assert j["value_lazy_history"] > j["value"] * 0.9 and j["value_full_gather"] is None
+    assert j["box"] is None or "idle_before_run" in j["box"]
