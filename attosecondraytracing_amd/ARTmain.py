@@ -99,7 +99,7 @@ def optimize_detector(RayListAnalysed, Detector, DetectorOptions, verbose=True, 
 
 
 def make_plots(OpticalChain, RayListAnalysed, Detector, SourceProperties, DetectorOptions, AnalysisOptions):
-    """ARTmain.py:193-244: the plots selected in AnalysisOptions (the PyVista scene render reports that it is not built)."""
+    """ARTmain.py:193-244: the plots selected in AnalysisOptions."""
     A = AnalysisOptions
     if A["plot_Render"]:
         mplots.RayRenderGraph(OpticalChain)

@@ -2,22 +2,12 @@
 
 `getETransmission` and `GetResultSummary` (the two functions ARTmain needs for its numbers) are built on the
 device reductions.  SpotDiagram, DelayGraph and MirrorProjection are matplotlib adaptors fed from the device
-(_plots.py: statistics over all rays, markers for a down-sampled subset).  RayRenderGraph (PyVista 3-D scene) is not
-built: the entry point exists so that ARTmain and CONFIG scripts run, and says so."""
+(_plots.py: statistics over all rays, markers for a down-sampled subset); RayRenderGraph, a PyVista scene in the
+reference, is drawn on matplotlib's 3-D axes from the same geometry (the image has no PyVista)."""
 
 from . import ModuleGeometry as mgeo
 from . import ModuleProcessing as mp
 from .bundle import RayBundle
-
-_warned = set()
-
-
-def _not_built(name):
-    if name not in _warned:
-        _warned.add(name)
-        print(f"[ART-MI355X] plot '{name}' is not part of this build (visualisation is out of scope); skipped.")
-    return None
-
 
 def _sum_intensity(rays):
     if isinstance(rays, RayBundle):
@@ -84,8 +74,16 @@ def MirrorProjection(OpticalChain, ReflectionNumber: int, Detector=None, ColorCo
     return _plots.MirrorProjection(OpticalChain, ReflectionNumber, Detector, ColorCoded)
 
 
-def RayRenderGraph(*a, **k):
-    return _not_built("RayRenderGraph")
+def RayRenderGraph(OpticalChain, EndDistance=None, maxRays=300, OEpoints=3000, scale_spheres=5.0, draw_mesh=False,
+                   cycle_ray_colors=False):
+    """3-D picture of the optical setup and the traced rays (ART/ModuleAnalysisAndPlots.py:616-673)."""
+    from . import _plots
+    return _plots.RayRenderGraph(OpticalChain, EndDistance, maxRays, OEpoints, scale_spheres, draw_mesh, cycle_ray_colors)
+
+
+def generate_distinct_colors(num_colors):
+    from . import _plots
+    return _plots.generate_distinct_colors(num_colors)
 
 
 def show():

@@ -22,6 +22,11 @@ class Mask:
     def get_centre(self):
         return np.array([0, 0, 0])
 
+    def get_grid3D(self, NbPoint, **kwargs):
+        """Sample points of the mask's plane inside its support, for the 3-D render (ART/ModuleMask.py:72-91)."""
+        from .ModuleMirror import _surface_cloud
+        return _surface_cloud(self, lambda x, y: np.zeros_like(x), True, NbPoint, bool(kwargs.get("edges")))
+
     def __hash__(self):
         return hash(("Mask", hash(self.support)))
 

@@ -3,7 +3,8 @@
 The classes are parameter holders for the HIP kernels: each exposes `_abi_kind` / `_abi_params()` (layout in
 include/art_hip.h) plus the reference's host-side helpers `get_centre()` and `get_normal(Point)` for a single
 point.  Ray/surface intersection, aperture test and reflection of a *bundle* never run in Python; see
-ModuleProcessing.RayTracingCalculation -> libart_hip.so.  Rendering meshes (`get_grid3D`) are out of scope."""
+ModuleProcessing.RayTracingCalculation -> libart_hip.so.  `get_grid3D` samples the surface for the 3-D render
+(host, a few thousand points)."""
 import math
 
 import numpy as np
@@ -49,6 +50,53 @@ class _Mirror:
     def __hash__(self):
         return hash((self.type, hash(self.support)) + tuple(float(v) for v in self._abi_params()))
 
+    _cloud_has_outline = True      # the point cloud of get_grid3D starts with the outline of the support
+
+    def _sag(self, x, y):
+        """Surface height z(x, y) in the mirror's own frame (arrays; NaN where the surface does not exist)."""
+        return np.zeros_like(x)
+
+    def get_grid3D(self, NbPoint: int, **kwargs):
+        """About NbPoint points of the surface inside its support, in the mirror's own frame: a tenth of them on the
+        outline of the support (and of its hole), the rest on the support's grid (the `get_grid3D` of every optic
+        class of ART/ModuleMirror.py, e.g. :93-113).  With edges=True also the closed index loops of the hole outlines.
+        Points where the surface does not exist under the support are left out."""
+        return _surface_cloud(self, self._sag, self._cloud_has_outline, NbPoint, bool(kwargs.get("edges")))
+
+
+def _surface_cloud(optic, sag, with_outline, NbPoint, want_edges):
+    n_outline = int(round(0.1 * NbPoint))
+    outline, loops = optic.support._Contour_points(n_outline, edges=True)
+    outline = np.asarray(outline, dtype=float).reshape(-1, 2)
+    grid = optic.support._grid_xy(NbPoint - n_outline)
+    centre = optic.get_centre()
+
+    def lift(xy):
+        x, y = xy[:, 0] + centre[0], xy[:, 1] + centre[1]
+        with np.errstate(invalid="ignore"):
+            z = sag(x, y)
+        return np.column_stack((x, y, z)), np.isfinite(z)
+
+    if with_outline:
+        P, ok = lift(np.concatenate((outline, grid)))
+        new_index = np.cumsum(ok) - 1
+        loops = [[int(new_index[i]) for i in loop if ok[i]] for loop in loops]
+        P = P[ok]
+    else:
+        # the ellipsoid's cloud (ART/ModuleMirror.py:716-751): grid points first, then only the outline points an edge
+        # loop refers to (the hole), in loop order -- the loop's closing index is a point of its own
+        G, okg = lift(grid)
+        O, oko = lift(outline)
+        parts, first, new_loops = [G[okg]], int(okg.sum()), []
+        for loop in loops:
+            keep = [i for i in loop if oko[i]]
+            parts.append(O[keep])
+            new_loops.append(list(range(first, first + len(keep))))
+            first += len(keep)
+        P, loops = np.concatenate(parts), new_loops
+    cloud = list(P)
+    return (cloud, loops) if want_edges else cloud
+
 
 class MirrorPlane(_Mirror):
     """Plane mirror in the xy-plane of its own frame (ART/ModuleMirror.py:42-113)."""
@@ -89,6 +137,9 @@ class MirrorSpherical(_Mirror):
 
     def get_centre(self):
         return np.array([0, 0, -self.radius])
+
+    def _sag(self, x, y):
+        return -np.sqrt(self.radius ** 2 - (x * x + y * y))
 
 
 class MirrorParabolic(_Mirror):
@@ -140,6 +191,9 @@ class MirrorParabolic(_Mirror):
         return np.array([self.feff * np.sin(self.offaxisangle), 0,
                          self._p * 0.5 - self.feff * np.cos(self.offaxisangle)])
 
+    def _sag(self, x, y):
+        return (x * x + y * y) / (2 * self._p)
+
 
 class MirrorToroidal(_Mirror):
     """Torus (sqrt(x^2+z^2) - R)^2 + y^2 = r^2 (ART/ModuleMirror.py:391-527)."""
@@ -162,6 +216,9 @@ class MirrorToroidal(_Mirror):
 
     def get_centre(self):
         return np.array([0, 0, -self.majorradius - self.minorradius])
+
+    def _sag(self, x, y):
+        return -np.sqrt((np.sqrt(self.minorradius ** 2 - y * y) + self.majorradius) ** 2 - x * x)
 
 
 def ReturnOptimalToroidalRadii(Focal: float, AngleIncidence: float):
@@ -226,6 +283,11 @@ class MirrorEllipsoidal(_Mirror):
             return np.array([0, 0, -self.b])
         return np.array([self.a * np.sqrt(1 - z ** 2 / self.b ** 2), 0, sign * z])
 
+    _cloud_has_outline = False
+
+    def _sag(self, x, y):
+        return -self.b * np.sqrt(1 - (x / self.a) ** 2 - (y / self.b) ** 2)
+
 
 def ReturnOptimalEllipsoidalAxes(Focal: float, AngleIncidence: float):
     """ART/ModuleMirror.py:755-777."""
@@ -253,6 +315,9 @@ class MirrorCylindrical(_Mirror):
 
     def get_centre(self):
         return np.array([0, 0, -self.radius])
+
+    def _sag(self, x, y):
+        return -np.sqrt(self.radius ** 2 - y * y) + 0.0 * x
 
 
 class DeformedMirror(_Mirror):
@@ -319,6 +384,10 @@ class DeformedMirror(_Mirror):
 
     def get_centre(self):
         return self.Mirror.get_centre()
+
+    def get_grid3D(self, NbPoint, **kwargs):
+        """The undeformed surface: the render does not show the defects (ART/ModuleMirror.py:966-967)."""
+        return self.Mirror.get_grid3D(NbPoint, **kwargs)
 
     def __hash__(self):
         return hash((hash(self.Mirror),) + tuple(hash(d) for d in self.DeformationList))

@@ -1,9 +1,9 @@
 """Aperture shapes of optics ("supports"), API of ART/ModuleSupport.py.
 
-Only what the tracing path needs is built: the five `_IncludeSupport` predicates (which the HIP kernels
-evaluate per ray from `_abi_kind` / `_abi_params`), the circumscribed rectangle/circle used by defects and
-source sizing.  Plot meshes and contours of the reference (`_get_grid`, `_ContourSupport`, ...) are out of
-scope (rendering)."""
+The five `_IncludeSupport` predicates (which the HIP kernels evaluate per ray from `_abi_kind` / `_abi_params`), the
+circumscribed rectangle/circle used by defects and source sizing, and the sample points the plots draw an aperture
+with: `_ContourSupport` (MirrorProjection), `_get_grid` / `_Contour_points` (RayRenderGraph)."""
+import math
 from abc import ABC, abstractmethod
 
 import numpy as np
@@ -43,6 +43,96 @@ class Support(ABC):
             axe.add_patch(patches.Rectangle((-self.holeX * 0.5 + self.centerholeX, -self.holeY * 0.5 + self.centerholeY),
                                             self.holeX, self.holeY, color="white", alpha=1))
         return axe
+
+    # ---- sample points for the 3-D render (the `_get_grid` / `_Contour_points` of every support class of
+    # ART/ModuleSupport.py; point counts and order as there, tests/golden/render_grids.npz) ----
+    def _lattice_counts(self, NbPoint):
+        """Columns and rows of the lattice on a rectangular support (ART/ModuleSupport.py:232-249)."""
+        ratio, skew = self.dimX / self.dimY, (self.dimX - self.dimY) / self.dimY
+        nbx = int(math.sqrt(ratio * NbPoint + 0.25 * skew ** 2) - 0.5 * skew)
+        return nbx, int(NbPoint / nbx)
+
+    def _grid_xy(self, NbPoint):
+        """(m, 2) array: Vogel spiral on a round support, lattice (x-major) on a rectangular one, without the points
+        that fall into the hole."""
+        if hasattr(self, "radius"):
+            xy = mgeo.SpiralVogel(NbPoint, self.radius)
+        else:
+            nbx, nby = self._lattice_counts(NbPoint)
+            gx, gy = np.meshgrid(np.linspace(-self.dimX / 2, self.dimX / 2, nbx),
+                                 np.linspace(-self.dimY / 2, self.dimY / 2, nby), indexing="ij")
+            xy = np.column_stack((gx.ravel(), gy.ravel()))
+        if hasattr(self, "radiushole"):
+            keep = (xy[:, 0] - self.centerholeX) ** 2 + (xy[:, 1] - self.centerholeY) ** 2 > self.radiushole ** 2
+        elif hasattr(self, "holeX"):
+            keep = (np.abs(xy[:, 0] - self.centerholeX) > self.holeX / 2) | (np.abs(xy[:, 1] - self.centerholeY) > self.holeY / 2)
+        else:
+            return xy
+        return xy[keep]
+
+    def _get_grid(self, NbPoint: int, **kwargs):
+        return list(self._grid_xy(NbPoint))
+
+    def _contour_xy(self, NbPoint):
+        """Outline points: (outer, hole or None), the hole in the order its closed edge loop runs."""
+        round_outer = hasattr(self, "radius")
+        outer_len = 2 * math.pi * self.radius if round_outer else 2 * (self.dimX + self.dimY)
+        if hasattr(self, "radiushole"):
+            if round_outer:     # shares by radius (ART/ModuleSupport.py:184-197)
+                n_hole = NbPoint - int(round(NbPoint - NbPoint * self.radiushole / self.radius))
+            else:               # shares by length (:355-369)
+                hole_len = 2 * math.pi * self.radiushole
+                n_hole = int(round(hole_len / (outer_len + hole_len) * NbPoint))
+            hole = gen_circle_contour(self.radiushole, n_hole).reshape(-1, 2)
+        elif hasattr(self, "holeX"):
+            hole_len = 2 * (self.holeX + self.holeY)
+            n_hole = int(round(hole_len / (outer_len + hole_len) * NbPoint))
+            hole = gen_rectangle_contour(self.holeX, self.holeY, n_hole)[::-1]
+        else:
+            n_hole, hole = 0, None
+        outer = (gen_circle_contour(self.radius, NbPoint - n_hole) if round_outer
+                 else gen_rectangle_contour(self.dimX, self.dimY, NbPoint - n_hole))
+        if hole is not None:
+            hole = hole + np.array([self.centerholeX, self.centerholeY])
+        return outer.reshape(-1, 2), hole
+
+    def _Contour_points(self, NbPoint=100, edges=False):
+        outer, hole = self._contour_xy(NbPoint)
+        return flatten_point_arrays(outer, [] if hole is None else [hole], edges=edges)
+
+
+def gen_circle_contour(radius, NbPoints):
+    """NbPoints points on a circle, counter-clockwise from angle 0 (ART/ModuleSupport.py:566-574)."""
+    if NbPoints == 0:
+        return np.array([])
+    phi = 2 * math.pi / NbPoints * np.arange(NbPoints)
+    return np.column_stack((radius * np.cos(phi), radius * np.sin(phi)))
+
+
+def gen_rectangle_contour(dimX, dimY, NbPoints):
+    """Outline of a rectangle, clockwise from its top-left corner; NbPoints is shared between ONE horizontal and ONE
+    vertical side, so about 2 NbPoints - 4 points come back (ART/ModuleSupport.py:546-563)."""
+    nX = max(math.ceil(dimX / (dimX + dimY) * NbPoints), 2)
+    nY = max(NbPoints - nX, 2)            # (the reference divides by zero when a side gets fewer than two points)
+    dX, dY = dimX / (nX - 1), dimY / (nY - 1)
+    i, j = np.arange(nX), np.arange(nY)
+    top = np.column_stack((i * dX - dimX / 2, np.full(nX, dimY / 2)))
+    right = np.column_stack((np.full(nY - 1, dimX / 2), dimY / 2 - j[1:] * dY))
+    bottom = np.column_stack((dimX / 2 - i[1:] * dX, np.full(nX - 1, -dimY / 2)))
+    left = np.column_stack((np.full(max(nY - 2, 0), -dimX / 2), -dimY / 2 + j[1:nY - 1] * dY))
+    return np.concatenate((top, right, bottom, left))
+
+
+def flatten_point_arrays(outer, holes=(), edges=False):
+    """Outer outline followed by the hole outlines as ONE list of points; with `edges`, also the closed index loop of
+    every hole (ART/ModuleSupport.py:577-596)."""
+    coords = list(outer)
+    loops = []
+    for arr in holes:
+        first = len(coords)
+        coords.extend(arr)
+        loops.append(list(range(first, first + len(arr))) + [first])
+    return (coords, loops) if edges else coords
 
 
 class SupportRound(Support):
@@ -128,6 +218,10 @@ class SupportRectangleHole(Support):
 
     def _abi_params(self):
         return [self.dimX, self.dimY, self.radiushole, self.centerholeX, self.centerholeY]
+
+    def _lattice_counts(self, NbPoint):
+        """This class counts its lattice differently from the other rectangles (ART/ModuleSupport.py:328-335)."""
+        return int(self.dimX / self.dimY * math.sqrt(NbPoint)), int(self.dimY / self.dimX * math.sqrt(NbPoint))
 
     def _CircumRect(self):
         return np.array([self.dimX, self.dimY])

@@ -1,10 +1,11 @@
 """matplotlib adaptors for the plot entry points of ART/ModuleAnalysisAndPlots.py (SpotDiagram :133-281, DelayGraph
-:284-441, MirrorProjection :444-525), fed from device-resident bundles.
+:284-441, MirrorProjection :444-525, RayRenderGraph :529-673), fed from device-resident bundles.
 
 Numbers shown in the legends (spot size, standard deviations, numerical aperture) are reduced on the device over
 ALL rays; the scatter itself shows at most MAX_POINTS survivors, evenly spaced in ray order, because a figure cannot
 resolve more and 1e7 markers would take minutes to draw.  matplotlib is imported on first use only, so the tracing
-path never depends on it.  The 3-D scene render of the reference (RayRenderGraph) needs PyVista and is not built."""
+path never depends on it.  The 3-D scene render (RayRenderGraph) is PyVista's in the reference; the image has no
+PyVista, so the same geometry (`render_scene`) is drawn on matplotlib's 3-D axes."""
 import numpy as np
 
 from . import ModuleProcessing as mp
@@ -243,6 +244,112 @@ def MirrorProjection(OpticalChain, ReflectionNumber: int, Detector=None, ColorCo
     ax.autoscale_view()
     fig.tight_layout()
     plt.show()
+    return fig
+
+
+def _same_slots(a, b):
+    """Slot i of both bundles is the same source ray (bundles of one trace share their `number` tensor)."""
+    return a.n_slots == b.n_slots and a.number is b.number
+
+
+def _ray_segments(history, EndDistance, maxRays):
+    """Per stage k of the history a (2 m, 3) array of segment end points, pairs in ray order: from the ray's point in
+    bundle k to its point in bundle k + 1 for the rays that are still alive there; for the last bundle, from the point
+    along the direction over EndDistance (ART/ModuleAnalysisAndPlots.py:563-602).  At most maxRays rays per stage --
+    evenly spaced in ray order here, a random draw in the reference.  Only the drawn rays leave the device."""
+    import torch
+    out = []
+    for k, B in enumerate(history):
+        last = k == len(history) - 1
+        nxt = B if last else history[k + 1]
+        pos = _sample_positions(len(nxt), cap=maxRays)
+        slots = nxt.index().index_select(0, torch.as_tensor(pos, device=nxt.backend.device))
+        P2 = nxt.data[0:3].index_select(1, slots).cpu().numpy().T
+        if last:
+            P1, P2 = P2, P2 + nxt.data[3:6].index_select(1, slots).cpu().numpy().T * EndDistance
+        elif _same_slots(B, nxt):
+            P1 = B.data[0:3].index_select(1, slots).cpu().numpy().T
+        else:       # bundles that do not share their slots (e.g. built from Ray lists): match the ray numbers
+            mine = B.numbers()
+            order = np.argsort(mine, kind="stable")
+            want = nxt.numbers()[pos]
+            at = order[np.searchsorted(mine, want, sorter=order)]
+            if not np.array_equal(mine[at], want):
+                raise ValueError("a ray of bundle %d has no ancestor in bundle %d" % (k + 1, k))
+            P1 = B.points()[at]
+        seg = np.empty((2 * len(pos), 3))
+        seg[0::2], seg[1::2] = P1, P2
+        out.append(seg)
+    return out
+
+
+def _optic_cloud(OE, OEpoints, draw_mesh=False):
+    """Sample points of one optical element's surface in the lab frame and the closed index loops of its hole outlines
+    (ART/ModuleAnalysisAndPlots.py:529-561).  Without a mesh the cloud sits 0.5 mm behind the surface, so that the ray
+    ends on it stay visible."""
+    from . import ModuleGeometry as mgeo
+    pts, loops = OE.type.get_grid3D(OEpoints, edges=True)
+    P = np.asarray(pts, dtype=float).reshape(-1, 3) - np.asarray(OE.type.get_centre(), dtype=float)
+    _, bwd = mgeo.frame_maps(OE.normal, OE.majoraxis)
+    P = P @ bwd.T + np.asarray(OE.position, dtype=float)
+    if not draw_mesh:
+        P = P - 0.5 * np.asarray(OE.normal, dtype=float)
+    return P, loops
+
+
+def render_scene(OpticalChain, EndDistance=None, maxRays=300, OEpoints=3000, draw_mesh=False):
+    """The geometry RayRenderGraph draws, as host arrays (for any renderer): {"segments": one (2 m, 3) array of
+    segment end points per stage (source -> element 0, ..., last element -> EndDistance further), "optics": one
+    (p, 3) lab-frame point cloud per optical element, "loops": their hole outlines as index loops, "EndDistance"}."""
+    history = [_as_bundle(OpticalChain.source_rays)] + [_as_bundle(b) for b in OpticalChain.get_output_rays()]
+    if EndDistance is None:
+        EndDistance = float(np.linalg.norm(np.asarray(OpticalChain.source_rays[0].point, dtype=float)
+                                           - np.asarray(OpticalChain.optical_elements[0].position, dtype=float)))
+    clouds = [_optic_cloud(OE, OEpoints, draw_mesh) for OE in OpticalChain.optical_elements]
+    return {"segments": _ray_segments(history, EndDistance, maxRays), "optics": [c[0] for c in clouds],
+            "loops": [c[1] for c in clouds], "EndDistance": EndDistance}
+
+
+def generate_distinct_colors(num_colors):
+    """num_colors visually distinct colours (the reference takes colorcet's glasbey palette, :604-614; matplotlib's
+    tab20 here)."""
+    cmap = _plt().get_cmap("tab20")
+    return [cmap(i % 20)[:3] for i in range(num_colors)]
+
+
+def RayRenderGraph(OpticalChain, EndDistance=None, maxRays=300, OEpoints=3000, scale_spheres=5.0, draw_mesh=False,
+                   cycle_ray_colors=False):
+    """3-D picture of the optical setup and of at most maxRays traced rays (ART/ModuleAnalysisAndPlots.py:616-673), on
+    matplotlib's 3-D axes.  Returns the figure; `fig._art_scene` holds the arrays that were drawn (render_scene)."""
+    import colorsys
+    from mpl_toolkits.mplot3d.art3d import Line3DCollection
+    plt = _plt()
+    print("...rendering image of optical chain...", end="", flush=True)
+    scene = render_scene(OpticalChain, EndDistance, maxRays, OEpoints, draw_mesh)
+    n_stage = len(scene["segments"])
+    colors = generate_distinct_colors(n_stage) if cycle_ray_colors else [(0.7, 0.0, 0.0)] * n_stage
+    fig = plt.figure(figsize=(15, 5))
+    ax = fig.add_subplot(111, projection="3d")
+    for seg, color in zip(scene["segments"], colors):
+        ax.add_collection3d(Line3DCollection(seg.reshape(-1, 2, 3), colors=[color], linewidths=0.6))
+    everything = [seg for seg in scene["segments"] if len(seg)]
+    for i, (cloud, loops) in enumerate(zip(scene["optics"], scene["loops"])):
+        h, sat, v = colorsys.rgb_to_hsv(*colors[min(i + 1, n_stage - 1)])
+        pale = colorsys.hsv_to_rgb(h, 0.2 * sat, v)        # the optic in the pale shade of the rays that leave it
+        ax.scatter(cloud[:, 0], cloud[:, 1], cloud[:, 2], s=scale_spheres, color=[pale], depthshade=False)
+        if draw_mesh:
+            for loop in loops:
+                ax.plot(*cloud[loop].T, color=pale, linewidth=1.0)
+        everything.append(cloud)
+    lo, hi = np.concatenate(everything).min(axis=0), np.concatenate(everything).max(axis=0)
+    mid, half = 0.5 * (lo + hi), 0.5 * float((hi - lo).max())
+    for setter, c in zip((ax.set_xlim, ax.set_ylim, ax.set_zlim), mid):
+        setter(c - half, c + half)                         # equal scales on the three axes
+    ax.set_xlabel("x (mm)")
+    ax.set_ylabel("y (mm)")
+    ax.set_zlabel("z (mm)")
+    fig._art_scene = scene
+    print("\r\033[K", end="", flush=True)
     return fig
 
 

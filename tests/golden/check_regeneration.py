@@ -20,7 +20,8 @@ def main():
     out = sys.argv[1] if len(sys.argv) > 1 else tempfile.mkdtemp(prefix="golden_regen_")
     os.makedirs(out, exist_ok=True)
     env = dict(os.environ, ART_GOLDEN_OUT=out, PYTHONDONTWRITEBYTECODE="1")
-    subprocess.check_call([sys.executable, os.path.join(HERE, "generate_goldens.py")], env=env, stdout=subprocess.DEVNULL)
+    for script in ("generate_goldens.py", "generate_render_goldens.py"):
+        subprocess.check_call([sys.executable, os.path.join(HERE, script)], env=env, stdout=subprocess.DEVNULL, cwd=HERE)
     bad, n = [], 0
     for f in sorted(glob.glob(os.path.join(HERE, "*.npz"))):
         g = os.path.join(out, os.path.basename(f))

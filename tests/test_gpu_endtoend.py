@@ -1,7 +1,7 @@
 """GPU (-m gpu): SURVEY 8 rows f4 and the end-to-end path on the HIP backend.
   * archives: save_compressed / load_compressed (ART/ModuleProcessing.py:612-633) of DEVICE bundles -- bit-equal
     arrays, lazy re-upload, usable for further tracing;
-  * plot adaptors fed from device bundles (SpotDiagram, DelayGraph, MirrorProjection; ART/ModuleAnalysisAndPlots.py:
+  * plot adaptors fed from device bundles (SpotDiagram, DelayGraph, MirrorProjection, RayRenderGraph; ART/ModuleAnalysisAndPlots.py:
     62-129, :133-673): the data inside the figures against the oracle;
   * ARTmain.run_ART / ARTmain.main (ART/ARTmain.py:248-342) on fixture-built chains against the fixtures'
     ETransmission / SpotSizeSD / DurationSD, with and without autofocus, single chain and loop list."""
@@ -51,6 +51,14 @@ def test_gpu_delay_graph_and_mirror_projection(scene):
 
 def test_gpu_large_bundles_are_down_sampled(scene, monkeypatch):
     tp.test_large_bundles_are_down_sampled(scene, monkeypatch)
+
+
+def test_gpu_render_scene_is_the_references_geometry(scene):
+    tp.test_render_scene_is_the_references_geometry(scene)       # only the drawn rays leave the device
+
+
+def test_gpu_ray_render_graph_draws_the_scene(scene):
+    tp.test_ray_render_graph_draws_the_scene(scene)
 
 
 def test_gpu_archive_round_trip_of_device_bundles(hip, tmp_path, monkeypatch):

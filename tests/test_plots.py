@@ -119,3 +119,96 @@ def test_large_bundles_are_down_sampled(scene, monkeypatch):
     text = fig.axes[0].get_legend().get_texts()[0].get_text()
     assert "{:.1f} μm SD".format(scene["scene"]["SpotSizeSD"] * 1e3) in text     # statistics still over all rays
     plt.close(fig)
+
+
+# ---- the 3-D scene render (RayRenderGraph, ART/ModuleAnalysisAndPlots.py:529-673) against tests/golden/render_grids.npz,
+# made by running the reference's own _get_grid / _Contour_points / get_grid3D / _RenderRays / _RenderOpticalElement
+def _render_golden():
+    return load_golden("render_grids")
+
+
+def test_support_sample_points_are_the_references():
+    sc, z = _render_golden()
+    for name, d in sc["supports"].items():
+        S = pc.build_support(d)
+        for n in (200, 37):
+            got = np.array(S._get_grid(n)).reshape(-1, 2)
+            assert got.shape == z[f"sup_{name}_grid{n}"].shape and np.abs(got - z[f"sup_{name}_grid{n}"]).max() <= 1e-12
+            assert all(S._IncludeSupport(p) for p in got)
+        pts, loops = S._Contour_points(40, edges=True)
+        assert loops == d["contour40_edges"]
+        assert np.abs(np.array(pts).reshape(-1, 2) - z[f"sup_{name}_contour40"]).max() <= 1e-12
+        assert len(S._Contour_points(40)) == len(pts)
+
+
+def test_surface_sample_points_are_the_references():
+    sc, z = _render_golden()
+    for name, d in sc["optics"].items():
+        O = pc.build_optic(d)
+        pts, loops = O.get_grid3D(300, edges=True)
+        ref = z[f"opt_{name}_grid300"]
+        got = np.array(pts).reshape(-1, 3)
+        assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()), name
+        assert loops == d["grid300_edges"], name
+        assert len(O.get_grid3D(300)) == len(ref)
+    import ART.ModuleMirror as mmirror
+    import ART.ModuleDefects as mdef
+    par = pc.build_optic(sc["optics"]["parabola"])
+    deformed = mmirror.DeformedMirror(par, [mdef.Zernike(par.support, {(2, 1): 1e-4})])
+    assert np.array_equal(np.array(deformed.get_grid3D(100)), np.array(par.get_grid3D(100)))   # the render ignores defects
+
+
+def test_render_scene_is_the_references_geometry(scene):
+    from attosecondraytracing_amd import _plots
+    sc, z = _render_golden()
+    assert sc["c3"]["fixture"] == "c3_twisted_chain04"
+    r = _plots.render_scene(scene["chain"], None, maxRays=5000, OEpoints=sc["c3"]["OEpoints"])
+    assert abs(r["EndDistance"] - sc["c3"]["EndDistance"]) <= 1e-9
+    assert len(r["segments"]) == 4 and len(r["optics"]) == 3
+    for k, seg in enumerate(r["segments"]):
+        ref = z[f"c3_segments{k}"]
+        assert seg.shape == ref.shape and np.abs(seg - ref).max() <= 1e-10 * np.abs(ref).max(), k
+    for k, cloud in enumerate(r["optics"]):
+        ref = z[f"c3_optic{k}"]
+        assert cloud.shape == ref.shape and np.abs(cloud - ref).max() <= 1e-10 * np.abs(ref).max(), k
+    # down-sampled: at most maxRays rays per stage, each segment still joins one ray's points in consecutive bundles
+    few = _plots.render_scene(scene["chain"], 25.0, maxRays=40, OEpoints=100)
+    history = [scene["chain"].source_rays] + list(scene["chain"].get_output_rays())
+    for k, seg in enumerate(few["segments"]):
+        assert len(seg) == 80
+        nxt = history[min(k + 1, 3)]
+        ends = seg[1::2] if k < 3 else seg[0::2]
+        d = np.abs(ends[:, None, :] - nxt.points()[None, :, :]).max(axis=2).min(axis=1)
+        assert d.max() == 0.0
+    assert np.allclose(np.linalg.norm(few["segments"][3][1::2] - few["segments"][3][0::2], axis=1), 25.0, rtol=1e-12)
+
+
+def test_render_scene_matches_rays_by_number_when_slots_differ(scene):
+    """Bundles built from Ray lists do not share their slots: the segments are then matched by ray number."""
+    from attosecondraytracing_amd import _plots
+    from attosecondraytracing_amd.bundle import RayBundle
+    history = [scene["chain"].source_rays] + list(scene["chain"].get_output_rays())
+    same = _plots._ray_segments(history, 10.0, 5000)
+    rebuilt = [history[0]] + [RayBundle.from_ray_list(list(b)) for b in history[1:]]
+    assert not _plots._same_slots(rebuilt[0], rebuilt[1])
+    other = _plots._ray_segments(rebuilt, 10.0, 5000)
+    for a, b in zip(same, other):      # (a Ray renormalises its vector: the last stage agrees to rounding only)
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-12 * np.abs(a).max()
+
+
+def test_ray_render_graph_draws_the_scene(scene):
+    import ART.ModuleAnalysisAndPlots as mplots
+    import matplotlib.pyplot as plt
+    fig = mplots.RayRenderGraph(scene["chain"], maxRays=50, OEpoints=200, draw_mesh=True, cycle_ray_colors=True)
+    ax = fig.axes[0]
+    lines = [c for c in ax.collections if type(c).__name__ == "Line3DCollection"]
+    clouds = [c for c in ax.collections if type(c).__name__ == "Path3DCollection"]
+    assert len(lines) == 4 and len(clouds) == 3
+    assert [len(s) // 2 for s in fig._art_scene["segments"]] == [50, 50, 50, 50]
+    assert len(mplots.generate_distinct_colors(5)) == 5
+    lo, hi = ax.get_xlim()
+    assert abs((hi - lo) - (ax.get_ylim()[1] - ax.get_ylim()[0])) <= 1e-9 * (hi - lo)      # equal scales
+    plt.close(fig)
+    fig = scene["chain"].render()
+    assert len(fig._art_scene["optics"]) == 3
+    plt.close(fig)
