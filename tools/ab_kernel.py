@@ -5,7 +5,9 @@ on the launch stream, so that clock ramps, thermal state and the box itself are 
 runs of the same build differ by up to 6 % in kernel time on this pool).
 
     python tools/ab_kernel.py [--config relay4|C2|C3|C4] [--rounds 12] [--launches 20] [--readout fused|none]
-                              [--variants "ART_CHAIN_RPL=1;ART_CHAIN_RPL=2 ART_CHAIN_WAVES=4"]
+                              [--variants "ART_CHAIN_RPL=1;ART_CHAIN_RPL=2 ART_CHAIN_WAVES=4;LIB=build/variants/libart_x.so"]
+(`LIB=path`: a diagnostic BUILD of the library, loaded beside the default one; its results may be wrong by design;
+ `RO=none|fused`: the read-out of this variant)
 Prints per variant the median / min of the per-round mean launch time and the ratio to the first variant."""
 import argparse
 import os
@@ -25,6 +27,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=12)
     ap.add_argument("--launches", type=int, default=20)
     ap.add_argument("--readout", default="fused", choices=["fused", "none"])
+    ap.add_argument("--mode", default=None, choices=["chain", "element"], help="launch form of a single chain (default: the library's choice)")
     ap.add_argument("--variants", default="ART_CHAIN_RPL=1;ART_CHAIN_RPL=2 ART_CHAIN_WAVES=4")
     args = ap.parse_args()
     import torch
@@ -53,24 +56,39 @@ def main():
         del out
     many = len(element_lists) > 1
 
+    state = {"readout": args.readout}
+
     def launch():
+        fused = state["readout"] == "fused"
         if many:
             return mp.RayTracingCalculationMany([src] * len(element_lists), element_lists, IgnoreDefects=ign,
-                                                detectors=dets if args.readout == "fused" else None)
-        return mp.RayTracingCalculation(src, element_lists[0], IgnoreDefects=ign,
-                                        detector=dets[0] if args.readout == "fused" else None)
+                                                detectors=dets if fused else None)
+        return mp.RayTracingCalculation(src, element_lists[0], IgnoreDefects=ign, mode=args.mode,
+                                        detector=dets[0] if fused else None)
 
     variants = [v.strip() for v in args.variants.split(";")]
-    knobs = sorted({kv.split("=")[0] for v in variants for kv in v.split() if "=" in kv})
+    knobs = sorted({kv.split("=")[0] for v in variants for kv in v.split() if "=" in kv} - {"LIB", "RO"})
     times = {v: [] for v in variants}
+    default_be, builds = be, {}
     for rnd in range(args.rounds + 1):
         for v in variants:
             for k in knobs:
                 os.environ.pop(k, None)
+            be = default_be
+            state["readout"] = args.readout
             for kv in v.split():
-                if "=" in kv:
+                if kv.startswith("RO="):            # this variant's read-out: fused | none
+                    state["readout"] = kv[3:]
+                    continue
+                if kv.startswith("LIB="):           # another BUILD of the library, loaded into this process beside the default
+                    path = kv[4:]
+                    if path not in builds:
+                        builds[path] = _lib.HipBackend(os.path.join(ROOT, path))
+                    be = builds[path]
+                elif "=" in kv:
                     k, val = kv.split("=")
                     os.environ[k] = val
+            _lib._BACKEND = src._backend = be
             be.trace_events = []
             for _ in range(args.launches):
                 launch()
