@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=12)
     ap.add_argument("--launches", type=int, default=20)
     ap.add_argument("--readout", default="fused", choices=["fused", "none"])
+    ap.add_argument("--scene", action="store_true", help="a single chain through the scene-table launch (what a graph-replayed SceneProgram issues) instead of the by-value one")
     ap.add_argument("--mode", default=None, choices=["chain", "element"], help="launch form of a single chain (default: the library's choice)")
     ap.add_argument("--variants", default="ART_CHAIN_RPL=1;ART_CHAIN_RPL=2 ART_CHAIN_WAVES=4")
     args = ap.parse_args()
@@ -54,7 +55,7 @@ def main():
         d.autoplace(out[-1], dist)
         dets.append(d)
         del out
-    many = len(element_lists) > 1
+    many = len(element_lists) > 1 or args.scene
 
     state = {"readout": args.readout}
 
