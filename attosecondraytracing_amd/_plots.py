@@ -297,17 +297,34 @@ def _optic_cloud(OE, OEpoints, draw_mesh=False):
     return P, loops
 
 
+def _optic_triangles(OE, OEpoints):
+    """Triangles (index triples into the cloud of _optic_cloud) of the optic's surface for draw_mesh=True: a Delaunay
+    triangulation of the sample points in the plane of the support, without the triangles that bridge a hole or a
+    concave outline (the reference asks PyVista for a Delaunay mesh constrained by the hole outlines, :544-560)."""
+    from matplotlib.tri import Triangulation
+    pts = np.asarray(OE.type.get_grid3D(OEpoints), dtype=float).reshape(-1, 3)
+    xy = pts[:, :2] - np.asarray(OE.type.get_centre(), dtype=float)[:2]
+    if len(xy) < 3:
+        return np.empty((0, 3), dtype=np.int64)
+    tri = Triangulation(xy[:, 0], xy[:, 1]).triangles
+    mid = xy[tri].mean(axis=1)
+    inside = np.fromiter((bool(OE.type.support._IncludeSupport(m)) for m in mid), dtype=bool, count=len(mid))
+    return tri[inside].astype(np.int64)
+
+
 def render_scene(OpticalChain, EndDistance=None, maxRays=300, OEpoints=3000, draw_mesh=False):
     """The geometry RayRenderGraph draws, as host arrays (for any renderer): {"segments": one (2 m, 3) array of
     segment end points per stage (source -> element 0, ..., last element -> EndDistance further), "optics": one
-    (p, 3) lab-frame point cloud per optical element, "loops": their hole outlines as index loops, "EndDistance"}."""
+    (p, 3) lab-frame point cloud per optical element, "loops": their hole outlines as index loops, "EndDistance",
+    "triangles": with draw_mesh, the surface mesh of every optic as index triples into its cloud}."""
     history = [_as_bundle(OpticalChain.source_rays)] + [_as_bundle(b) for b in OpticalChain.get_output_rays()]
     if EndDistance is None:
         EndDistance = float(np.linalg.norm(np.asarray(OpticalChain.source_rays[0].point, dtype=float)
                                            - np.asarray(OpticalChain.optical_elements[0].position, dtype=float)))
     clouds = [_optic_cloud(OE, OEpoints, draw_mesh) for OE in OpticalChain.optical_elements]
     return {"segments": _ray_segments(history, EndDistance, maxRays), "optics": [c[0] for c in clouds],
-            "loops": [c[1] for c in clouds], "EndDistance": EndDistance}
+            "loops": [c[1] for c in clouds], "EndDistance": EndDistance,
+            "triangles": [_optic_triangles(OE, OEpoints) for OE in OpticalChain.optical_elements] if draw_mesh else None}
 
 
 def generate_distinct_colors(num_colors):
@@ -338,6 +355,9 @@ def RayRenderGraph(OpticalChain, EndDistance=None, maxRays=300, OEpoints=3000, s
         pale = colorsys.hsv_to_rgb(h, 0.2 * sat, v)        # the optic in the pale shade of the rays that leave it
         ax.scatter(cloud[:, 0], cloud[:, 1], cloud[:, 2], s=scale_spheres, color=[pale], depthshade=False)
         if draw_mesh:
+            tri = scene["triangles"][i]
+            if len(tri):
+                ax.plot_trisurf(cloud[:, 0], cloud[:, 1], cloud[:, 2], triangles=tri, color=pale, alpha=0.6, linewidth=0)
             for loop in loops:
                 ax.plot(*cloud[loop].T, color=pale, linewidth=1.0)
         everything.append(cloud)

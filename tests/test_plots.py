@@ -204,6 +204,12 @@ def test_ray_render_graph_draws_the_scene(scene):
     lines = [c for c in ax.collections if type(c).__name__ == "Line3DCollection"]
     clouds = [c for c in ax.collections if type(c).__name__ == "Path3DCollection"]
     assert len(lines) == 4 and len(clouds) == 3
+    meshes = [c for c in ax.collections if type(c).__name__ == "Poly3DCollection"]
+    assert len(meshes) == 3                                  # draw_mesh: one triangulated surface per optic
+    for OE, cloud, tri in zip(scene["chain"].optical_elements, fig._art_scene["optics"], fig._art_scene["triangles"]):
+        assert len(tri) > 50 and tri.min() >= 0 and tri.max() < len(cloud)
+        pts = np.asarray(OE.type.get_grid3D(200), dtype=float)[:, :2] - np.asarray(OE.type.get_centre(), dtype=float)[:2]
+        assert all(OE.type.support._IncludeSupport(m) for m in pts[tri].mean(axis=1))     # no triangle bridges the hole
     assert [len(s) // 2 for s in fig._art_scene["segments"]] == [50, 50, 50, 50]
     assert len(mplots.generate_distinct_colors(5)) == 5
     lo, hi = ax.get_xlim()
