@@ -347,6 +347,8 @@ def RayRenderGraph(OpticalChain, EndDistance=None, maxRays=300, OEpoints=3000, s
     colors = generate_distinct_colors(n_stage) if cycle_ray_colors else [(0.7, 0.0, 0.0)] * n_stage
     fig = plt.figure(figsize=(15, 5))
     ax = fig.add_subplot(111, projection="3d")
+    ax.view_init(elev=20, azim=-75)
+    ax.set_proj_type("ortho")           # (a perspective camera clips the near end of a zoomed, elongated box)
     for seg, color in zip(scene["segments"], colors):
         ax.add_collection3d(Line3DCollection(seg.reshape(-1, 2, 3), colors=[color], linewidths=0.6))
     everything = [seg for seg in scene["segments"] if len(seg)]
@@ -362,9 +364,12 @@ def RayRenderGraph(OpticalChain, EndDistance=None, maxRays=300, OEpoints=3000, s
                 ax.plot(*cloud[loop].T, color=pale, linewidth=1.0)
         everything.append(cloud)
     lo, hi = np.concatenate(everything).min(axis=0), np.concatenate(everything).max(axis=0)
-    mid, half = 0.5 * (lo + hi), 0.5 * float((hi - lo).max())
-    for setter, c in zip((ax.set_xlim, ax.set_ylim, ax.set_zlim), mid):
-        setter(c - half, c + half)                         # equal scales on the three axes
+    span = np.maximum(hi - lo, 0.08 * float((hi - lo).max()))      # a beam line is thin: no axis flatter than 8 % of the longest
+    mid = 0.5 * (lo + hi)
+    for setter, c, w in zip((ax.set_xlim, ax.set_ylim, ax.set_zlim), mid, span):
+        setter(c - 0.5 * w, c + 0.5 * w)
+    ax.set_box_aspect(tuple(span), zoom=1.9)               # equal scales on the three axes, the box shaped like the setup
+    fig.subplots_adjust(left=0.0, right=1.0, bottom=0.0, top=1.0)
     ax.set_xlabel("x (mm)")
     ax.set_ylabel("y (mm)")
     ax.set_zlabel("z (mm)")

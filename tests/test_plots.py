@@ -212,8 +212,9 @@ def test_ray_render_graph_draws_the_scene(scene):
         assert all(OE.type.support._IncludeSupport(m) for m in pts[tri].mean(axis=1))     # no triangle bridges the hole
     assert [len(s) // 2 for s in fig._art_scene["segments"]] == [50, 50, 50, 50]
     assert len(mplots.generate_distinct_colors(5)) == 5
-    lo, hi = ax.get_xlim()
-    assert abs((hi - lo) - (ax.get_ylim()[1] - ax.get_ylim()[0])) <= 1e-9 * (hi - lo)      # equal scales
+    spans = np.array([np.diff(ax.get_xlim())[0], np.diff(ax.get_ylim())[0], np.diff(ax.get_zlim())[0]])
+    ratio = spans / np.asarray(ax.get_box_aspect())
+    assert np.abs(ratio / ratio[0] - 1).max() <= 1e-9                                          # equal scales on the three axes
     plt.close(fig)
     fig = scene["chain"].render()
     assert len(fig._art_scene["optics"]) == 3
