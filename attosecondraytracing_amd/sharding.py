@@ -283,6 +283,9 @@ class SurvivorGather:
         self.be, self.n, self.world, self.rank, self.dst = backend, int(n), int(world), int(rank), int(dst)
         # (first, step, n) of every rank's shard: for the implicit numbers of dense shards on the root
         self.specs = specs if specs is not None else [(0, 1, self.n)] * self.world
+        top = max(first + (cnt - 1) * step for first, step, cnt in self.specs if cnt > 0) if any(s[2] > 0 for s in self.specs) else 0
+        if top > 2 ** 31 - 1:
+            raise ValueError("ray numbers up to %d do not fit the int32 of a survivor record" % top)
         dev = backend.device
         # capacity of every buffer: the longest shard with every slot alive and explicit numbers (28 B per ray)
         self.cap = backend.survivor_bytes(max([self.n] + [s[2] for s in self.specs]), False)

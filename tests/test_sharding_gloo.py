@@ -279,3 +279,17 @@ def test_strided_shards_reassemble_to_the_single_process_result():
         assert sharding.shard_spec(10, 3, 4, "strided") == (3, 4, 2) and sharding.shard_spec(2, 3, 4, "strided")[2] == 0
     finally:
         _lib._BACKEND = old
+
+
+def test_survivor_gather_refuses_ray_numbers_beyond_int32():
+    """The survivor record carries the ray number as int32: a job whose numbers do not fit is refused when the
+    gather is set up, not truncated on the device."""
+    from attosecondraytracing_amd import sharding
+
+    class NoBackend:            # the check comes before anything touches the device
+        device = "cpu"
+
+        def survivor_bytes(self, count, dense):
+            raise AssertionError("not reached")
+    with pytest.raises(ValueError, match="int32"):
+        sharding.SurvivorGather(NoBackend(), 10, 2, 0, specs=[(0, 1, 10), (2 ** 31 - 5, 1, 10)])
