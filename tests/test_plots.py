@@ -28,7 +28,6 @@ def scene(twin):
 def build_plot_scene():
     """Golden chain c3_twisted_chain04 traced by whatever backend is active + the oracle's view of the same scene
     (shared with the GPU suite, tests/test_gpu_endtoend.py)."""
-    import ART.ModuleProcessing as mp
     import ART.ModuleDetector as mdet
     import ART.ModuleOpticalChain as moc
     sc, a = load_golden("c3_twisted_chain04")
