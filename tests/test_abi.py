@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def lib():
+    import torch  # noqa: F401  (before the library: one HIP runtime per process, see __graft_entry__.build)
     import __graft_entry__ as g
     if g._stale(g.HIP_LIB, g.HIP_DEPS):
         g.build()
