@@ -624,6 +624,11 @@ def test_gpu_fused_readout_full_size(hip):
     rel = max(abs(g[k] - w[k]) / abs(w[k]) for k in (1, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 20, 21) if w[k] != 0)
     report(f"[fused read-out relay4 1e7] statistics vs separate read-out: max rel diff {rel:.1e} (summation order)")
     assert rel <= 1e-11
+    # the partials are folded in a fixed order: a second launch (by-value and scene-table form) gives the same bits
+    again = D.readout(mp.RayTracingCalculation(src, els, detector=D)[-1], sync=False)["stats_dev"]
+    assert torch.equal(again.view(torch.int64), got["stats_dev"].view(torch.int64))
+    many = mp.RayTracingCalculationMany([src], [els], detectors=[D])[0]
+    assert torch.equal(D.readout(many[-1], sync=False)["stats_dev"].view(torch.int64), got["stats_dev"].view(torch.int64))
 
 
 def test_gpu_fused_readout_fold_boundary(hip):
