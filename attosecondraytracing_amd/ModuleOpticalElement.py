@@ -65,7 +65,9 @@ class OpticalElement:
     majoraxis = property(_get_majoraxis, _set_majoraxis)
 
     def __hash__(self):
-        pose = tuple(self.position) + tuple(self.normal) + tuple(self.majoraxis)
+        # equal poses hash equal whatever their dtype and the sign of their zeros, like the reference's tuples of numbers
+        # (ART/ModuleOpticalElement.py:107-112); through bytes, because this runs for every element of every trace call
+        pose = b"".join((np.asarray(v, dtype=float) + 0.0).tobytes() for v in (self._position, self._normal, self._majoraxis))
         return hash(pose) + hash(self.type)
 
     # ------------------------------------------------------------------ (mis-)alignment, angles in degrees
