@@ -109,3 +109,18 @@ def test_profile_of_another_build_is_dropped(monkeypatch):
     assert hit is None and "dropped" in note and os.path.basename(profs[-1]) in note
     # the tree's own hash is a pure function of the four source files
     assert len(sh.__dict__["FILES"]) == 4 and all(os.path.exists(os.path.join(ROOT, f)) for f in sh.FILES)
+
+
+def test_bench_gpus_8_over_gloo():
+    """The driver's largest case, rehearsed with CPU ranks: eight ranks (an odd ray count per rank, strided shards of a
+    masked loop-list scene), every rank in the all-gather and in the ONE survivor gather."""
+    p = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--rays", "1501", "--config", "C3", "--shard", "strided",
+              "--cpu-sample", "0"], OMP_NUM_THREADS="1")
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["config"]["world_size_seen"] == 8 and j["config"]["shard_layout"] == "strided"
+    assert j["value"] > 0 and j["value_full_gather"] > 0
+    # the gathered records are the survivors of the whole job: about two thirds of 8 x 1501 rays pass C3's mask
+    assert 0.5 * 8 * 1501 < j["config"]["gather_survivors"] < 0.8 * 8 * 1501
