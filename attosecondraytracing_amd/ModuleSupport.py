@@ -112,15 +112,15 @@ def gen_circle_contour(radius, NbPoints):
 def gen_rectangle_contour(dimX, dimY, NbPoints):
     """Outline of a rectangle, clockwise from its top-left corner; NbPoints is shared between ONE horizontal and ONE
     vertical side, so about 2 NbPoints - 4 points come back (ART/ModuleSupport.py:546-563)."""
-    nX = max(math.ceil(dimX / (dimX + dimY) * NbPoints), 2)
-    nY = max(NbPoints - nX, 2)            # (the reference divides by zero when a side gets fewer than two points)
-    dX, dY = dimX / (nX - 1), dimY / (nY - 1)
-    i, j = np.arange(nX), np.arange(nY)
-    top = np.column_stack((i * dX - dimX / 2, np.full(nX, dimY / 2)))
-    right = np.column_stack((np.full(nY - 1, dimX / 2), dimY / 2 - j[1:] * dY))
-    bottom = np.column_stack((dimX / 2 - i[1:] * dX, np.full(nX - 1, -dimY / 2)))
-    left = np.column_stack((np.full(max(nY - 2, 0), -dimX / 2), -dimY / 2 + j[1:nY - 1] * dY))
-    return np.concatenate((top, right, bottom, left))
+    along = max(math.ceil(dimX / (dimX + dimY) * NbPoints), 2)      # points on a horizontal side, corners included
+    up = max(NbPoints - along, 2)          # ... on a vertical side (the reference divides by zero when a side gets fewer than two)
+    xs = np.linspace(-dimX / 2, dimX / 2, along)
+    ys = np.linspace(dimY / 2, -dimY / 2, up)
+    sides = (np.column_stack((xs, np.full(along, dimY / 2))),                           # top, left to right
+             np.column_stack((np.full(up - 1, dimX / 2), ys[1:])),                      # right, downwards
+             np.column_stack((xs[::-1][1:], np.full(along - 1, -dimY / 2))),            # bottom, right to left
+             np.column_stack((np.full(max(up - 2, 0), -dimX / 2), ys[::-1][1:up - 1])))  # left, upwards, both corners taken
+    return np.concatenate(sides)
 
 
 def flatten_point_arrays(outer, holes=(), edges=False):
