@@ -71,20 +71,11 @@ class SceneProgram:
             raise ValueError("all chains of a SceneProgram share the element count and the ray count")
         # history=False: only every chain's LAST bundle is written (the others are None) -- what a caller that analyses the
         # final bundle needs (ARTmain's lazy history); chains of at most 8 elements (one fused launch, no hand-over bundle)
-        if history:
-            self.outputs = RayBundle.allocate_grid(self.n, self.c, self.m, self.sources, self.be)
-        else:
-            if self.m > 8:
-                raise ValueError("SceneProgram(history=False) covers chains of at most 8 elements")
-            self.outputs = [[None] * (self.m - 1) + [RayBundle.allocate(self.n, like=s, backend=self.be)] for s in self.sources]
-        for ci, outs in enumerate(self.outputs):
-            prev = self.sources[ci]
-            for b in outs:
-                if b is not None:
-                    b.parent = prev
-                    prev = b
+        if not history and self.m > 8:
+            raise ValueError("SceneProgram(history=False) covers chains of at most 8 elements")
+        self._history = bool(history)
         self._views_in = [s.view() for s in self.sources]
-        self._views_out = [b.view() if b is not None else _abi.ArtBundleView() for outs in self.outputs for b in outs]
+        self._bind(self._alloc_outputs())
         self.detectors, self.readouts = None, None
         if detectors is not None and self.n <= self.be.MAX_FUSED_READOUT_RAYS:
             if len(detectors) != self.c:
@@ -96,6 +87,9 @@ class SceneProgram:
         self._signature = None
         self.post, self.post_result = post, None
         self.update(element_lists)
+        self.placement = None
+        if self.be.name == "hip":
+            self._tune_placement(element_lists)
         self.graph = None
         if capture and self.be.name == "hip":
             side = torch.cuda.Stream()
@@ -110,6 +104,72 @@ class SceneProgram:
                 self._launch()
             if hasattr(self.be, "counted_launches"):
                 self.be.counted_launches = counted      # a captured launch has not run
+
+    # ---- where the output bundles lie ------------------------------------------------------------------------------
+    # The same launch into another allocation of the same size takes up to 25 % longer or shorter (tools/pitch_probe.py:
+    # 16 buffers of one size, C4 1.10-1.16 ms in thirteen of them and 1.39-1.42 ms in three, relay4 0.535-0.547 / 0.585-
+    # 0.595 ms; a plain fill runs at the same 6.7 TB/s in all of them, row pitch and start offset INSIDE one buffer change
+    # nothing).  A launch writes 8 m + 3 streams at once, i.e. it keeps that many pages per workgroup in flight: what
+    # differs from one allocation to the next is how the driver mapped it, not the memory.  A program keeps its output
+    # bundles for its lifetime, so it can afford to look: it allocates a few candidates, times its own launch into each and
+    # keeps the fastest (ART_PLACEMENT_TRIES, default 6; 1 = take the first).
+    def _alloc_outputs(self):
+        from .bundle import RayBundle
+        if self._history:
+            return RayBundle.allocate_grid(self.n, self.c, self.m, self.sources, self.be)
+        return [[None] * (self.m - 1) + [RayBundle.allocate(self.n, like=s, backend=self.be)] for s in self.sources]
+
+    def _bind(self, outputs):
+        self.outputs = outputs
+        for ci, outs in enumerate(outputs):
+            prev = self.sources[ci]
+            for b in outs:
+                if b is not None:
+                    b.parent = prev
+                    prev = b
+        self._views_out = [b.view() if b is not None else self._abi.ArtBundleView() for outs in outputs for b in outs]
+
+    def _time_launch(self, reps=2):
+        seg = -(-self.m // 8)
+        self.be.trace_scene(self.dev, self.host, self.n, segments=seg)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            self.be.trace_scene(self.dev, self.host, self.n, segments=seg)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def _tune_placement(self, element_lists):
+        import os
+        rows = sum(b is not None for outs in self.outputs for b in outs)
+        nbytes = rows * 65 * self.n
+        tries = int(os.environ.get("ART_PLACEMENT_TRIES", "6"))
+        if nbytes < (64 << 20) or tries <= 1:
+            return
+        free, _ = torch.cuda.mem_get_info()
+        tries = max(1, min(tries, 1 + int(0.4 * free // nbytes)))      # the candidates exist side by side
+        if tries <= 1:
+            return
+        # the clocks first: a launch takes a third longer on a device that has just been idle (the governor's ramp lasts
+        # ~40 ms); without this the LAST candidate measured looks best
+        import time
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.08:
+            self._time_launch(reps=4)
+        pool = [self.outputs] + [self._alloc_outputs() for _ in range(tries - 1)]
+        times = [float("inf")] * tries
+        for order in (range(tries), reversed(range(tries))):       # two passes, the second in reverse order
+            for j in order:
+                self._bind(pool[j])
+                self.update(element_lists)
+                times[j] = min(times[j], self._time_launch(reps=3))
+        best = min(range(tries), key=times.__getitem__)
+        self._bind(pool[best])
+        self.update(element_lists)
+        self.placement = {"tries": tries, "launch_ms": [round(t, 4) for t in times], "chosen": best}
+        del pool
+        torch.cuda.empty_cache()        # hand the other candidates back to the driver
 
     def set_detectors(self, detectors):
         """(Re)place the fused read-outs' detectors; takes effect with the next update().  Only for a program that was

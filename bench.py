@@ -781,6 +781,11 @@ def worker(args):
                        "name": cfg, "rays_per_gpu": n, "elements": n_elems, "chains": n_chains,
                        "trace_mode": "scene (one launch for all chains)" if program is not None else mode,
                        "hip_graph": bool(use_graph), "world_size_seen": world, "shard_layout": args.shard,
+                       "output_placement": None if program is None or program.placement is None else dict(
+                           program.placement, note="the program allocated `tries` candidate blocks for its output bundles, "
+                           "timed its own launch into each (launch_ms) and kept the fastest: the same launch takes up to "
+                           "25 % longer in one allocation than in another of the same size (DESIGN.md 5, "
+                           "tools/pitch_probe.py); ART_PLACEMENT_TRIES=1 takes the first"),
                        "readout": "fused into the tracing launch" if fuse else "separate launch",
                        "step": "RayTracingCalculation + Detector.readout"
                                + (f" + ONE RCCL all-gather of every shard's 24 statistics and a {sample_k * world}-ray sample "

@@ -586,6 +586,32 @@ def test_gpu_scene_program_replays(hip):
     scene_cases.run_chain_list_cache()
 
 
+def test_gpu_scene_program_chooses_its_output_placement(hip, monkeypatch):
+    """A program times its own launch into a few candidate allocations of its output bundles and keeps the fastest
+    (graph.SceneProgram._tune_placement): same results as a program that takes the first allocation, bit for bit."""
+    import torch
+    import bench
+    from attosecondraytracing_amd.graph import SceneProgram
+    chain, _ = bench.build_scene(3)
+    els = chain.optical_elements
+    n = 2_000_000                                        # 3 x 65 B x 2e6 = 390 MB of outputs: above the tuner's threshold
+    src = bench.device_source(n, 0, n, hip)
+    monkeypatch.setenv("ART_PLACEMENT_TRIES", "4")
+    tuned = SceneProgram([src], [els])
+    assert tuned.placement["tries"] == 4 and len(tuned.placement["launch_ms"]) == 4
+    assert tuned.placement["launch_ms"][tuned.placement["chosen"]] == min(tuned.placement["launch_ms"])
+    monkeypatch.setenv("ART_PLACEMENT_TRIES", "1")
+    first = SceneProgram([src], [els])
+    assert first.placement is None
+    a, b = tuned.run()[0], first.run()[0]
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert x.data.data_ptr() != y.data.data_ptr()
+        assert torch.equal(x.alive, y.alive) and torch.equal(x.data.view(torch.int64), y.data.view(torch.int64))
+    small = SceneProgram([bench.device_source(1000, 0, 1000, hip)], [els])
+    assert small.placement is None                       # small bundles are not worth the look
+
+
 def test_gpu_loop_list_prefix_sharing(hip):
     """Loop lists from OEPlacement share the trace of their common prefix (mask + first toroid in C2 / C3)."""
     import scene_cases
