@@ -81,7 +81,36 @@ static int run(int64_t n, int nbuf) {
   return 0;
 }
 
+// `tlb_probe map [chunk_GiB] [count]`: the rate of the pattern (E = 4: 32 rows + 4 byte rows filling one chunk) in EVERY
+// chunk of `count` consecutive allocations -- the map of fast and slow regions a process meets as it allocates
+static int map_regions(double gib, int count) {
+  constexpr int E = 4;
+  const int64_t n = (int64_t)(gib * (1 << 30) / (E * 65)) / 32768 * 32768;
+  const int64_t nb = n / kB;
+  double* in; uint8_t* ain;
+  CK(hipMalloc(&in, 8 * n * 8)); CK(hipMalloc(&ain, n));
+  CK(hipMemset(in, 0, 8 * n * 8)); CK(hipMemset(ain, 1, n));
+  static double* out[512];
+  int got = 0;
+  for (; got < count && got < 512; ++got)
+    if (hipMalloc(&out[got], (size_t)E * 65 * n) != hipSuccess) { (void)hipGetLastError(); break; }
+  printf("map: %d chunks of %.2f GiB (%lld rays x %d rows each), pattern bytes %.2f GB per launch\n", got, E * 65.0 * n / (1 << 30),
+         (long long)n, 8 * E, (57.0 + 65.0 * E) * n * 1e-9);
+  const double bytes = (57.0 + 65.0 * E) * n;
+  for (int pass = 0; pass < 2; ++pass)
+    for (int b = 0; b < got; ++b) {
+      uint8_t* aout = reinterpret_cast<uint8_t*>(out[b]) + (size_t)E * 64 * n;
+      const float ms = timeit([&] { k_pattern<E, 0><<<nb, kB>>>(in, ain, out[b], aout, n); }, 10);
+      if (pass) printf("chunk %3d at %p  %.4f ms  %6.3f TB/s\n", b, (void*)out[b], ms, bytes / ms * 1e-9);
+    }
+  CK(hipDeviceSynchronize());
+  for (int b = 0; b < got; ++b) (void)hipFree(out[b]);
+  (void)hipFree(in); (void)hipFree(ain);
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && argv[1][0] == 'm') return map_regions(argc > 2 ? atof(argv[2]) : 2.0, argc > 3 ? atoi(argv[3]) : 100);
   const int64_t n = argc > 1 ? atoll(argv[1]) : 10000000;
   const int nbuf = argc > 2 ? atoi(argv[2]) : 12;
   if (n <= 0 || n > 50000000 || nbuf < 1 || nbuf > 32) { printf("arguments out of range\n"); return 2; }
