@@ -102,10 +102,33 @@ def main():
                 torch.cuda.synchronize()
                 fill[j] = nbytes * 5 / e[0].elapsed_time(e[1]) * 1e-9
                 copy[j] = nbytes * 5 / e[1].elapsed_time(e[2]) * 1e-9      # read + written bytes
+        # the BARE pattern (tools/pattern_lib.hip: the same reads and writes without any arithmetic) into the same views: the
+        # launch against its floor IN THE SAME MEMORY -- the only comparison the allocation lottery does not blur
+        bare = {}
+        lib_path = os.path.join(ROOT, "tools", "_build", "libpattern.so")
+        if os.path.exists(lib_path) and m in (1, 2, 3, 4, 8):
+            import ctypes as C
+            pl = C.CDLL(lib_path)
+            pl.pattern_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
+            sp = be.stream_ptr()
+            for rnd in range(3):
+                for j, b in enumerate(bufs):
+                    p0 = b.data_ptr()
+                    varr = (_abi.ArtBundleView * m)(*views(0, 0))
+                    for _ in range(3):
+                        assert pl.pattern_launch(C.byref(vin), varr, m, n, sp) == 0
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(args.launches):
+                        pl.pattern_launch(C.byref(vin), varr, m, n, sp)
+                    e1.record()
+                    e1.synchronize()
+                    bare[j] = e0.elapsed_time(e1) / args.launches
         for j, b in enumerate(bufs):
             t = np.array(times[j])
+            tail = f"   bare pattern {bare[j]:.4f} ms -> launch / floor {np.median(t) / bare[j]:.3f}" if j in bare else ""
             print(f"buffer {j}: {b.numel() / 2**30:.3f} GiB at 0x{b.data_ptr():x}  median {np.median(t):.4f} ms  min {t.min():.4f}  max {t.max():.4f}"
-                  f"   fill {fill[j]:.2f} TB/s  copy {copy[j]:.2f} TB/s")
+                  f"   fill {fill[j]:.2f} TB/s  copy {copy[j]:.2f} TB/s{tail}")
         return
     variants = [(pe, off) for off in offsets for pe in pitches]
     times = {v: [] for v in variants}
