@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--launches", type=int, default=20)
     ap.add_argument("--pitches", default="0;512;4096;65536;1048576;2097152;4194304;8388608;12582912;16777216;33554432")
     ap.add_argument("--offsets", default="0")
+    ap.add_argument("--knobs", default="", help="with --buffers: ';'-separated environment settings of the library (e.g. "
+                    "'ART_CHAIN_RPL=1;ART_CHAIN_RPL=2'), each timed in every buffer")
     ap.add_argument("--buffers", default="", help="instead: ';'-separated EXTRA sizes in bytes -- one buffer per entry, the same "
                     "launch (default pitch, offset 0) into each of them: is it the allocation that matters?")
     args = ap.parse_args()
@@ -73,18 +75,27 @@ def main():
     if args.buffers:
         extra = [int(v) for v in args.buffers.split(";")]
         bufs = [torch.empty(m * 8 * base_pitch + 4096 + e, dtype=torch.uint8, device=be.device) for e in extra]
+        knobs = [k for k in args.knobs.split(";") if k] or [""]
         times = {j: [] for j in range(len(bufs))}
+        ktimes = {(j, k): [] for j in range(len(bufs)) for k in knobs}
         for rnd in range(args.rounds + 1):
             for j, b in enumerate(bufs):
                 p0 = b.data_ptr()
                 vs = views(0, 0)
-                be.trace_events = []
-                for _ in range(args.launches):
-                    be.trace_chain(descs, vin, vs, n)
-                torch.cuda.synchronize()
-                ev, be.trace_events = be.trace_events, None
+                for k in knobs:
+                    for kv in k.split():
+                        os.environ[kv.split("=")[0]] = kv.split("=")[1]
+                    be.trace_events = []
+                    for _ in range(args.launches):
+                        be.trace_chain(descs, vin, vs, n)
+                    torch.cuda.synchronize()
+                    ev, be.trace_events = be.trace_events, None
+                    for kv in k.split():
+                        os.environ.pop(kv.split("=")[0], None)
+                    if rnd > 0:
+                        ktimes[(j, k)].append(float(np.mean([a.elapsed_time(c) for a, c in ev])))
                 if rnd > 0:
-                    times[j].append(float(np.mean([a.elapsed_time(c) for a, c in ev])))
+                    times[j].append(ktimes[(j, knobs[0])][-1])
         # is it the memory itself?  a plain fill and a plain copy of the same bytes into each buffer (first m * 8 rows)
         nbytes = m * 8 * base_pitch
         srcbuf = torch.empty(nbytes // 2, dtype=torch.uint8, device=be.device)
@@ -127,6 +138,8 @@ def main():
         for j, b in enumerate(bufs):
             t = np.array(times[j])
             tail = f"   bare pattern {bare[j]:.4f} ms -> launch / floor {np.median(t) / bare[j]:.3f}" if j in bare else ""
+            if len(knobs) > 1:
+                tail += "   " + "  ".join(f"[{k}] {np.median(ktimes[(j, k)]):.4f}" for k in knobs)
             print(f"buffer {j}: {b.numel() / 2**30:.3f} GiB at 0x{b.data_ptr():x}  median {np.median(t):.4f} ms  min {t.min():.4f}  max {t.max():.4f}"
                   f"   fill {fill[j]:.2f} TB/s  copy {copy[j]:.2f} TB/s{tail}")
         return
