@@ -157,7 +157,15 @@ class SceneProgram:
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < 0.08:
             self._time_launch(reps=4)
-        pool = [self.outputs] + [self._alloc_outputs() for _ in range(tries - 1)]
+        # Consecutive allocations lie in one region of physical memory more often than not (the levels come in runs of
+        # 10-50 GB, tools/pitch_probe.py): an untouched spacer in front of every further candidate spreads them out
+        spacer = max(0, min(8 << 30, int(0.5 * free // tries)) - nbytes)
+        pool, spacers = [self.outputs], []
+        for _ in range(tries - 1):
+            if spacer >= (256 << 20):
+                spacers.append(torch.empty(spacer, dtype=torch.uint8, device=self.be.device))
+            pool.append(self._alloc_outputs())
+        del spacers
         times = [float("inf")] * tries
         for order in (range(tries), reversed(range(tries))):       # two passes, the second in reverse order
             for j in order:
@@ -167,7 +175,8 @@ class SceneProgram:
         best = min(range(tries), key=times.__getitem__)
         self._bind(pool[best])
         self.update(element_lists)
-        self.placement = {"tries": tries, "launch_ms": [round(t, 4) for t in times], "chosen": best}
+        self.placement = {"tries": tries, "launch_ms": [round(t, 4) for t in times], "chosen": best,
+                          "spacer_bytes": spacer if spacer >= (256 << 20) else 0}
         del pool
         torch.cuda.empty_cache()        # hand the other candidates back to the driver
 
