@@ -116,33 +116,74 @@ def make_plots(OpticalChain, RayListAnalysed, Detector, SourceProperties, Detect
             mplots.DelayGraph(RayListAnalysed, Detector, SourceProperties["DeltaFT"], A["DrawAiryAndFourier"], kind)
 
 
+def analyse_chain_list(OpticalChainList, SourceProperties, DetectorOptions, AnalysisOptions, loop=True, announce=False):
+    """`run_ART` for every chain of a list (ARTmain.py:248-300 per chain, :304-342 the loop) with the device work of ALL
+    chains batched: one scene launch traces them (moc.trace_chain_list), then ONE device analysis (analysis.analyse:
+    four launches, blockIdx.y = chain, one copy back) yields every chain's transmitted energy, its detector placed on
+    the mean ray (ART/ModuleDetector.py:109-137) and the read-out moments from which the autofocus search
+    (ART/ModuleProcessing.py:317-460) or the result summary (ART/ModuleAnalysisAndPlots.py:81-129) of every chain
+    follows by arithmetic on the host.  Same numbers as calling run_ART chain by chain (which is this function with a
+    list of one).  Returns [(OpticalChain, Detector, ETransmission, SpotSizeSD, DurationSD)]."""
+    from . import analysis
+    chains = list(OpticalChainList)
+    k_an = DetectorOptions["ReflectionNumber"]
+    # ONE bundle of every history is analysed: trace it alone; any other entry of `output_rays` (a plot of another
+    # element, Ray.path tuples, an archive) is materialised bit-identically on first access (mp.LazyHistory)
+    outs = moc.trace_chain_list(chains, history="lazy", want=k_an)
+    analysed = [o[k_an] for o in outs]
+    # requests: every chain's analysed bundle (placement + moments) and every DISTINCT source (sum of intensities)
+    requests, src_slot = [], {}
+    if DetectorOptions["ManualDetector"] or DetectorOptions["DistanceDetector"] is not None:
+        for ch, B in zip(chains, analysed):
+            if DetectorOptions["ManualDetector"]:
+                requests.append((B, "manual", setup_detector(ch, DetectorOptions)))
+            else:
+                requests.append((B, "autoplace", DetectorOptions["DistanceDetector"]))
+    else:
+        setup_detector(chains[0], DetectorOptions, analysed[0])      # raises the reference's RuntimeError
+    for ch in chains:
+        key = ch.source_rays.content_key()
+        if key not in src_slot:
+            if ch.source_rays.intensity is None or analysed[0].intensity is None:
+                raise TypeError("rays carry no intensity")
+            src_slot[key] = len(requests)
+            requests.append((ch.source_rays, "sums", None))
+    res = analysis.analyse(requests)
+    results = []
+    for i, (ch, B) in enumerate(zip(chains, analysed)):
+        if announce:
+            print("Optical Chain " + str(i) + "/" + str(len(chains)) + " ", end="", flush=True)
+        ana = res[i]
+        ETransmission = 100 * float(ana.sum_w) / float(res[src_slot[ch.source_rays.content_key()]].sum_w)
+        if AnalysisOptions["verbose"]:
+            print(_NICELINE, flush=True)
+            if isinstance(ch.description, str) and len(ch.description) > 0:
+                print("***" + ch.description + "*** :")
+            if ch.loop_variable_name is not None and ch.loop_variable_value is not None:
+                print("For " + ch.loop_variable_name + " = " + "{:f}".format(ch.loop_variable_value) + ":\n")
+                print("The optical setup has an energy transmission of " + "{:.1f}".format(ETransmission) + "%.\n")
+        if DetectorOptions["ManualDetector"]:
+            Detector = requests[i][2]
+            Detector._analysis = ana
+        else:
+            Detector = mdet.Detector(np.asarray(ch.optical_elements[k_an].position, dtype=float))
+            Detector._adopt(ana)
+        if DetectorOptions["AutoDetectorDistance"]:
+            Detector, SpotSizeSD, DurationSD = optimize_detector(B, Detector, DetectorOptions, AnalysisOptions["verbose"],
+                                                                 maxRaystoConsider=None, IntensityWeighted=True)
+        else:
+            SpotSizeSD, DurationSD = mplots.GetResultSummary(Detector, B, AnalysisOptions["verbose"])
+        if AnalysisOptions["verbose"]:
+            print(_NICELINE + "\n")
+        if any(AnalysisOptions[k] for k in AnalysisOptions if k.startswith("plot_")):
+            make_plots(ch, B, Detector, SourceProperties, DetectorOptions, AnalysisOptions)
+        results.append((ch, Detector, ETransmission, SpotSizeSD, DurationSD))
+    return results
+
+
 def run_ART(OpticalChain, SourceProperties, DetectorOptions, AnalysisOptions, loop=False):
     """One chain: trace, transmission, detector, summary, plots (ARTmain.py:248-300)."""
-    # ONE bundle of the history is analysed: trace it alone; any other entry of `output_rays` (a plot of another
-    # element, Ray.path tuples, an archive) is materialised bit-identically on first access (mp.LazyHistory)
-    output_rays = OpticalChain.get_output_rays(history="lazy", want=DetectorOptions["ReflectionNumber"])
-    RayListAnalysed = output_rays[DetectorOptions["ReflectionNumber"]]
-    ETransmission = mplots.getETransmission(OpticalChain.source_rays, RayListAnalysed)
-    if AnalysisOptions["verbose"]:
-        print(_NICELINE, flush=True)
-        if isinstance(OpticalChain.description, str) and len(OpticalChain.description) > 0:
-            print("***" + OpticalChain.description + "*** :")
-        if OpticalChain.loop_variable_name is not None and OpticalChain.loop_variable_value is not None:
-            print("For " + OpticalChain.loop_variable_name + " = " + "{:f}".format(OpticalChain.loop_variable_value)
-                  + ":\n")
-            print("The optical setup has an energy transmission of " + "{:.1f}".format(ETransmission) + "%.\n")
-    Detector = setup_detector(OpticalChain, DetectorOptions, RayListAnalysed)
-    if DetectorOptions["AutoDetectorDistance"]:
-        Detector, SpotSizeSD, DurationSD = optimize_detector(RayListAnalysed, Detector, DetectorOptions,
-                                                             AnalysisOptions["verbose"], maxRaystoConsider=None,
-                                                             IntensityWeighted=True)
-    else:
-        SpotSizeSD, DurationSD = mplots.GetResultSummary(Detector, RayListAnalysed, AnalysisOptions["verbose"])
-    if AnalysisOptions["verbose"]:
-        print(_NICELINE + "\n")
-    if any(AnalysisOptions[k] for k in AnalysisOptions if k.startswith("plot_")):
-        make_plots(OpticalChain, RayListAnalysed, Detector, SourceProperties, DetectorOptions, AnalysisOptions)
-    return OpticalChain, Detector, ETransmission, SpotSizeSD, DurationSD
+    return analyse_chain_list([OpticalChain], SourceProperties, DetectorOptions, AnalysisOptions, loop)[0]
 
 
 def main(OpticalChainList, SourceProperties, DetectorOptions, AnalysisOptions, save_file_name=None):
@@ -159,13 +200,10 @@ def main(OpticalChainList, SourceProperties, DetectorOptions, AnalysisOptions, s
                          "should be.")
     else:
         loop = True
-    if loop and len(OpticalChainList) > 1:
-        # the whole loop list in ONE launch (chains that differ only in poses share a device-resident scene table);
-        # run_ART below then finds every chain's result cached
-        moc.trace_chain_list(OpticalChainList, history="lazy", want=DetectorOptions["ReflectionNumber"])
-    for i, chain in enumerate(OpticalChainList):
-        print("Optical Chain " + str(i) + "/" + str(len(OpticalChainList)) + " ", end="", flush=True)
-        results = run_ART(chain, SourceProperties, DetectorOptions, AnalysisOptions, loop)
+    # the whole loop list in ONE trace launch and ONE device analysis (chains that differ only in poses share a
+    # device-resident scene table; blockIdx.y = chain in both): analyse_chain_list
+    for results in analyse_chain_list(OpticalChainList, SourceProperties, DetectorOptions, AnalysisOptions, loop,
+                                      announce=True):
         for n, v in zip(names, results):
             kept_data[n].append(v)
     if AnalysisOptions["save_results"]:

@@ -13,7 +13,12 @@ def _sum_intensity(rays):
     if isinstance(rays, RayBundle):
         if rays.intensity is None:
             raise TypeError("rays carry no intensity")
-        return rays.backend.bundle_sums(rays.view(), rays.intensity, rays.n_slots)[7]
+        # the sum of a bundle's intensities is remembered with the bundle (per version): the chains of a loop list share
+        # their source, and ARTmain asks for its sum once per chain
+        hit = getattr(rays, "_sum_w", None)
+        if hit is None or hit[0] != rays.version:
+            hit = rays._sum_w = (rays.version, float(rays.backend.bundle_sums(rays.view(), rays.intensity, rays.n_slots)[7]))
+        return hit[1]
     return sum(r.intensity for r in rays)
 
 
@@ -22,26 +27,35 @@ def getETransmission(RayListIn, RayListOut) -> float:
     return 100 * _sum_intensity(RayListOut) / _sum_intensity(RayListIn)
 
 
+def _summary_from_analysis(Detector, ana, verbose=False):
+    """GetResultSummary's numbers from a device analysis of the bundle on `Detector` (analysis.BundleAnalysis)."""
+    from .ModuleDetector import LightSpeed
+    FocalSpotSizeSD, DurationSD = ana.spot_duration(0.0, False)
+    if verbose:
+        s = ana.bbox
+        FocalSpotSize = max(s[1] - s[0], s[3] - s[2])
+        delay_range = (s[5] - s[4]) / LightSpeed * 1e15
+        print("At the detector distance of " + "{:.3f}".format(Detector.get_distance()) + " mm we get:\n"
+              + "Spatial std : " + "{:.3f}".format(FocalSpotSizeSD * 1e3) + " μm and min-max: "
+              + "{:.3f}".format(FocalSpotSize * 1e3) + " μm\n"
+              + "Temporal std : " + "{:.3e}".format(DurationSD) + " fs and min-max : "
+              + "{:.3e}".format(delay_range) + " fs")
+    return FocalSpotSizeSD, DurationSD
+
+
 def GetResultSummary(Detector, RayListAnalysed, verbose=False):
     """Spot-size and duration standard deviations at the detector (ART/ModuleAnalysisAndPlots.py:81-129).
-    For a RayBundle everything is reduced on the device (moment sums + bounding box); no per-ray array is copied."""
+    For a RayBundle everything is reduced on the device (analysis.analyse: moment sums + bounding box in one pass, reused
+    if `Detector.autoplace` has just analysed this bundle); no per-ray array is copied."""
     if isinstance(RayListAnalysed, RayBundle):
-        from .ModuleDetector import LightSpeed
-        FocalSpotSizeSD, DurationSD = Detector._spot_duration_from_moments(Detector._scan_moments(RayListAnalysed),
-                                                                           0.0, False)
-        if verbose:
-            s = Detector.readout(RayListAnalysed, store=False)["stats"]
-            FocalSpotSize = max(s[3] - s[2], s[5] - s[4])
-            delay_range = (s[13] - s[12]) / LightSpeed * 1e15
-    else:
-        P = Detector.get_PointList2DCentre(RayListAnalysed)
-        FocalSpotSizeSD = mp.StandardDeviation(P)
-        DelayList = Detector.get_Delays(RayListAnalysed)
-        DurationSD = mp.StandardDeviation(DelayList)
-        if verbose:
-            FocalSpotSize = mgeo.DiameterPointList(P)
-            delay_range = max(DelayList) - min(DelayList)
+        return _summary_from_analysis(Detector, Detector._analysis_of(RayListAnalysed), verbose)
+    P = Detector.get_PointList2DCentre(RayListAnalysed)
+    FocalSpotSizeSD = mp.StandardDeviation(P)
+    DelayList = Detector.get_Delays(RayListAnalysed)
+    DurationSD = mp.StandardDeviation(DelayList)
     if verbose:
+        FocalSpotSize = mgeo.DiameterPointList(P)
+        delay_range = max(DelayList) - min(DelayList)
         print("At the detector distance of " + "{:.3f}".format(Detector.get_distance()) + " mm we get:\n"
               + "Spatial std : " + "{:.3f}".format(FocalSpotSizeSD * 1e3) + " μm and min-max: "
               + "{:.3f}".format(FocalSpotSize * 1e3) + " μm\n"

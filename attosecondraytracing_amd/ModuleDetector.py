@@ -55,15 +55,38 @@ class Detector:
 
     # ------------------------------------------------------------------ placement
     def copy_detector(self):
-        return Detector(self.refpoint, self.centre, self.normal)
+        d = Detector(self.refpoint, self.centre, self.normal)
+        if self._normal is not None:
+            d._normal = self._normal      # (bit for bit: the setter's renormalisation may move the last bit)
+        d._analysis = getattr(self, "_analysis", None)
+        return d
 
     def autoplace(self, RayList, DistanceDetector: float):
-        """Normal to the central ray of RayList, DistanceDetector away from its origin (ART/ModuleDetector.py:109-137)."""
-        central = mp.FindCentralRay(RayList)
-        normal = -central.vector
-        self.normal = normal
-        self.centre = central.point - normal * DistanceDetector
-        self.refpoint = central.point
+        """Normal to the central ray of RayList, DistanceDetector away from its origin (ART/ModuleDetector.py:109-137).
+        Sums, placement and the read-out moments on the new detector come from ONE device analysis of the bundle
+        (analysis.analyse); it stays attached, so that an autofocus search or a result summary that follows on the same
+        bundle and detector (ARTmain.run_ART) does not touch the bundle again."""
+        from . import analysis
+        self._adopt(analysis.analyse([(RayList, "autoplace", DistanceDetector)])[0])
+
+    def _adopt(self, ana):
+        """Take the pose a device analysis placed (bit for bit: the setters' normalisation already happened there)."""
+        if not ana.count > 0:
+            raise TypeError("Detector Normal must be a 3D-vector of norm >0, given as numpy.ndarray of shape (3,).")
+        self._normal, self._centre, self._refpoint = ana.normal, ana.centre, ana.refpoint
+        self._analysis = ana
+
+    def _analysis_of(self, RayList):
+        """The device analysis of `RayList` on THIS detector pose: the attached one if it still applies, else a new one."""
+        from . import analysis
+        self._iscomplete()
+        ana = getattr(self, "_analysis", None)
+        if ana is not None and isinstance(RayList, RayBundle) and ana.matches(RayList, (self._centre.tobytes(), self._normal.tobytes())):
+            return ana
+        ana = analysis.analyse([(RayList, "manual", self)])[0]
+        if isinstance(RayList, RayBundle):
+            self._analysis = ana
+        return ana
 
     def get_distance(self):
         """ART/ModuleDetector.py:139-145."""

@@ -388,25 +388,19 @@ def RayTracingCalculationMany(source_rays_list, optical_elements_list, IgnoreDef
 
 
 # ------------------------------------------------------------------------------------------- placement
-def _singleOEPlacement(SourceProperties, OpticsList, DistanceList, IncidenceAngleList, IncidencePlaneAngleList,
-                       Description):
-    """Place and align the optics of one chain along the central ray (ART/ModuleProcessing.py:32-130)."""
-    from . import ModuleOpticalChain as moc
+def _placement_source(SourceProperties, FirstOptic):
+    """The source bundle `_singleOEPlacement` builds (ART/ModuleProcessing.py:32-130, its first half)."""
     from . import ModuleSource as msource
 
     Divergence = SourceProperties["Divergence"]
     SourceSize = SourceProperties["SourceSize"]
     RayNumber = SourceProperties["NumberRays"]
     Wavelength = SourceProperties["Wavelength"]
-
-    plane_angles = [np.deg2rad(a % 360) for a in IncidencePlaneAngleList]
-    inc_angles = [np.deg2rad(a % 360) for a in IncidenceAngleList]
-
     SourcePosition = np.array([0, 0, 0])
     SourceDirection = np.array([1, 0, 0])
     if Divergence == 0:
         if SourceSize == 0:
-            S0 = OpticsList[0].support
+            S0 = FirstOptic.support
             radius = 0.5 * min(S0.dimX, S0.dimY) if hasattr(S0, "dimX") else S0.radius
         else:
             radius = SourceSize / 2
@@ -418,40 +412,101 @@ def _singleOEPlacement(SourceProperties, OpticsList, DistanceList, IncidenceAngl
     else:
         SourceRayList = msource.ExtendedSource(SourcePosition, SourceDirection, SourceSize, Divergence, RayNumber,
                                                Wavelength=Wavelength)
-    SourceRayList = msource.ApplyGaussianIntensityToRayList(SourceRayList, 1 / np.e ** 2)
+    return msource.ApplyGaussianIntensityToRayList(SourceRayList, 1 / np.e ** 2)
 
-    # one alignment ray along the bundle axis, traced through the growing chain to find the next direction
-    guide = [mray.Ray(SourcePosition.astype(float), SourceDirection.astype(float))]
-    elements = []
-    guide_elements = []
-    centre = SourcePosition
-    central = SourceDirection
-    rot_axis = np.array([0, 1, 0])  # normal of the incidence plane, initially the x-z plane
+
+def _placeChains(SourceProperties, OpticsList, variants, Description):
+    """Place and align the optics of SEVERAL chains along their central rays (ART/ModuleProcessing.py:32-130 for one
+    chain; :203-239 calls it once per value of a loop list).  `variants`: one (DistanceList, IncidenceAngleList,
+    IncidencePlaneAngleList) per chain, all over the same OpticsList.
+
+    The chains advance in lockstep, optic by optic: every chain's alignment ray lives in one small device array and ONE
+    launch (art_trace_guides: guide j through element j) + ONE read-back moves them all across the optic just placed --
+    instead of one trace of the growing guide chain, with its own read-back, per chain and mirror.  The rays' states
+    are what those traces produce (the same per-ray code, element after element).  The source bundle is a pure function
+    of SourceProperties and the first optic's support, hence the same for every chain of the list: it is generated
+    ONCE, and every chain holds an alias of it (a bundle object of its own over the same immutable device arrays:
+    bundle.RayBundle.alias)."""
+    from . import ModuleOpticalChain as moc
+
+    c = len(variants)
+    Source = _placement_source(SourceProperties, OpticsList[0])
+    be = Source.backend
+    plane_angles = [[np.deg2rad(a % 360) for a in v[2]] for v in variants]
+    inc_angles = [[np.deg2rad(a % 360) for a in v[1]] for v in variants]
+    centre = [np.array([0, 0, 0]) for _ in range(c)]
+    central = [np.array([1, 0, 0]) for _ in range(c)]
+    rot_axis = [np.array([0, 1, 0]) for _ in range(c)]   # normal of the incidence plane, initially the x-z plane
+    elements = [[] for _ in range(c)]
+    # one alignment ray per chain along the bundle axis: origin, direction, path, incidence (NaN: none yet)
+    guides = be.from_numpy(np.tile(np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, np.nan]), (c, 1)))
+    guide_alive = be.from_numpy(np.ones(c, dtype=np.uint8))
+
+    def advance(through):
+        """Every chain's guide ray through its element `through[j]`; chains whose element the guide kernel refuses
+        (Zernike tables in the recurrence layout) go through the element kernel, one ray at a time."""
+        descs = [element_descriptor(oe, True, be)[0] for oe in through]
+        if any(d.nonfinite for d in descs):
+            # a mirror with NaN / inf parameters: the reference's np.roots raises for the first ray that reaches it
+            # (see RayTracingCalculation), and the guide ray always does
+            raise np.linalg.LinAlgError("Array must not contain infs or NaNs")
+        slow = [j for j, d in enumerate(descs) if d.flags & _abi.ART_FLAG_ZERN_RECURRENCE]
+        if not slow:
+            be.trace_guides(descs, guides, guide_alive)
+            return
+        host, al = guides.cpu().numpy(), guide_alive.cpu().numpy()
+        for j in range(c):
+            if not al[j]:
+                continue
+            one = RayBundle.from_arrays(host[j, 0:3], host[j, 3:6], path0=host[j, 6], backend=be)
+            out = RayTracingCalculation(one, [through[j]])[-1]
+            if len(out) == 0:
+                al[j] = 0
+            else:
+                host[j] = out.data[:, 0].cpu().numpy()
+        guides.copy_(be.from_numpy(host))
+        guide_alive.copy_(be.from_numpy(al))
 
     for k, Optic in enumerate(OpticsList):
-        if Optic.type in ("SphericalCX Mirror", "CylindricalCX Mirror"):
-            inc_angles[k] = np.pi - inc_angles[k]  # convex: reflect off the "back side"
-        centre = central * DistanceList[k] + centre
-        if abs(plane_angles[k] - np.pi) < 1e-10:
-            rot_axis = -rot_axis
-        else:
-            rot_axis = mgeo.RotationAroundAxis(central, -plane_angles[k], rot_axis)
-        normal = mgeo.RotationAroundAxis(rot_axis, -np.pi / 2 + inc_angles[k], np.cross(central, rot_axis))
-        major = np.cross(rot_axis, normal)
-        element = moe.OpticalElement(Optic, centre, normal, major)
-        elements.append(element)
-        if "Mirror" in Optic.type:
-            guide_elements.append(element)
-            out = RayTracingCalculation(guide, guide_elements)
-            central = out[-1][0].vector
-        elif Optic.type == "Mask":
-            # the guide ray must always pass: a fully open stand-in mask (only in the guide chain)
-            open_mask = mmask.Mask(msupp.SupportRoundHole(Radius=100, RadiusHole=100, CenterHoleX=0, CenterHoleY=0))
-            guide_elements.append(moe.OpticalElement(open_mask, centre, normal, major))
-        else:
+        if not ("Mirror" in Optic.type or Optic.type == "Mask"):
             raise NameError("I don`t recognize the type of optical element " + Optic.type + ".")
+        through = []
+        for j in range(c):
+            if Optic.type in ("SphericalCX Mirror", "CylindricalCX Mirror"):
+                inc_angles[j][k] = np.pi - inc_angles[j][k]  # convex: reflect off the "back side"
+            centre[j] = central[j] * variants[j][0][k] + centre[j]
+            if abs(plane_angles[j][k] - np.pi) < 1e-10:
+                rot_axis[j] = -rot_axis[j]
+            else:
+                rot_axis[j] = mgeo.RotationAroundAxis(central[j], -plane_angles[j][k], rot_axis[j])
+            normal = mgeo.RotationAroundAxis(rot_axis[j], -np.pi / 2 + inc_angles[j][k], np.cross(central[j], rot_axis[j]))
+            major = np.cross(rot_axis[j], normal)
+            element = moe.OpticalElement(Optic, centre[j], normal, major)
+            elements[j].append(element)
+            if Optic.type == "Mask":
+                # the guide ray must always pass: a fully open stand-in mask (only for the guide)
+                open_mask = mmask.Mask(msupp.SupportRoundHole(Radius=100, RadiusHole=100, CenterHoleX=0, CenterHoleY=0))
+                through.append(moe.OpticalElement(open_mask, centre[j], normal, major))
+            else:
+                through.append(element)
+        if k == len(OpticsList) - 1 and Optic.type == "Mask":
+            break                              # nothing is placed behind it
+        advance(through)
+        if "Mirror" in Optic.type:
+            host, al = guides.cpu().numpy(), guide_alive.cpu().numpy()      # the one read-back of this optic
+            for j in range(c):
+                if not al[j]:
+                    raise IndexError("list index out of range")     # the reference indexes an empty survivor list here
+                v = host[j, 3:6]
+                central[j] = v / np.linalg.norm(v)                  # (the Ray.vector setter, ModuleOpticalRay.py:85-90)
+    return [moc.OpticalChain(Source, els, Description, _alias_source=True) for els in elements]
 
-    return moc.OpticalChain(SourceRayList, elements, Description)
+
+def _singleOEPlacement(SourceProperties, OpticsList, DistanceList, IncidenceAngleList, IncidencePlaneAngleList,
+                       Description):
+    """Place and align the optics of one chain along the central ray (ART/ModuleProcessing.py:32-130)."""
+    return _placeChains(SourceProperties, OpticsList, [(DistanceList, IncidenceAngleList, IncidencePlaneAngleList)],
+                        Description)[0]
 
 
 def _which_indeces(lst):
@@ -483,14 +538,14 @@ def OEPlacement(SourceProperties, OpticsList, DistanceList, IncidenceAngleList, 
     name = OpticsList[i].type + "_idx_" + str(i) + labels[which]
     loop_list = lists[which]
     values = copy.deepcopy(loop_list[i])
-    chains = []
+    variants = []
     for x in values:
         loop_list[i] = x
-        ch = _singleOEPlacement(SourceProperties, OpticsList, DistanceList, IncidenceAngleList,
-                                IncidencePlaneAngleList, Description)
+        variants.append((list(DistanceList), list(IncidenceAngleList), list(IncidencePlaneAngleList)))
+    chains = _placeChains(SourceProperties, OpticsList, variants, Description)
+    for ch, x in zip(chains, values):
         ch.loop_variable_name = name
         ch.loop_variable_value = x
-        chains.append(ch)
     return chains
 
 
@@ -541,65 +596,91 @@ def ReturnAiryRadius(Wavelength: float, NumericalAperture: float) -> float:
 
 
 # ------------------------------------------------------------------------------------------- autofocus
-def _scan(detector, Amplitude, Step, RayList, OptFor, IntensityWeighted):
-    """One pass of the detector scan (ART/ModuleProcessing.py:317-366).  The read-out of every ray is linear in the
-    detector shift, so the spot size and duration at all scan positions follow from one set of moment sums computed
-    on the device (Detector._scan_moments: two passes over the bundle, all rays) instead of one pass per position."""
+def _scan(ana, detector0, RayList, s_centre, Amplitude, Step, OptFor, IntensityWeighted):
+    """One pass of the detector scan (ART/ModuleProcessing.py:317-366) about the shift `s_centre` of `detector0` (shifts
+    as in Detector.shiftByDistance): positions s_centre - Amplitude + i Step, i < int(2 Amplitude / Step).  The read-out
+    of every ray is linear in the shift, so spot size and duration at all positions follow from the ONE set of moment
+    sums of the device analysis `ana` (analysis.BundleAnalysis, taken at detector0) instead of one pass over the bundle
+    per position.  Returns (best shift, spot size there, duration there)."""
     if OptFor not in ("intensity", "duration", "spotsize"):
         # FindOptimalDistance lets "size" through, but the reference's scan only knows "spotsize": its fitness is
         # then never assigned (ART/ModuleProcessing.py:342-348)
         raise UnboundLocalError("local variable 'Fitness' referenced before assignment")
-    detector.shiftByDistance(-Amplitude)
+    start = s_centre - Amplitude
     n = int(2 * Amplitude / Step)
-    mom = detector._scan_moments(RayList, span=(n - 1) * Step)
+    shifts = start + np.arange(n) * Step
     # A scan that carries the detector through the last optic (Amplitude clipped to the detector distance: the scan
     # starts AT the optic) meets rays whose hit lies behind their origin; the reference's path |I - A| has a kink
     # there and is no longer linear in the shift.  Those scans are evaluated position by position (still on the
     # device, still all rays), exactly as the reference's loop does.
-    exact = mom["kinked"] and OptFor in ("intensity", "duration")
-    sizes, durations, fitness = [], [], []
-    for i in range(n):
-        if exact:
-            here = detector.copy_detector()
-            here.shiftByDistance(i * Step)
-            spot, dur = here._spot_duration_from_moments(here._scan_moments(RayList), 0.0, IntensityWeighted)
-        else:
-            spot, dur = detector._spot_duration_from_moments(mom, i * Step, IntensityWeighted)
-        sizes.append(spot if OptFor in ("intensity", "spotsize") else np.nan)
-        durations.append(dur if OptFor in ("intensity", "duration") else np.nan)
-        fitness.append(spot ** 2 * dur if OptFor == "intensity" else (dur if OptFor == "duration" else spot))
+    exact = OptFor in ("intensity", "duration") and n > 0 and not ana.linear_over(shifts[0], shifts[-1])
+    if exact:
+        sizes, durations = np.empty(n), np.empty(n)
+        for i in range(n):
+            here = detector0.copy_detector()
+            here.shiftByDistance(float(shifts[i]))
+            sizes[i], durations[i] = here._spot_duration_from_moments(here._scan_moments(RayList), 0.0, IntensityWeighted)
+    else:
+        sizes, durations = _spot_duration_at(ana.moments, shifts, IntensityWeighted)
+    fitness = sizes ** 2 * durations if OptFor == "intensity" else (durations if OptFor == "duration" else sizes)
     ind = int(np.argmin(fitness))
-    detector.shiftByDistance(ind * Step)
-    return detector, sizes[ind], durations[ind]
+    return (float(shifts[ind]), float(sizes[ind]) if OptFor in ("intensity", "spotsize") else np.nan,
+            float(durations[ind]) if OptFor in ("intensity", "duration") else np.nan)
 
 
-def FindOptimalDistance(Detector, RayList, OptFor="intensity", Amplitude: float = None, Precision: int = 3,
-                        IntensityWeighted=False, verbose=False):
-    """Detector distance minimising spot size, duration or spot^2*duration (ART/ModuleProcessing.py:369-460).
-    Note: like the reference, the accepted names are 'intensity', 'size', 'duration' although the scan itself
-    understands 'spotsize' (reference quirk, ModuleProcessing.py:424 vs :328)."""
+def _spot_duration_at(m, shifts, weighted):
+    """analysis.spot_duration_from_moments for an array of shifts (the same operations in the same order)."""
+    from .analysis import LightSpeed
+    m = m[16:] if weighted else m[:16]
+    var = []
+    for k in range(3):
+        q, sq, qq, qs, ss = m[1 + 5 * k: 6 + 5 * k]
+        mean = (q + shifts * sq) / m[0]
+        var.append(np.maximum((qq + 2 * shifts * qs + shifts * shifts * ss) / m[0] - mean * mean, 0.0))
+    return np.sqrt(var[0] + var[1]), np.sqrt(var[2]) / LightSpeed * 1e15
+
+
+def _optimise_from_analysis(Detector, RayList, ana, OptFor, Amplitude, Precision, IntensityWeighted, verbose):
+    """The search of FindOptimalDistance on a device analysis of RayList taken at `Detector` (ana): arithmetic on 64
+    doubles, no pass over the bundle (unless a scan crosses the last optic, see _scan)."""
     if OptFor not in ["intensity", "size", "duration"]:
         raise NameError("I don`t recognize what you want to optimize the detector distance for. OptFor must be "
                         "either 'intensity', 'size' or 'duration'.")
     FirstDistance = Detector.get_distance()
-    SizeSpot = 2 * Detector._spot_duration_from_moments(Detector._scan_moments(RayList), 0.0, False)[0]
-    NumericalAperture = ReturnNumericalAperture(RayList, 1)
+    SizeSpot = 2 * ana.spot_duration(0.0, False)[0]
+    NumericalAperture = float(np.sin(ana.max_angle) * 1)
     if Amplitude is None:
         Amplitude = min(4 * np.ceil(SizeSpot / np.tan(np.arcsin(NumericalAperture))), FirstDistance)
     Step = Amplitude / 10
     if verbose:
         print(f"Searching optimal detector position for *{OptFor}* within [{FirstDistance-Amplitude:.3f}, "
               f"{FirstDistance+Amplitude:.3f}] mm...", end="", flush=True)
-    moving = Detector.copy_detector()
+    shift = 0.0
     for k in range(Precision + 1):
-        moving, OptSpotSize, OptDuration = _scan(moving, Amplitude * 0.1 ** k, Step * 0.1 ** k, RayList, OptFor,
-                                                 IntensityWeighted)
+        shift, OptSpotSize, OptDuration = _scan(ana, Detector, RayList, shift, Amplitude * 0.1 ** k, Step * 0.1 ** k,
+                                                OptFor, IntensityWeighted)
+    moving = Detector.copy_detector()
+    moving.shiftByDistance(shift)
     if not FirstDistance - Amplitude + 10 ** -Precision < moving.get_distance() < FirstDistance + Amplitude - 10 ** -Precision:
         print("There`s no minimum-size/duration focus in the searched range.")
     print("\r\033[K", end="", flush=True)
     if OptFor == "duration":
         OptSpotSize = np.nan
     return moving, OptSpotSize, OptDuration
+
+
+def FindOptimalDistance(Detector, RayList, OptFor="intensity", Amplitude: float = None, Precision: int = 3,
+                        IntensityWeighted=False, verbose=False):
+    """Detector distance minimising spot size, duration or spot^2*duration (ART/ModuleProcessing.py:369-460).
+    Note: like the reference, the accepted names are 'intensity', 'size', 'duration' although the scan itself
+    understands 'spotsize' (reference quirk, ModuleProcessing.py:424 vs :328).
+    ONE device analysis of the bundle on `Detector` (the one `Detector.autoplace` left attached, if it still applies)
+    serves the whole search: analysis.py."""
+    if OptFor not in ["intensity", "size", "duration"]:
+        raise NameError("I don`t recognize what you want to optimize the detector distance for. OptFor must be "
+                        "either 'intensity', 'size' or 'duration'.")
+    return _optimise_from_analysis(Detector, RayList, Detector._analysis_of(RayList), OptFor, Amplitude, Precision,
+                                   IntensityWeighted, verbose)
 
 
 # ------------------------------------------------------------------------------------------- misc

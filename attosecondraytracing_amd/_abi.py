@@ -1,7 +1,7 @@
 """ctypes mirror of include/art_hip.h (structs, enums, prototypes).  Keep in sync with ART_ABI_VERSION."""
 import ctypes as C
 
-ART_ABI_VERSION = 9
+ART_ABI_VERSION = 10
 
 ART_OK = 0
 ART_ERR_BAD_ARG = -1
@@ -80,6 +80,24 @@ class ArtChainReadout(C.Structure):
     ]
 
 
+ART_GUIDES_MAX = 8
+ART_ANALYSIS_DOUBLES = 64
+ART_JOB_AUTOPLACE, ART_JOB_MANUAL, ART_JOB_SUMS = range(3)
+
+
+class ArtAnalysisJob(C.Structure):
+    _fields_ = [
+        ("b", ArtBundleView),
+        ("w", C.c_void_p),
+        ("distance", C.c_double),
+        ("mode", C.c_int32),
+        ("reserved", C.c_int32),
+        ("centre", C.c_double * 3),
+        ("normal", C.c_double * 3),
+        ("refpoint", C.c_double * 3),
+    ]
+
+
 # name -> (restype, argtypes); the loader checks every symbol exists (tests/test_abi.py does too)
 PROTOTYPES = {
     "art_abi_version": (C.c_int, []),
@@ -128,6 +146,10 @@ PROTOTYPES = {
     "art_survivor_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
     "art_pack_survivors": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 4 + [C.c_int64, C.c_int64, C.c_void_p,
                                                                                     C.c_void_p, C.c_int64, C.c_void_p]),
+    "art_trace_guides": (C.c_int, [C.POINTER(ArtElementDesc), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "art_analysis_scratch_doubles": (C.c_int64, [C.c_int32]),
+    "art_analyse_bundles": (C.c_int, [C.c_void_p, C.POINTER(ArtAnalysisJob), C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
     "art_make_extended_source": (C.c_int, [C.c_double, C.c_double, C.c_int64, C.c_int64, c_double_p, c_double_p,
                                            C.c_int64, C.c_int64, C.POINTER(ArtBundleView), C.c_void_p]),
 }

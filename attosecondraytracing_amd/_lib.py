@@ -47,6 +47,7 @@ class HipBackend:
         self.device = torch.device("cuda", torch.cuda.current_device())
         self._scratch = {}
         self._scene_pool, self._scene_uploads = {}, {}
+        self._job_pool = {}
         # bookkeeping for measurements: launches of the fused kernels over at least `count_from` slots, in issue order
         # (bench.py reports which of them lie inside its timed region, so that a kernel trace can be cut to it)
         self.count_from, self.counted_launches = None, 0
@@ -338,6 +339,43 @@ class HipBackend:
         self.check(self.fn["art_pack_survivors"](ptr(alive), n, ptr(X), ptr(Y), ptr(opl), ptr(number), int(first),
                                                  int(step), sc.data_ptr(), send.data_ptr(), int(send.numel()),
                                                  self.stream_ptr()), "art_pack_survivors")
+
+    def trace_guides(self, descs, rays, alive):
+        """Advance guide ray j (row j of the DEVICE tensor rays[count, 8], in place) through descs[j]; alive[count] uint8
+        (art_trace_guides, 8 rays per launch)."""
+        count = len(descs)
+        sp = self.stream_ptr()
+        for k0 in range(0, count, _abi.ART_GUIDES_MAX):
+            m = min(_abi.ART_GUIDES_MAX, count - k0)
+            darr = (_abi.ArtElementDesc * m)(*descs[k0:k0 + m])
+            self.check(self.fn["art_trace_guides"](darr, m, rays.data_ptr() + 64 * k0, alive.data_ptr() + k0, sp),
+                       "art_trace_guides")
+
+    def analyse_bundles(self, jobs, n):
+        """art_analyse_bundles for a list of ArtAnalysisJob (host structs): uploads the job table, enqueues the four
+        launches and returns the DEVICE tensor out[len(jobs), 64] -- nothing is read back here."""
+        c = len(jobs)
+        arr = (_abi.ArtAnalysisJob * c)(*jobs)
+        nb = C.sizeof(arr)
+        # pinned staging + device table from a per-size pool (pinning host memory costs milliseconds): the pinned image is
+        # rewritten only after its previous upload has completed, the device table is read by launches enqueued before
+        # the next upload on the same stream
+        pair = self._job_pool.get(nb)
+        if pair is None:
+            pair = self._job_pool[nb] = [torch.empty(nb, dtype=torch.uint8, pin_memory=True),
+                                         torch.empty(nb, dtype=torch.uint8, device=self.device), None]
+        host, dev, ev = pair
+        if ev is not None:
+            ev.synchronize()
+        C.memmove(host.data_ptr(), C.addressof(arr), nb)
+        dev.copy_(host, non_blocking=True)
+        pair[2] = torch.cuda.Event()
+        pair[2].record()
+        out = torch.empty((c, _abi.ART_ANALYSIS_DOUBLES), dtype=torch.float64, device=self.device)
+        scratch = self.scratch("analysis", self.fn["art_analysis_scratch_doubles"](c), torch.float64)
+        self.check(self.fn["art_analyse_bundles"](dev.data_ptr(), arr, c, int(n), scratch.data_ptr(), out.data_ptr(),
+                                                  self.stream_ptr()), "art_analyse_bundles")
+        return out
 
     def make_extended_source(self, radius, divergence, n_points, per, rot, S, first, n, view):
         r = (C.c_double * 9)(*[float(v) for v in np.asarray(rot).reshape(9)])

@@ -353,6 +353,19 @@ class RayBundle:
         out.tag_content(self.content_key())        # a copy is bit-identical to its original
         return out
 
+    def alias(self):
+        """A new bundle OBJECT over the same device arrays (attributes such as `intensity` can be replaced per object;
+        the arrays themselves are shared and must be treated as immutable -- `copy()` gives private storage).  What the
+        chains of an OEPlacement loop list hold of their common source."""
+        out = RayBundle(self.data, self.alive, self.number, self.intensity, self.wavelength, self._parent, self.backend)
+        self._share_parent(out)
+        out.path_head = self.path_head
+        out.tag_content(self.content_key())
+        hit = getattr(self, "_sum_w", None)
+        if hit is not None and hit[0] == self.version:
+            out._sum_w = (out.version, hit[1])
+        return out
+
     def __deepcopy__(self, memo):
         return self.copy()
 

@@ -912,6 +912,89 @@ ART_HD void detector_ray_scan(const ArtDetectorDesc& d, const Ray& r, double spa
   crosses = t0 * fma(span, dt, t0) < 0.0;
 }
 
+// The same with the shift at which the hit point passes through the ray's origin instead of a yes/no for a given span:
+// t(s) = t0 + s * dt vanishes at s_kink = -t0 / dt (no such shift for a ray parallel to the normal's plane: +inf).
+ART_HD void detector_ray_scan_kink(const ArtDetectorDesc& d, const Ray& r, double& X, double& Y, double& opl, double& sx,
+                                   double& sy, double& so, double& s_kink) {
+  double Ix, Iy, Iz;
+  detector_ray(d, r, Ix, Iy, Iz, X, Y, opl);
+  const double den = dot3(r.dx, r.dy, r.dz, d.normal[0], d.normal[1], d.normal[2]);
+  const double nn = dot3(d.normal[0], d.normal[1], d.normal[2], d.normal[0], d.normal[1], d.normal[2]);
+  const double dt = -nn / den;
+  double rx, ry, rz;
+  mat3_apply(d.rot, fma(dt, r.dx, d.normal[0]), fma(dt, r.dy, d.normal[1]), fma(dt, r.dz, d.normal[2]), rx, ry, rz);
+  sx = rx; sy = ry;
+  const double num = dot3(d.normal[0], d.normal[1], d.normal[2], d.centre[0] - r.ox, d.centre[1] - r.oy,
+                          d.centre[2] - r.oz);
+  const double t0 = num / den;
+  const double sgn = (t0 >= 0.0) ? 1.0 : -1.0;
+  so = sgn * dt * sqrt(dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz));
+  s_kink = (dt != 0.0) ? -t0 / dt : INFINITY;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Detector placement on the device (art_analyse_bundles; ART/ModuleDetector.py:109-137, ART/ModuleGeometry.py:321-343).
+// 3x3 map of RotationPoint(., a, ez) for a UNIT vector a, with the reference's special cases: identity for an angle
+// below 1e-10, the point inversion -I within 1e-10 of pi; otherwise the rotation by the Kahan angle about a x ez, written
+// as the Rodrigues sum with half-angle terms that the host shell uses (ModuleGeometry.RotationAroundAxis).
+ART_HD void rotation_to_ez(const double* a, double* M) {
+  const double ang = kahan_angle_unit(a[0], a[1], a[2], 0.0, 0.0, 1.0, a[2]);
+  const bool same = fabs(ang) < 1e-10, opposite = fabs(ang - 3.14159265358979323846) < 1e-10;
+  if (same || opposite) {
+    const double d = same ? 1.0 : -1.0;
+    M[0] = d; M[1] = 0.0; M[2] = 0.0; M[3] = 0.0; M[4] = d; M[5] = 0.0; M[6] = 0.0; M[7] = 0.0; M[8] = d;
+    return;
+  }
+  // axis = a x ez = (a1, -a0, 0), normalised; q = sin(ang/2) axis, w = cos(ang/2)
+  const double nx = a[1], ny = -a[0];
+  const double nrm = sqrt(fma(nx, nx, ny * ny));
+  const double sh = sin(0.5 * ang), w = cos(0.5 * ang);
+  const double qx = sh * (nx / nrm), qy = sh * (ny / nrm), qz = 0.0;
+  for (int j = 0; j < 3; ++j) {      // column j = image of the basis vector e_j: v + 2 (w (q x v) + q x (q x v))
+    const double vx = (j == 0) ? 1.0 : 0.0, vy = (j == 1) ? 1.0 : 0.0, vz = (j == 2) ? 1.0 : 0.0;
+    const double cx = qy * vz - qz * vy, cy = qz * vx - qx * vz, cz = qx * vy - qy * vx;
+    const double ex = qy * cz - qz * cy, ey = qz * cx - qx * cz, ez = qx * cy - qy * cx;
+    M[0 + j] = vx + 2.0 * (w * cx + ex);
+    M[3 + j] = vy + 2.0 * (w * cy + ey);
+    M[6 + j] = vz + 2.0 * (w * cz + ez);
+  }
+}
+
+// sums9 = count, sum point (3), sum vector (3), sum w, sum path.  Fills the detector (centre, normal, rot), its
+// reference point, the mean direction (unit) and the provisional path centre co.  mode: ArtJobMode (0 autoplace, 1 manual).
+// The sequence of normalisations is the reference's: FindCentralRay's mean vector goes through the Ray.vector setter
+// (ART/ModuleOpticalRay.py:85-90), its negative through the Detector.normal setter (ART/ModuleDetector.py:57-66).
+ART_HD void analysis_place(const double* sums9, int mode, double distance, const double* centre_in,
+                           const double* normal_in, const double* refpoint_in, ArtDetectorDesc& d, double* refpoint,
+                           double* axis, double& co) {
+  const double cnt = sums9[0];
+  const double px = sums9[1] / cnt, py = sums9[2] / cnt, pz = sums9[3] / cnt;
+  double vx = sums9[4] / cnt, vy = sums9[5] / cnt, vz = sums9[6] / cnt;
+  const double vl = sqrt(dot3(vx, vy, vz, vx, vy, vz));
+  vx /= vl; vy /= vl; vz /= vl;
+  axis[0] = vx; axis[1] = vy; axis[2] = vz;
+  if (mode == 1) {
+    for (int k = 0; k < 3; ++k) {
+      d.normal[k] = normal_in[k];       // unit by contract (ArtDetectorDesc everywhere): used bit for bit
+      d.centre[k] = centre_in[k];
+      refpoint[k] = refpoint_in[k];
+    }
+  } else {
+    const double nx = -vx, ny = -vy, nz = -vz;
+    const double nl = sqrt(dot3(nx, ny, nz, nx, ny, nz));
+    d.normal[0] = nx / nl; d.normal[1] = ny / nl; d.normal[2] = nz / nl;
+    d.centre[0] = px - d.normal[0] * distance;
+    d.centre[1] = py - d.normal[1] * distance;
+    d.centre[2] = pz - d.normal[2] * distance;
+    refpoint[0] = px; refpoint[1] = py; refpoint[2] = pz;
+  }
+  rotation_to_ez(d.normal, d.rot);
+  // the mean ray's distance to the detector plane: within a fraction of a millimetre of the mean of |I - A| over the rays
+  const double num = dot3(d.normal[0], d.normal[1], d.normal[2], d.centre[0] - px, d.centre[1] - py, d.centre[2] - pz);
+  const double den = dot3(vx, vy, vz, d.normal[0], d.normal[1], d.normal[2]);
+  co = sums9[8] / cnt + fabs(num / den);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Sources (ART/ModuleSource.py:23-81, :135-169; SpiralVogel ART/ModuleGeometry.py:61-76) for ray index k
 ART_HD void vogel_point(int64_t k, int64_t n_total, double radius, double& x, double& y) {

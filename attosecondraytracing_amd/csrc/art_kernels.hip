@@ -314,6 +314,28 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NS], const int 
   }
 }
 
+// The same with the operator of slot k given by a function (computed, not looked up: a run-time indexed local array of
+// operators lives in scratch memory).
+template <int NS, typename F>
+__device__ __forceinline__ void block_reduce_store_f(double (&acc)[NS], F op_of, double* dst) {
+  __shared__ double s[kBlock / 64][NS];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const double v = wave_reduce(acc[k], op_of(k));
+    if (lane == 0) s[w][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NS) {
+    const int k = threadIdx.x;
+    const int op = op_of(k);
+    double v = s[0][k];
+    for (int j = 1; j < kBlock / 64; ++j)
+      v = (op == RSUM) ? v + s[j][k] : (op == RMIN ? fmin(v, s[j][k]) : fmax(v, s[j][k]));
+    dst[k] = v;
+  }
+}
+
 // Final fold of per-block partials laid out [block][ns]: launched with ns blocks, block k folds slot k in a fixed
 // order (thread t takes partials t, t+256, ...; then the shuffle tree) — deterministic, and ns blocks work in
 // parallel instead of one block walking the whole table.
@@ -1047,10 +1069,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_moments_partial(const ArtDetect
       acc[16 + o + 4] = fma(ws, sq[k], acc[16 + o + 4]);
     }
   }
-  int ops[kScanSlots];
-#pragma unroll
-  for (int k = 0; k < kScanSlots; ++k) ops[k] = RSUM;
-  block_reduce_store<kScanSlots>(acc, ops, scratch + (int64_t)blockIdx.x * kScanSlots);
+  block_reduce_store_f<kScanSlots>(acc, [](int) { return (int)RSUM; }, scratch + (int64_t)blockIdx.x * kScanSlots);
 }
 
 __global__ __launch_bounds__(kBlock) void k_scan_moments_final(const double* scratch, const int nblocks, double* out) {
@@ -1149,6 +1168,179 @@ __global__ __launch_bounds__(kBlock) void k_gauss_weights(const ArtBundleView b,
     }
     w[i] = exp(-2.0 * q * q * kexp);
   }
+}
+
+// ------------------------------------------------------------------------------------------- guide rays
+// One guide ray per thread, each through ITS OWN element (art_trace_guides): the 1-ray alignment traces of OEPlacement for
+// up to 8 chains in one launch.  The descriptors are kernel arguments, indexed per lane (vector loads from the constant
+// argument segment: this kernel is launch-latency, not throughput).
+struct GuideArgs {
+  ArtElementDesc e[ART_GUIDES_MAX];
+};
+template <bool DEFECT>
+__global__ __launch_bounds__(64) void k_trace_guides(const GuideArgs ga, double* rays, uint8_t* alive, const int count) {
+  const int t = threadIdx.x;
+  if (t >= count) return;
+  art::Ray r;
+  double* q = rays + 8 * t;
+  r.ox = q[0]; r.oy = q[1]; r.oz = q[2]; r.dx = q[3]; r.dy = q[4]; r.dz = q[5]; r.path = q[6]; r.inc = q[7];
+  bool ok = alive[t] != 0;
+  if (ok) {
+    // one lane at a time: the torus solver's Newton loop votes across the wave and the descriptor must be wave-uniform
+    for (int j = 0; j < count; ++j) {
+      if (t == j) ok = art::trace_ray_dyn<DEFECT>(ga.e[j], ga.e[j].zern, r);
+    }
+  }
+  if (ok) { q[0] = r.ox; q[1] = r.oy; q[2] = r.oz; q[3] = r.dx; q[4] = r.dy; q[5] = r.dz; q[6] = r.path; q[7] = r.inc; }
+  alive[t] = (uint8_t)(ok ? 1 : 0);
+}
+
+// ------------------------------------------------------------------------------------------- batched analysis
+// art_analyse_bundles: blockIdx.y = job.  Partials per job and workgroup, folded in a fixed order.
+constexpr int kAnaSums = 9;      // count, sum point (3), sum vector (3), sum w, sum path
+constexpr int kAnaMom = 42;      // 32 moment sums, kink shifts (2), max angle, bounding box + path range (6), pad
+constexpr int kAnaPlace = 24;    // per job: ArtDetectorDesc (15 doubles), axis (3), co, pad
+constexpr int kAnaBlocks = 1024; // workgroups per job at most
+// Workgroups per job: a function of the ray count ALONE, so that a bundle's sums are folded in the same order whether it
+// is analysed alone or as one of a list (same bits either way).
+inline int analysis_blocks(int64_t n) {
+  const int64_t b = (n + kBlock - 1) / kBlock;
+  return (int)(b < 1 ? 1 : (b > kAnaBlocks ? kAnaBlocks : b));
+}
+__device__ __forceinline__ int ana_mom_op(const int q) {   // operator of moment-pass partial q
+  return (q < 32) ? RSUM : ((q == 33 || q == 35 || q == 37 || q == 39) ? RMIN : ((q == 41) ? RSUM : RMAX));
+}
+__device__ __forceinline__ int ana_mom_slot(const int q) { // where partial q lands in a job's output row
+  return (q < 32) ? 20 + q : ((q < 35) ? 53 + (q - 32) : 56 + (q - 35));
+}
+
+__global__ __launch_bounds__(kBlock) void k_analysis_sums(const ArtAnalysisJob* __restrict__ jobs, const int64_t n,
+                                                          double* scratch) {
+  const ArtAnalysisJob& jb = jobs[blockIdx.y];
+  const ArtBundleView b = jb.b;
+  const double* w = jb.w;
+  const int ops[kAnaSums] = {RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM};
+  double acc[kAnaSums] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    if (b.alive[i] == 0) continue;
+    acc[0] += 1.0;
+    acc[1] += b.ox[i]; acc[2] += b.oy[i]; acc[3] += b.oz[i];
+    acc[4] += b.dx[i]; acc[5] += b.dy[i]; acc[6] += b.dz[i];
+    acc[7] += w ? w[i] : 1.0;
+    acc[8] += b.path[i];
+  }
+  block_reduce_store<kAnaSums>(acc, ops, scratch + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * kAnaSums);
+}
+
+// one workgroup per job: fold the sums (thread t takes partials t, t + 256, ...; fixed tree), place the detector
+__global__ __launch_bounds__(kBlock) void k_analysis_place(const ArtAnalysisJob* __restrict__ jobs, const int nblocks,
+                                                           const double* partials, double* place, double* out) {
+  const int j = blockIdx.x;
+  __shared__ double s_sum[kAnaSums];
+  const int ops[kAnaSums] = {RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM};
+  double acc[kAnaSums] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const double* mine = partials + (int64_t)j * nblocks * kAnaSums;
+  for (int blk = threadIdx.x; blk < nblocks; blk += kBlock) {
+#pragma unroll
+    for (int k = 0; k < kAnaSums; ++k) acc[k] += mine[(int64_t)blk * kAnaSums + k];
+  }
+  block_reduce_store<kAnaSums>(acc, ops, s_sum);
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const ArtAnalysisJob& jb = jobs[j];
+  double* o = out + (int64_t)j * ART_ANALYSIS_DOUBLES;
+  double* pl = place + (int64_t)j * kAnaPlace;
+  for (int k = 0; k < ART_ANALYSIS_DOUBLES; ++k) o[k] = 0.0;
+  for (int k = 0; k < kAnaSums; ++k) o[k] = s_sum[k];
+  o[53] = -INFINITY; o[54] = INFINITY;
+  o[56] = INFINITY; o[57] = -INFINITY; o[58] = INFINITY; o[59] = -INFINITY; o[60] = INFINITY; o[61] = -INFINITY;
+  if (jb.mode == ART_JOB_SUMS) return;
+  ArtDetectorDesc d;
+  double ref[3], axis[3], co;
+  if (s_sum[0] > 0.0) {
+    art::analysis_place(s_sum, jb.mode, jb.distance, jb.centre, jb.normal, jb.refpoint, d, ref, axis, co);
+  } else {
+    for (int k = 0; k < 3; ++k) { d.centre[k] = NAN; d.normal[k] = NAN; ref[k] = NAN; axis[k] = NAN; }
+    for (int k = 0; k < 9; ++k) d.rot[k] = NAN;
+    co = NAN;
+  }
+  for (int k = 0; k < 3; ++k) { o[10 + k] = d.centre[k]; o[13 + k] = d.normal[k]; o[16 + k] = ref[k]; }
+  o[19] = co;
+  for (int k = 0; k < 3; ++k) { pl[k] = d.centre[k]; pl[3 + k] = d.normal[k]; pl[15 + k] = axis[k]; }
+  for (int k = 0; k < 9; ++k) pl[6 + k] = d.rot[k];
+  pl[18] = co;
+}
+
+__global__ __launch_bounds__(kBlock) void k_analysis_moments(const ArtAnalysisJob* __restrict__ jobs, const int64_t n,
+                                                             const double* place, const double* out, double* scratch) {
+  const int j = blockIdx.y;
+  const ArtAnalysisJob& jb = jobs[j];
+  double acc[kAnaMom];
+#pragma unroll
+  for (int k = 0; k < kAnaMom; ++k) acc[k] = (ana_mom_op(k) == RSUM) ? 0.0 : (ana_mom_op(k) == RMIN ? INFINITY : -INFINITY);
+  acc[34] = 0.0;    // the largest angle of an empty set is 0 (ReturnNumericalAperture's max over nothing never happens)
+  const bool active = jb.mode != ART_JOB_SUMS && out[(int64_t)j * ART_ANALYSIS_DOUBLES] > 0.0;
+  if (active) {
+    const double* pl = place + (int64_t)j * kAnaPlace;
+    ArtDetectorDesc d;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { d.centre[k] = pl[k]; d.normal[k] = pl[3 + k]; }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) d.rot[k] = pl[6 + k];
+    const Axis3 ax = {pl[15], pl[16], pl[17]};
+    const double co = pl[18];
+    const ArtBundleView b = jb.b;
+    const double* w = jb.w;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+      if (b.alive[i] == 0) continue;
+      art::Ray r;
+      load_ray(b, i, r);
+      double q0[3], sq[3], sk;
+      art::detector_ray_scan_kink(d, r, q0[0], q0[1], q0[2], sq[0], sq[1], sq[2], sk);
+      acc[35] = fmin(acc[35], q0[0]); acc[36] = fmax(acc[36], q0[0]);
+      acc[37] = fmin(acc[37], q0[1]); acc[38] = fmax(acc[38], q0[1]);
+      acc[39] = fmin(acc[39], q0[2]); acc[40] = fmax(acc[40], q0[2]);
+      acc[32] = fmax(acc[32], (sk <= 0.0) ? sk : -INFINITY);
+      acc[33] = fmin(acc[33], (sk > 0.0) ? sk : INFINITY);
+      acc[34] = fmax(acc[34], angle_to_axis(ax, r.dx, r.dy, r.dz));
+      q0[2] -= co;
+      sq[2] -= 1.0;
+      const double ww = w ? w[i] : 1.0;
+      acc[0] += 1.0;
+      acc[16] += ww;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int o = 1 + 5 * k;
+        acc[o] += q0[k]; acc[o + 1] += sq[k];
+        acc[o + 2] = fma(q0[k], q0[k], acc[o + 2]); acc[o + 3] = fma(q0[k], sq[k], acc[o + 3]);
+        acc[o + 4] = fma(sq[k], sq[k], acc[o + 4]);
+        const double wq = ww * q0[k], ws = ww * sq[k];
+        acc[16 + o] += wq; acc[16 + o + 1] += ws;
+        acc[16 + o + 2] = fma(wq, q0[k], acc[16 + o + 2]); acc[16 + o + 3] = fma(wq, sq[k], acc[16 + o + 3]);
+        acc[16 + o + 4] = fma(ws, sq[k], acc[16 + o + 4]);
+      }
+    }
+  }
+  block_reduce_store_f<kAnaMom>(acc, [](int k) { return ana_mom_op(k); }, scratch + ((int64_t)j * gridDim.x + blockIdx.x) * kAnaMom);
+}
+
+// grid (kAnaMom - 1, n_jobs): workgroup (q, j) folds partial q of job j into its output slot
+__global__ __launch_bounds__(kBlock) void k_analysis_fold(const ArtAnalysisJob* __restrict__ jobs, const int nblocks,
+                                                          const double* scratch, double* out) {
+  const int q = blockIdx.x, j = blockIdx.y;
+  if (jobs[j].mode == ART_JOB_SUMS) return;
+  const int op = ana_mom_op(q);
+  const int op1[1] = {op};
+  const double ident = (op == RSUM) ? 0.0 : (op == RMIN ? INFINITY : -INFINITY);
+  double acc[1] = {ident};
+  const double* mine = scratch + (int64_t)j * nblocks * kAnaMom;
+  for (int blk = threadIdx.x; blk < nblocks; blk += kBlock) {
+    const double v = mine[(int64_t)blk * kAnaMom + q];
+    acc[0] = (op == RSUM) ? acc[0] + v : (op == RMIN ? fmin(acc[0], v) : fmax(acc[0], v));
+  }
+  block_reduce_store<1>(acc, op1, out + (int64_t)j * ART_ANALYSIS_DOUBLES + ana_mom_slot(q));
 }
 
 // ------------------------------------------------------------------------------------------- compaction
@@ -1470,10 +1662,11 @@ inline int chain_waves() {
 // dead pair with one branch and two dropped offsets, where the one-ray body still stages, synchronises and issues the
 // workgroup's stores) and -3 ... +9 % elsewhere, box-dependent; so it is the default exactly where a mask is part of the
 // launch.  ART_CHAIN_RPL=1|2 overrides (read at every call: the A/B tool alternates the variants inside one process).
+// (One getenv + atoi per launch, ~0.1 us, on purpose: a cached value could not be alternated by the A/B tool.)
 inline int chain_rpl(const bool has_mask) {
   const char* e = getenv("ART_CHAIN_RPL");
-  if (e && (atoi(e) == 1 || atoi(e) == 2)) return atoi(e);
-  return has_mask ? 2 : 1;
+  const int v = e ? atoi(e) : 0;
+  return (v == 1 || v == 2) ? v : (has_mask ? 2 : 1);
 }
 // ART_CHAIN_DYN_LDS=<bytes>: unused dynamic LDS per workgroup of the fused kernel, i.e. FEWER resident workgroups per CU
 // (20 KB static + 20480 -> 4, + 33000 -> 3).  An experiment knob: the bare access pattern gains 3-7 % of bandwidth with 2-3
@@ -1982,6 +2175,58 @@ int art_make_extended_source(double radius, double divergence, int64_t n_points,
                      divergence, n_points, rays_per_point, rs, first, n, *out);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_make_extended_source launch");
+  return ART_OK;
+}
+
+int art_trace_guides(const ArtElementDesc* elems, int32_t count, double* rays, uint8_t* alive, void* stream) {
+  if (!elems || !rays || !alive) return fail(ART_ERR_BAD_ARG, "NULL argument");
+  if (count < 0 || count > ART_GUIDES_MAX) return fail(ART_ERR_BAD_ARG, "art_trace_guides: count must be in 0..8");
+  if (count == 0) return ART_OK;
+  GuideArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  bool defects = false;
+  for (int k = 0; k < count; ++k) {
+    int rc = check_elem(&elems[k]);
+    if (rc) return rc;
+    if (elems[k].flags & ART_FLAG_ZERN_RECURRENCE)
+      return fail(ART_ERR_UNSUPPORTED, "an element carries Zernike tables in the recurrence layout: trace it with art_trace_element");
+    ga.e[k] = elems[k];
+    art::prepare_element(ga.e[k]);
+    defects = defects || ga.e[k].n_defects > 0 || ga.e[k].n_grid > 0;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (defects) hipLaunchKernelGGL(k_trace_guides<true>, dim3(1), dim3(64), 0, s, ga, rays, alive, (int)count);
+  else hipLaunchKernelGGL(k_trace_guides<false>, dim3(1), dim3(64), 0, s, ga, rays, alive, (int)count);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail_hip(err, "art_trace_guides launch");
+  return ART_OK;
+}
+
+int64_t art_analysis_scratch_doubles(int32_t n_jobs) {
+  if (n_jobs < 1) n_jobs = 1;
+  return (int64_t)n_jobs * ((int64_t)kAnaBlocks * (kAnaSums + kAnaMom) + kAnaPlace);
+}
+
+int art_analyse_bundles(const ArtAnalysisJob* jobs_dev, const ArtAnalysisJob* jobs_host, int32_t n_jobs, int64_t n,
+                        double* scratch, double* out, void* stream) {
+  if (!jobs_dev || !jobs_host || !scratch || !out) return fail(ART_ERR_BAD_ARG, "NULL argument");
+  if (n_jobs <= 0 || n_jobs > 65535) return fail(ART_ERR_BAD_ARG, "n_jobs must be in 1..65535");
+  if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
+  for (int j = 0; j < n_jobs; ++j) {
+    if (jobs_host[j].mode < ART_JOB_AUTOPLACE || jobs_host[j].mode > ART_JOB_SUMS) return fail(ART_ERR_BAD_ARG, "unknown job mode");
+    if (n > 0 && !view_ok(&jobs_host[j].b)) return fail(ART_ERR_BAD_ARG, "a job's bundle view has a NULL array");
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int P = analysis_blocks(n);
+  double* sums = scratch;
+  double* mom = sums + (int64_t)n_jobs * P * kAnaSums;
+  double* place = mom + (int64_t)n_jobs * P * kAnaMom;
+  hipLaunchKernelGGL(k_analysis_sums, dim3(P, n_jobs), dim3(kBlock), 0, s, jobs_dev, n, sums);
+  hipLaunchKernelGGL(k_analysis_place, dim3(n_jobs), dim3(kBlock), 0, s, jobs_dev, P, sums, place, out);
+  hipLaunchKernelGGL(k_analysis_moments, dim3(P, n_jobs), dim3(kBlock), 0, s, jobs_dev, n, place, out, mom);
+  hipLaunchKernelGGL(k_analysis_fold, dim3(kAnaMom - 1, n_jobs), dim3(kBlock), 0, s, jobs_dev, P, mom, out);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail_hip(err, "art_analyse_bundles launch");
   return ART_OK;
 }
 

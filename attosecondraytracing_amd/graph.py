@@ -53,9 +53,13 @@ class SceneProgram:
     `detector.readout(outputs[c][-1])` returns them).  `post`: optional callable `post(outputs)` captured right behind
     the trace; its return value is `self.post_result`.
 
+    `placement_tries` (default: ART_PLACEMENT_TRIES, else 1 = off): opt-in look at where the output bundles lie, see
+    `_tune_placement` below.
+
     Results are bit-identical to `RayTracingCalculation`; the returned bundles are overwritten by the next `run()`."""
 
-    def __init__(self, sources, element_lists, IgnoreDefects=True, post=None, capture=True, detectors=None, history=True):
+    def __init__(self, sources, element_lists, IgnoreDefects=True, post=None, capture=True, detectors=None, history=True,
+                 placement_tries=None):
         from . import ModuleProcessing as mp
         from . import _abi
         from .bundle import RayBundle
@@ -88,8 +92,11 @@ class SceneProgram:
         self.post, self.post_result = post, None
         self.update(element_lists)
         self.placement = None
-        if self.be.name == "hip":
-            self._tune_placement(element_lists)
+        if placement_tries is None:
+            import os
+            placement_tries = int(os.environ.get("ART_PLACEMENT_TRIES", "1"))
+        if self.be.name == "hip" and placement_tries > 1:
+            self._tune_placement(element_lists, int(placement_tries))
         self.graph = None
         if capture and self.be.name == "hip":
             side = torch.cuda.Stream()
@@ -106,13 +113,15 @@ class SceneProgram:
                 self.be.counted_launches = counted      # a captured launch has not run
 
     # ---- where the output bundles lie ------------------------------------------------------------------------------
-    # The same launch into another allocation of the same size takes up to 25 % longer or shorter (tools/pitch_probe.py:
-    # 16 buffers of one size, C4 1.10-1.16 ms in thirteen of them and 1.39-1.42 ms in three, relay4 0.535-0.547 / 0.585-
-    # 0.595 ms; a plain fill runs at the same 6.7 TB/s in all of them, row pitch and start offset INSIDE one buffer change
-    # nothing).  A launch writes 8 m + 3 streams at once, i.e. it keeps that many pages per workgroup in flight: what
-    # differs from one allocation to the next is how the driver mapped it, not the memory.  A program keeps its output
-    # bundles for its lifetime, so it can afford to look: it allocates a few candidates, times its own launch into each and
-    # keeps the fastest (ART_PLACEMENT_TRIES, default 6; 1 = take the first).
+    # The same launch into another allocation of the same size can take a few percent longer or shorter (what differs is
+    # how the driver mapped the block, not the memory: profiles/HISTORY.md, "placement").  A program keeps its output
+    # bundles for its lifetime, so it MAY look: `SceneProgram(..., placement_tries=N)` or ART_PLACEMENT_TRIES=N allocates
+    # up to N candidate blocks, times its own launch into each and keeps the fastest.  OFF by default (N = 1): under the
+    # driver's protocol the look chose the first block and the spread was 5 % (BENCH_r03).  When on, it is bounded: the
+    # candidates and the spacers between them together stay below ART_PLACEMENT_MEM_CAP (bytes, or a fraction < 1 of the
+    # free memory; default 0.25), an allocation that fails ends the look with the candidates found so far, a first pass
+    # whose spread is below 3 % ends it without a second pass, and the library never empties the caching allocator: the
+    # blocks of the candidates it drops go back to PyTorch's cache, where the caller's next allocation finds them.
     def _alloc_outputs(self):
         from .bundle import RayBundle
         if self._history:
@@ -140,45 +149,62 @@ class SceneProgram:
         e1.synchronize()
         return e0.elapsed_time(e1) / reps
 
-    def _tune_placement(self, element_lists):
+    @staticmethod
+    def _placement_budget(free):
         import os
+        cap = float(os.environ.get("ART_PLACEMENT_MEM_CAP", "0.25"))
+        return int(cap * free) if cap < 1.0 else int(min(cap, free))
+
+    def _tune_placement(self, element_lists, tries):
+        import time
         rows = sum(b is not None for outs in self.outputs for b in outs)
         nbytes = rows * 65 * self.n
-        tries = int(os.environ.get("ART_PLACEMENT_TRIES", "6"))
         if nbytes < (64 << 20) or tries <= 1:
             return
         free, _ = torch.cuda.mem_get_info()
-        tries = max(1, min(tries, 1 + int(0.4 * free // nbytes)))      # the candidates exist side by side
+        budget = self._placement_budget(free)
+        asked, tries = tries, max(1, min(tries, 1 + budget // max(nbytes, 1)))     # the candidates exist side by side
         if tries <= 1:
+            self.placement = {"tries": 1, "asked": asked, "chosen": 0, "note": "memory cap: no room for a second candidate"}
             return
         # the clocks first: a launch takes a third longer on a device that has just been idle (the governor's ramp lasts
         # ~40 ms); without this the LAST candidate measured looks best
-        import time
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < 0.08:
             self._time_launch(reps=4)
-        # Consecutive allocations lie in one region of physical memory more often than not (the levels come in runs of
-        # 10-50 GB, tools/pitch_probe.py): an untouched spacer in front of every further candidate spreads them out
-        spacer = max(0, min(8 << 30, int(0.5 * free // tries)) - nbytes)
-        pool, spacers = [self.outputs], []
+        # Consecutive allocations lie in one region of physical memory more often than not: an untouched spacer in front
+        # of every further candidate spreads them out -- inside the same budget
+        spacer = max(0, min(8 << 30, (budget - (tries - 1) * nbytes) // (tries - 1)))
+        spacer = spacer if spacer >= (256 << 20) else 0
+        pool, spacers, oom = [self.outputs], [], False
         for _ in range(tries - 1):
-            if spacer >= (256 << 20):
-                spacers.append(torch.empty(spacer, dtype=torch.uint8, device=self.be.device))
-            pool.append(self._alloc_outputs())
+            try:
+                if spacer:
+                    spacers.append(torch.empty(spacer, dtype=torch.uint8, device=self.be.device))
+                pool.append(self._alloc_outputs())
+            except torch.OutOfMemoryError:
+                oom = True          # another tenant of the device got there first: look at what there is
+                break
         del spacers
-        times = [float("inf")] * tries
-        for order in (range(tries), reversed(range(tries))):       # two passes, the second in reverse order
+        times = [float("inf")] * len(pool)
+        passes = 0
+        for order in (range(len(pool)), reversed(range(len(pool)))):       # two passes, the second in reverse order
             for j in order:
                 self._bind(pool[j])
                 self.update(element_lists)
                 times[j] = min(times[j], self._time_launch(reps=3))
-        best = min(range(tries), key=times.__getitem__)
+            passes += 1
+            if max(times) < 1.03 * min(times):
+                break               # nothing to choose between: keep the first block
+        best = min(range(len(pool)), key=times.__getitem__)
+        if times[0] < 1.03 * times[best]:
+            best = 0
         self._bind(pool[best])
         self.update(element_lists)
-        self.placement = {"tries": tries, "launch_ms": [round(t, 4) for t in times], "chosen": best,
-                          "spacer_bytes": spacer if spacer >= (256 << 20) else 0}
+        self.placement = {"tries": len(pool), "asked": asked, "launch_ms": [round(t, 4) for t in times], "chosen": best,
+                          "gain_vs_first": round(times[0] / times[best], 4), "passes": passes,
+                          "spacer_bytes": spacer, "budget_bytes": budget, "allocation_failed": oom}
         del pool
-        torch.cuda.empty_cache()        # hand the other candidates back to the driver
 
     def set_detectors(self, detectors):
         """(Re)place the fused read-outs' detectors; takes effect with the next update().  Only for a program that was

@@ -267,19 +267,29 @@ def decode_survivors(buf, count, flags, spec):
 
 class SurvivorGather:
     """The gather of SURVEY.md 8(e) as written: `(number:int32, X, Y, path)` = 28 B per SURVIVING ray from every shard to
-    rank `dst` in ONE collective (the consumer, ART/ModuleDetector.py:254-279, sees survivors only; ReadoutGather above
-    ships all slots, dead or alive).  Per step and rank:
+    rank `dst` in ONE payload collective (the consumer, ART/ModuleDetector.py:254-279, sees survivors only; ReadoutGather
+    above ships all slots, dead or alive).  Per step and rank:
       1. `art_pack_survivors` compacts the read-out of the alive slots into the rank's send buffer (header: count, flags;
          a shard whose every slot is alive and whose numbers are the implicit first + slot * step drops the number section:
          24 B/ray);
-      2. the 16-byte headers are all-gathered and read by the host -- the one host synchronisation of the exchange: a
-         collective's size must be known on the host, and it is the survivors' count that makes it small;
-      3. ONE `gather` of max_r art_survivor_bytes(count_r) bytes per rank, asynchronous on the communicator's stream.
+      2. the 16-byte headers are all-gathered on the device and copied to pinned host memory behind an event -- NOBODY
+         WAITS for them in this step;
+      3. ONE `gather` of `nbytes` bytes per rank, asynchronous on the communicator's stream.  A collective's size must be
+         known on the host when it is issued: it is PREDICTED from the newest headers the host already holds (those of
+         step i - 2 with two buffer sets: settled when their buffer set is taken again), with a margin (the larger of
+         `margin` = 1/16 of the count and `slack` = 1024 records, explicit numbers assumed; a shard that was dense is predicted dense).  The
+         count travels inside the payload's own header, so the root decodes exactly what was packed.  When the headers of
+         a step land and show that some shard packed MORE than was shipped (overflow), that one step's gather is issued
+         again with the exact size -- before its send buffer is packed again, on every rank alike (all ranks read the
+         same all-gathered headers at the same point of the program).  Only the first step of a gather (nothing to
+         predict from) reads its own headers synchronously.
+    So a steady-state step costs two collectives -- a 16-byte all-gather nobody waits for and the payload gather -- and no
+    host synchronisation; `host_syncs` counts the exceptions (first step, overflows).
     `buffers` independent sets let the gather of step i overlap the tracing of step i + 1 (start / drain / result as in
     ReadoutGather).  `result(b)` -> per-rank list of (number int64, X, Y, path) views on dst; `assemble(b)` -> the four
     arrays of the whole job in global ray order."""
 
-    def __init__(self, backend, n, world, rank, dst=0, buffers=2, specs=None):
+    def __init__(self, backend, n, world, rank, dst=0, buffers=2, specs=None, margin=1.0 / 16, slack=1024, predict=True):
         self.be, self.n, self.world, self.rank, self.dst = backend, int(n), int(world), int(rank), int(dst)
         # (first, step, n) of every rank's shard: for the implicit numbers of dense shards on the root
         self.specs = specs if specs is not None else [(0, 1, self.n)] * self.world
@@ -287,35 +297,100 @@ class SurvivorGather:
         if top > 2 ** 31 - 1:
             raise ValueError("ray numbers up to %d do not fit the int32 of a survivor record" % top)
         dev = backend.device
+        self.margin, self.slack, self.predict = float(margin), int(slack), bool(predict)
         # capacity of every buffer: the longest shard with every slot alive and explicit numbers (28 B per ray)
         self.cap = backend.survivor_bytes(max([self.n] + [s[2] for s in self.specs]), False)
         self.send = [torch.empty(self.cap, dtype=torch.uint8, device=dev) for _ in range(buffers)]
         self.recv = [[torch.empty(self.cap, dtype=torch.uint8, device=dev) for _ in range(self.world)]
                      if self.rank == self.dst else None for _ in range(buffers)]
         self.hdr = [torch.zeros((self.world, 2), dtype=torch.int64, device=dev) for _ in range(buffers)]
-        self.headers = [None] * buffers       # host copies: [[count, flags]] per rank
+        pin = torch.device(dev).type == "cuda"
+        self._hdr_host = [torch.zeros((self.world, 2), dtype=torch.int64, pin_memory=pin) for _ in range(buffers)]
+        self._hdr_event = [None] * buffers    # the headers of set b are on the host once this event has completed
+        self._settled = [True] * buffers      # headers read and the shipped size checked against them
+        self.headers = [None] * buffers       # host copies: [[count, flags]] per rank (valid once set b is settled)
         self.nbytes = [0] * buffers           # size of the collective issued on set b
         self.work = [None] * buffers
+        self._known = None                    # newest settled headers: what the next size is predicted from
+        self.host_syncs = 0                   # steps that read their own headers synchronously + overflow repairs
+        self.overflows = 0
+
+    # ---- sizes ---------------------------------------------------------------------------------------------------------
+    def _exact_bytes(self, headers):
+        return max(self.be.survivor_bytes(c, bool(f & 1)) for c, f in headers)
+
+    def _predicted_bytes(self, headers):
+        need = 0
+        for (c, f), (_, _, slots) in zip(headers, self.specs):
+            if f & 1:                                   # dense last time: predicted dense (a shard cannot grow)
+                b = self.be.survivor_bytes(c, True)
+            else:
+                b = self.be.survivor_bytes(min(int(slots), int(c + max(self.slack, self.margin * c))), False)
+            need = max(need, b)
+        return min(need, self.cap)
+
+    # ---- collectives ---------------------------------------------------------------------------------------------------
+    def _issue(self, b, nb):
+        self.nbytes[b] = nb
+        if dist.is_available() and dist.is_initialized():
+            recv = None if self.recv[b] is None else [t[:nb] for t in self.recv[b]]
+            self.work[b] = dist.gather(self.send[b][:nb], recv, dst=self.dst, async_op=True)     # ONE payload collective
+        elif self.recv[b] is not None:
+            self.recv[b][0][:nb].copy_(self.send[b][:nb])
+
+    def _read_headers(self, b):
+        ev = self._hdr_event[b]
+        if ev is not None:
+            ev.synchronize()
+        self.headers[b] = self._hdr_host[b].tolist()
+
+    def _settle(self, b):
+        """Headers of set b on the host, the shipped size checked: a step that packed more than was shipped is gathered
+        again with the exact size (its send buffer is still intact)."""
+        if self._settled[b]:
+            return
+        self._read_headers(b)
+        need = self._exact_bytes(self.headers[b])
+        if need > self.nbytes[b]:
+            self.overflows += 1
+            self.host_syncs += 1
+            if self.work[b] is not None:
+                self.work[b].wait()
+                self.work[b] = None
+            self._issue(b, need)
+            if self.work[b] is not None:
+                self.work[b].wait()
+                self.work[b] = None
+        self._settled[b] = True
+        self._known = self.headers[b]
 
     def start(self, b, X, Y, opl, alive, number=None):
+        """Pack this rank's survivors into buffer set b and enqueue the gather; returns the bytes shipped per rank."""
         if self.work[b] is not None:
             self.work[b].wait()
             self.work[b] = None
+        self._settle(b)                       # the previous use of this set (two steps ago with two sets)
         first, step, _ = self.specs[self.rank]
         self.be.pack_survivors(alive, X, Y, opl, number, first, step, self.send[b])
         mine = self.send[b][:16].view(torch.int64)
         if dist.is_available() and dist.is_initialized():
-            dist.all_gather_into_tensor(self.hdr[b].view(-1), mine)
+            w = dist.all_gather_into_tensor(self.hdr[b].view(-1), mine, async_op=True)
+            w.wait()                          # RCCL: the caller's STREAM waits; gloo (CPU tests): the host does
         else:
             self.hdr[b][0].copy_(mine)
-        self.headers[b] = self.hdr[b].cpu().tolist()            # host sync: the collective's size
-        self.nbytes[b] = max(self.be.survivor_bytes(c, bool(f & 1)) for c, f in self.headers[b])
-        nb = self.nbytes[b]
-        if dist.is_available() and dist.is_initialized():
-            recv = None if self.recv[b] is None else [t[:nb] for t in self.recv[b]]
-            self.work[b] = dist.gather(self.send[b][:nb], recv, dst=self.dst, async_op=True)     # ONE collective
-        elif self.recv[b] is not None:
-            self.recv[b][0][:nb].copy_(self.send[b][:nb])
+        self._hdr_host[b].copy_(self.hdr[b], non_blocking=True)
+        if self._hdr_host[b].is_pinned():
+            self._hdr_event[b] = torch.cuda.Event()
+            self._hdr_event[b].record()
+        self._settled[b] = False
+        if self._known is None or not self.predict:
+            self.host_syncs += 1              # nothing to predict from: this step's own headers, synchronously
+            self._read_headers(b)
+            nb = self._exact_bytes(self.headers[b])
+            self._settled[b], self._known = True, self.headers[b]       # exact by construction
+        else:
+            nb = self._predicted_bytes(self._known)
+        self._issue(b, nb)
         return nb
 
     def drain(self):
@@ -323,10 +398,15 @@ class SurvivorGather:
             if w is not None:
                 w.wait()
                 self.work[b] = None
+            self._settle(b)
 
     def result(self, b):
         """On dst: [(number int64 [c], X [c], Y [c], path [c])] per rank (views of receive set b; the numbers of a dense
         shard are generated).  None elsewhere."""
+        if self.work[b] is not None:
+            self.work[b].wait()
+            self.work[b] = None
+        self._settle(b)
         if self.recv[b] is None:
             return None
         return [decode_survivors(buf, *self.headers[b][r], self.specs[r]) for r, buf in enumerate(self.recv[b])]

@@ -40,6 +40,7 @@ it is a worker.  A worker fails if the process group's size differs from --gpus.
 import argparse
 import json
 import os
+import re
 import subprocess
 import sys
 import time
@@ -49,6 +50,7 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_INTERSECTION = 128.0   # read 48+8+4, write 48+8+8+4
 ALGO_BYTES_READOUT = 88.0             # read 48+8+4, write 8+8+8+4
+XGMI_LINK_GBS = 153.0                 # one xGMI link (7 per GPU, point to point)
 HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6300 GB/s is what a copy achieves)
 CONFIGS = ("relay4", "C2", "C3", "C4", "C5")
 SETTLE_SECONDS = 0.25   # device-busy time before the `value_sustained` region (see worker())
@@ -67,15 +69,28 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def launch_workers(n, argv):
-    """Start n workers of this script, one per GPU; relay rank 0's stdout (the JSON line); fail if any worker fails.
+def multi_process_env(env):
+    """What every process of a multi-process GPU job needs in its environment on this pool.
+    HSA_ENABLE_IPC_MODE_LEGACY=0: the hosts' kernel driver supports only dmabuf-based IPC.  RCCL opens its peers' buffers
+    through hipIpcGetMemHandle / hipIpcOpenMemHandle (and so does any CUDA-tensor sharing between processes); with the
+    runtime's LEGACY IPC mode (the default of some ROCr builds) those calls fail with `hipIpcGetMemHandle: invalid
+    argument` as soon as two ranks on one node set up their xGMI / P2P transport -- a one-rank group never gets there.
+    The image exports the variable already; it is set here too (setdefault: an explicit choice of the caller wins) so that
+    a worker started from a scrubbed environment behaves the same.  examples/sharded_trace.py does the same."""
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def launch_workers(n, argv, time_limit=1500.0):
+    """Start n workers of this script, one per GPU; relay rank 0's stdout (the JSON line); fail if any worker fails or
+    the job exceeds `time_limit` seconds of wall clock (all workers are killed, exit code 4).  The workers are fresh
+    child processes: nothing that has touched the GPU is ever re-exec'ed.
     Runs before any torch.cuda / HIP call of this process: nothing here initialises the GPU."""
     port = _free_port()
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env = multi_process_env(dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                                     MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
         out = subprocess.PIPE if r == 0 else sys.stderr
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
     # rank 0's stdout is drained while the workers run (a reader thread): a rank 0 that printed more than the pipe holds
@@ -85,10 +100,15 @@ def launch_workers(n, argv):
     reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
     reader.start()
     # watch all workers: if one dies, the others would sit in a collective until RCCL's own timeout -- end them at once
-    failed = False
+    failed = timed_out = False
+    t_start = time.monotonic()
     while any(p.poll() is None for p in procs):
         if any(p.poll() not in (None, 0) for p in procs):
             failed = True
+            break
+        if time.monotonic() - t_start > time_limit:
+            failed = timed_out = True
+            log(f"[bench] the {n}-rank job exceeded its wall-clock limit of {time_limit:.0f} s: killing all workers")
             break
         time.sleep(0.2)
     if failed:
@@ -103,7 +123,7 @@ def launch_workers(n, argv):
     sys.stdout.flush()
     if any(rc != 0 for rc in rcs):
         log(f"[bench] worker exit codes {rcs}: failing")
-        return 1
+        return 4 if timed_out else 1
     return 0
 
 
@@ -392,8 +412,9 @@ class _HostTables:
         return torch.from_numpy(np.array(a, copy=True))
 
 
-def profiled_traffic(config, kernel_prefix, rays):
-    """HBM bytes per launch of the kernel whose name starts with `kernel_prefix`, from the newest committed rocprofv3
+def profiled_traffic(config, kernel_pattern, rays):
+    """HBM bytes per launch of the kernel whose name matches the regular expression `kernel_pattern` (anchored at the
+    start; masked chains launch the two-rays-per-lane bodies k_trace_scene2 / k_trace_chain2), from the newest committed rocprofv3
     PMC summary of this workload (profiles/rNN_<config>*.json, written by tools/summarize_profile.py from separate
     --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 read correction) THAT WAS TAKEN ON THIS BUILD: a profile whose
     `source_hash` (csrc/* + include/art_hip.h at profiling time) differs from the tree's is dropped, and the line says so.
@@ -408,7 +429,7 @@ def profiled_traffic(config, kernel_prefix, rays):
             j = json.load(open(f))
         except Exception:
             continue
-        hits = [k for k in j.get("per_launch", {}) if k.startswith(kernel_prefix)]
+        hits = [k for k in j.get("per_launch", {}) if re.match(kernel_pattern, k)]
         if j.get("rays_per_gpu") == rays and hits:
             if j.get("source_hash") != here:
                 dropped.append(f"{os.path.relpath(f, ROOT)} (sources {j.get('source_hash', 'unrecorded')} != {here})")
@@ -454,7 +475,11 @@ def worker(args):
         os.environ.setdefault("MASTER_PORT", "29533")
         backend = os.environ.get("ART_DIST_BACKEND", "nccl")
         kw = {"device_id": torch.device("cuda", local)} if (on_gpu and backend == "nccl") else {}
-        dist.init_process_group(backend, rank=rank, world_size=env_world, **kw)
+        import datetime
+        # a rank that never arrives must not hold the others forever: collectives give up after --pg-timeout seconds
+        # (the launcher's own wall-clock limit, --time-limit, is the second line of defence)
+        dist.init_process_group(backend, rank=rank, world_size=env_world,
+                                timeout=datetime.timedelta(seconds=args.pg_timeout), **kw)
         world = dist.get_world_size()       # what RCCL actually saw
     if world != args.gpus:
         log(f"[bench] FATAL: --gpus {args.gpus} but the process group has {world} rank(s)")
@@ -582,7 +607,8 @@ def worker(args):
     program = None
     if batched or use_graph:
         program = SceneProgram([src] * n_chains, element_lists, IgnoreDefects=ignore_defects,
-                               post=readouts, capture=use_graph, detectors=dets if fuse else None)
+                               post=readouts, capture=use_graph, detectors=dets if fuse else None,
+                               placement_tries=args.placement_tries)
 
     # the same step WITHOUT the intermediate bundles (what ARTmain's lazy history traces: the analysed bundle + its
     # read-out; the rest of the history only when somebody looks at it) -- reported beside `value`, never as `value`
@@ -781,11 +807,11 @@ def worker(args):
                        "name": cfg, "rays_per_gpu": n, "elements": n_elems, "chains": n_chains,
                        "trace_mode": "scene (one launch for all chains)" if program is not None else mode,
                        "hip_graph": bool(use_graph), "world_size_seen": world, "shard_layout": args.shard,
-                       "output_placement": None if program is None or program.placement is None else dict(
-                           program.placement, note="the program allocated `tries` candidate blocks for its output bundles, "
-                           "timed its own launch into each (launch_ms) and kept the fastest: the same launch takes up to "
-                           "25 % longer in one allocation than in another of the same size (DESIGN.md 5, "
-                           "tools/pitch_probe.py); ART_PLACEMENT_TRIES=1 takes the first"),
+                       "output_placement": "first allocation (the placement look is opt-in: --placement-tries N)"
+                       if program is None or program.placement is None else dict(
+                           program.placement, note="OPT-IN (--placement-tries): the program allocated `tries` candidate blocks "
+                           "for its output bundles, timed its own launch into each (launch_ms) and kept the first unless another "
+                           "was 3 % faster; gain_vs_first = launch time in the first block / in the chosen one"),
                        "readout": "fused into the tracing launch" if fuse else "separate launch",
                        "step": "RayTracingCalculation + Detector.readout"
                                + (f" + ONE RCCL all-gather of every shard's 24 statistics and a {sample_k * world}-ray sample "
@@ -795,6 +821,13 @@ def worker(args):
                        "per survivor, 24 B in shards that lost nothing) to rank 0 in every step, double-buffered behind the "
                        "next step's tracing (value_full_gather)",
                        "gather_bytes_per_rank": None if not use_dist else state["gather_bytes"],
+                       # one xGMI link per peer into the root (the mesh is point to point): a shard's records cannot
+                       # arrive faster than bytes / link rate, whatever the tracing does
+                       "gather_floor_ms": None if not use_dist else state["gather_bytes"] / (XGMI_LINK_GBS * 1e9) * 1e3,
+                       "gather_floor_note": None if not use_dist else
+                       f"gather_bytes_per_rank / {XGMI_LINK_GBS:.0f} GB/s (one xGMI link per peer into rank 0; if that figure "
+                       "is the link's two directions together, the one-way floor is twice this); a step of value_full_gather "
+                       "cannot be shorter than max(trace, this)",
                        "gather_survivors": None if not use_dist else surv_last_job,
                        "dist_backend": None if not use_dist else dist.get_backend()},
             "value_sustained": None if dt_sus is None else inter_per_step_job * args.steps / dt_sus,
@@ -817,18 +850,20 @@ def worker(args):
         if on_gpu:
             inter_per_launch = inter_per_step_rank / launches
             defects = any(len(getattr(oe.type, "DeformationList", [])) > 0 for els in element_lists for oe in els)
+            # the body is chosen by the library (two rays per lane for chains with a mask): match either name
+            tf = "true" if defects else "false"
             if program is not None:
-                kprefix = "k_trace_scene<" + ("true" if defects else "false")
+                kprefix, kpat = f"k_trace_scene[2]<{tf}", rf"k_trace_scene2?<{tf}"
             elif mode == "chain" and (n_elems > 1 or fuse):
-                kprefix = "k_trace_chain<" + ("true" if defects else "false")
+                kprefix, kpat = f"k_trace_chain[2]<{tf}", rf"k_trace_chain2?<{tf}"
             else:                       # per-element launches; a one-element chain without read-out is that kernel too
-                kprefix = "k_trace_element<"
+                kprefix, kpat = "k_trace_element<", r"k_trace_element<"
             # profiles/r0N_<config>.json: the configuration as bench runs it by default; the other read-out mode is
             # profiled as r0N_<config>_fused.json / _separate.json
             auto_fuse = True
             base = f"relay{args.mirrors}" if cfg == "relay4" else cfg        # (profiles exist for the 4-mirror headline)
             pkey = base if fuse == auto_fuse else base + ("_fused" if fuse else "_separate")
-            tr, tr_note = profiled_traffic(pkey, kprefix, n)
+            tr, tr_note = profiled_traffic(pkey, kpat, n)
             # 128 B per intersection, + 88 B per ray of read-out when that rides on the same launch
             algo_bytes = ALGO_BYTES_PER_INTERSECTION * inter_per_launch + (ALGO_BYTES_READOUT * n * n_chains / launches if fuse else 0.0)
             algo = algo_bytes / (kernel_ms * 1e-3) / 1e9
@@ -870,9 +905,17 @@ def worker(args):
                 "algorithmic_bytes_per_intersection": ALGO_BYTES_PER_INTERSECTION,
                 "algorithmic_bytes_per_read_out_ray": ALGO_BYTES_READOUT if fuse else None,
                 "algorithmic_bytes_per_launch": algo_bytes,
+                # the same bytes over the DRIVER-TIMED step (ms_per_step: fold, gaps between launches and the clock ramp of
+                # the first steps included) -- the fraction the contract's own clock supports
+                "frac_step": (tr[0] if tr else comp) * launches / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                "frac_step_note": "bytes per launch x launches per step / ms_per_step / peak: the timed region itself; `frac` "
+                                  "divides by kernel_ms, which is measured AFTER the timed region (warmer clocks, no gaps)",
                 "kernel_ms": kernel_ms, "launches_per_step": launches, "intersections_per_launch": inter_per_launch,
-                "kernel_ms_note": f"mean of {EVENT_STEPS} event-bracketed launches (trace kernel + its 9-us fold) right after the "
-                                  "timed region(s), i.e. in their clock state; *_sustained: the same after the sustained-load region",
+                "kernel_ms_note": f"POST-REGION: mean of {EVENT_STEPS} event-bracketed launches (trace kernel + its 9-us fold) "
+                                  "issued right after the timed region(s) -- not inside them, because every timing event is a "
+                                  "barrier packet that would slow the timed steps; the clocks are warmer there than in the first "
+                                  "timed steps, so `frac` reads a few percent above `frac_step`; *_sustained: the same after the "
+                                  "sustained-load region",
                 "timed_region_launches": list(state.get("timed_launches", (0, 0))),
                 "timed_region_launches_note": "[first, last) of the full-size fused-kernel launches of this process, in issue "
                                               "order, that lie inside the timed region: cuts a rocprofv3 kernel trace of the "
@@ -898,7 +941,7 @@ def worker(args):
                             "24 B/ray of outputs and the per-workgroup partial statistics are part of that kernel's "
                             "traffic and time; `--readout separate` launches k_detector_readout instead"}
             else:
-                tro, _ = profiled_traffic(pkey, "k_detector_readout", n)
+                tro, _ = profiled_traffic(pkey, r"k_detector_readout", n)
                 algo_ro = ALGO_BYTES_READOUT * n / (readout_ms * 1e-3) / 1e9
                 counted_ro = None if tro is None else tro[0] / (readout_ms * 1e-3) / 1e9
                 res["roofline_readout"] = {
@@ -929,6 +972,12 @@ def worker(args):
                                                     f"{inter2} intersections in {secs2:.2f} s (best of 3); for scale only"}
             except Exception as e:    # noqa: BLE001 -- an optional extra must never cost the result line
                 log(f"[bench] cpu_twin_allcores skipped: {e!r}")
+        if use_dist:
+            log(f"[bench] N = {world}: `value` ({res['value']:.4g} intersections/s) is the step with the per-step exchange of "
+                f"statistics + sample (ONE all-gather) -- the number the >= 6x scaling target is judged on; "
+                f"`value_full_gather` ({res['value_full_gather']:.4g}) ships every surviving ray's record to rank 0 in every "
+                f"step and is bounded by one xGMI link per peer (gather_floor_ms "
+                f"{res['config']['gather_floor_ms']:.3f} ms per step vs {res['ms_per_step']:.3f} ms traced)")
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(res), flush=True)
@@ -956,11 +1005,18 @@ def main(argv=None):
                     help="fused: the detector read-out rides on the tracing launch; separate: its own kernel afterwards; "
                          "auto (default) = fused")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="rays of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--placement-tries", type=int, default=1,
+                    help="opt-in: let the step's program time its launch into N candidate output allocations and keep the "
+                         "fastest (graph.SceneProgram; default 1 = take the first allocation)")
+    ap.add_argument("--time-limit", type=float, default=float(os.environ.get("ART_BENCH_TIME_LIMIT", "1500")),
+                    help="N > 1 launcher: wall-clock limit in seconds after which all workers are killed (exit code 4)")
+    ap.add_argument("--pg-timeout", type=float, default=float(os.environ.get("ART_PG_TIMEOUT", "300")),
+                    help="N > 1 worker: timeout in seconds of the process group's collectives")
     args = ap.parse_args(argv)
     if args.cpu_sample < 0:
         args.cpu_sample = {"relay4": 2_000_000, "C2": 1_000_000, "C3": 1_000_000, "C4": 400_000, "C5": 150_000}[args.config]
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        return launch_workers(args.gpus, argv)      # nothing above or in there touches the GPU
+        return launch_workers(args.gpus, argv, args.time_limit)      # nothing above or in there touches the GPU
     return worker(args)
 
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ART_ABI_VERSION 9
+#define ART_ABI_VERSION 10
 
 /* error codes */
 #define ART_OK 0
@@ -346,6 +346,62 @@ int64_t art_survivor_bytes(int64_t count, int32_t dense);
 int art_pack_survivors(const uint8_t* alive, int64_t n, const double* X, const double* Y, const double* opl,
                        const int64_t* number, int64_t first, int64_t step, int32_t* scratch_ints, void* send,
                        int64_t send_bytes, void* stream);
+
+/* Guide rays of the placement (ART/ModuleProcessing.py:98-126: `_singleOEPlacement` traces ONE alignment ray through the
+ * chain built so far to find the direction in which the next optic is placed; OEPlacement with a list-valued argument,
+ * :203-239, does that for 10-11 chains one after the other).  One launch advances the guide rays of up to `count` chains
+ * by one element each: ray j meets elems[j] (any kind, the per-ray code of art_trace_element).  rays: DEVICE, count x 8
+ * doubles, row j = ox, oy, oz, dx, dy, dz, path, incidence of guide ray j, updated in place; alive: DEVICE, count bytes
+ * (a guide that misses its optic gets 0 and keeps its state).  The descriptors travel as kernel arguments: count <= 8 per
+ * call (ART_ERR_BAD_ARG beyond; callers loop).  Elements in the Zernike recurrence layout are refused (ART_ERR_UNSUPPORTED:
+ * the guide of such an optic is traced through art_trace_element).                                                       */
+#define ART_GUIDES_MAX 8
+int art_trace_guides(const ArtElementDesc* elems, int32_t count, double* rays, uint8_t* alive, void* stream);
+
+/* Analysis of MANY bundles in four launches and ZERO host round trips (ART/ARTmain.py:248-300 runs, per chain of a loop
+ * list: getETransmission, ART/ModuleAnalysisAndPlots.py:62-77; Detector.autoplace, ART/ModuleDetector.py:109-137;
+ * FindOptimalDistance, ART/ModuleProcessing.py:369-460, or GetResultSummary, ModuleAnalysisAndPlots.py:81-129).  Per job
+ * (= one bundle of n slots; all jobs of a call share n):
+ *   1. sums over the alive rays: count, sum point, sum vector, sum w, sum path;
+ *   2. the detector: given (mode ART_JOB_MANUAL) or placed like Detector.autoplace -- normal = -(mean vector, normalised),
+ *      centre = mean point - normal * distance, refpoint = mean point; its rotation normal -> ez with the reference's
+ *      special cases (ModuleGeometry.py:333-343); the provisional path centre co = mean path + the mean ray's distance
+ *      to the detector (within a fraction of a millimetre of the mean optical path: second moments about it are well
+ *      conditioned, so no pass is spent on finding the exact mean);
+ *   3. ONE pass of read-out moments on that detector: the 32 sums of art_detector_scan_moments (the read-out of every ray
+ *      is linear in a shift s of the detector along its normal, so spot size and duration at ANY s follow from them --
+ *      a whole autofocus search without touching the bundle again), the bounding box of (X, Y) and the range of the
+ *      optical path at s = 0, the largest angle between a ray and the mean vector (ReturnNumericalAperture,
+ *      ModuleProcessing.py:536-566), and the two shifts nearest to 0 at which some ray's hit point passes through its
+ *      origin (there |I - A| has a kink and the linear model ends: callers evaluate scans beyond them position by position).
+ * Jobs with mode ART_JOB_SUMS stop after step 1 (e.g. the source bundle, for the transmission's denominator).
+ * jobs_dev: DEVICE copy of the HOST array jobs_host (the caller's memcpy; jobs_host is read for validation only and must
+ * hold the same contents).  out: DEVICE, n_jobs x ART_ANALYSIS_DOUBLES doubles, job-major:
+ *   [0] count  [1..3] sum point  [4..6] sum vector  [7] sum w (= count if w is NULL)  [8] sum path  [9] 0
+ *   [10..12] detector centre  [13..15] detector normal  [16..18] refpoint (mean point; manual: job.refpoint)  [19] co
+ *   [20..51] the 32 moment sums of art_detector_scan_moments (path centred on co)  [52] 0
+ *   [53] largest shift s <= 0 and [54] smallest shift s > 0 at which a ray's t changes sign (-inf / +inf if none)
+ *   [55] largest angle to the mean vector (rad)
+ *   [56] min X [57] max X [58] min Y [59] max Y [60] min opl [61] max opl   (s = 0; +inf / -inf if nothing is alive)
+ *   [62..63] 0
+ * A job without alive rays gets count 0, NaN detector fields and zero moments.  scratch: DEVICE,
+ * art_analysis_scratch_doubles(n_jobs) doubles.  Deterministic (fixed grids, fixed fold order, no float atomics); the
+ * launches are enqueued on `stream`, nothing returns to the host.                                                        */
+#define ART_ANALYSIS_DOUBLES 64
+enum ArtJobMode { ART_JOB_AUTOPLACE = 0, ART_JOB_MANUAL = 1, ART_JOB_SUMS = 2 };
+typedef struct ArtAnalysisJob {
+  ArtBundleView b;        /* the analysed bundle                                                       */
+  const double* w;        /* DEVICE weights (Ray.intensity) or NULL (w = 1)                            */
+  double distance;        /* ART_JOB_AUTOPLACE: DistanceDetector                                       */
+  int32_t mode;           /* ArtJobMode                                                                */
+  int32_t reserved;
+  double centre[3];       /* ART_JOB_MANUAL: the detector (unit normal, used bit for bit)              */
+  double normal[3];
+  double refpoint[3];
+} ArtAnalysisJob;
+int64_t art_analysis_scratch_doubles(int32_t n_jobs);
+int art_analyse_bundles(const ArtAnalysisJob* jobs_dev, const ArtAnalysisJob* jobs_host, int32_t n_jobs, int64_t n,
+                        double* scratch, double* out, void* stream);
 
 #ifdef __cplusplus
 }

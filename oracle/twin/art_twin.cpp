@@ -208,6 +208,45 @@ int art_cpu_make_extended_source(double radius, double divergence, int64_t n_poi
   return 0;
 }
 
+// guide rays of the placement (art_trace_guides): ray j through element j, in place
+int art_cpu_trace_guides(const ArtElementDesc* elems, int32_t count, double* rays, uint8_t* alive) {
+  for (int j = 0; j < count; ++j) {
+    if (alive[j] == 0) continue;
+    ArtElementDesc e = elems[j];
+    art::prepare_element(e);
+    double* q = rays + 8 * j;
+    art::Ray r = {q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7]};
+    const bool ok = art::trace_ray_dyn<true>(e, e.zern, r);
+    if (ok) { q[0] = r.ox; q[1] = r.oy; q[2] = r.oz; q[3] = r.dx; q[4] = r.dy; q[5] = r.dz; q[6] = r.path; q[7] = r.inc; }
+    alive[j] = ok ? 1 : 0;
+  }
+  return 0;
+}
+
+// detector placement of art_analyse_bundles (art_device.h analysis_place): out = centre(3), normal(3), rot(9), refpoint(3),
+// axis(3), co
+int art_cpu_analysis_place(const double* sums9, int32_t mode, double distance, const double* centre, const double* normal,
+                           const double* refpoint, double* out22) {
+  ArtDetectorDesc d;
+  double ref[3], axis[3], co;
+  art::analysis_place(sums9, mode, distance, centre, normal, refpoint, d, ref, axis, co);
+  for (int k = 0; k < 3; ++k) { out22[k] = d.centre[k]; out22[3 + k] = d.normal[k]; out22[15 + k] = ref[k]; out22[18 + k] = axis[k]; }
+  for (int k = 0; k < 9; ++k) out22[6 + k] = d.rot[k];
+  out22[21] = co;
+  return 0;
+}
+
+int art_cpu_detector_scan_kink(const ArtDetectorDesc* d, const ArtBundleView* b, int64_t n, double* X, double* Y, double* O,
+                               double* sx, double* sy, double* so, double* skink) {
+  for (int64_t i = 0; i < n; ++i) {
+    if (b->alive[i] == 0) continue;
+    art::Ray r;
+    load_ray(*b, i, r);
+    art::detector_ray_scan_kink(*d, r, X[i], Y[i], O[i], sx[i], sy[i], so[i], skink[i]);
+  }
+  return 0;
+}
+
 // test hooks for the scalar helpers of art_device.h (tests/test_device_math.py): n values each
 void art_cpu_kahan_angle_unit(const double* u, const double* v, int64_t n, double* out) {
   for (int64_t i = 0; i < n; ++i)

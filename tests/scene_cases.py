@@ -303,3 +303,113 @@ def run_prefix_sharing():
     s, a = load_golden("c2_fxf_chain00")
     b1, b2 = pc.source_bundle(a, s), pc.source_bundle(a, s)
     assert b1.content_key() != b2.content_key() and b1.copy().content_key() == b1.content_key()
+
+
+def _c3_list(rays, twists):
+    import ART.ModuleMask as mmask
+    import ART.ModuleMirror as mmirror
+    import ART.ModuleProcessing as mp
+    import ART.ModuleSupport as msupp
+    source = dict(Divergence=25e-3, SourceSize=0, Wavelength=50e-6, DeltaFT=0.5, NumberRays=rays)
+    R, r = mmirror.ReturnOptimalToroidalRadii(600, 80)
+    toroid = mmirror.MirrorToroidal(R, r, msupp.SupportRectangle(200, 30))
+    mask = mmask.Mask(msupp.SupportRoundHole(30, 10.25, 0, 0))
+    return source, mp.OEPlacement(source, [mask, toroid, toroid], [500, 100, 600], [0, 80, -80], [0, 0, list(twists)], "C3")
+
+
+def run_list_analysis(rays=3001):
+    """ARTmain.analyse_chain_list (the device analysis of a whole loop list: art_analyse_bundles, blockIdx.y = chain)
+    against (a) ARTmain.run_ART chain by chain -- identical numbers --, (b) the per-ray read-out reduced with NumPy on
+    the host (ART/ModuleDetector.py:191-279 + ART/ModuleProcessing.py:485-532), and (c) its launch / copy budget."""
+    import ARTmain
+    import ART.ModuleProcessing as mp
+    from attosecondraytracing_amd import _lib, analysis
+    twists = np.linspace(-90, 90, 5)
+    source, chains = _c3_list(rays, twists)
+    # the chains of a loop list hold aliases of ONE source: same arrays, bundle objects of their own
+    assert len({ch.source_rays.data.data_ptr() for ch in chains}) == 1 and len({id(ch.source_rays) for ch in chains}) == 5
+    be = _lib.get_backend()
+    for auto in (True, False):
+        SP, DO, AO = ARTmain.complete_defaults(source, dict(ReflectionNumber=-1, ManualDetector=False, DistanceDetector=600,
+                                                            AutoDetectorDistance=auto, OptFor="intensity"),
+                                               dict(verbose=not auto, save_results=False))
+        calls = {"analyse": 0, "other": 0}
+        real = {k: getattr(be, k) for k in ("analyse_bundles", "bundle_sums", "detector_scan_moments", "bundle_max_angle",
+                                            "detector_readout")}
+
+        def counted(name):
+            def f(*a, **k):
+                calls["analyse" if name == "analyse_bundles" else "other"] += 1
+                return real[name](*a, **k)
+            return f
+        for k in real:
+            setattr(be, k, counted(k))
+        try:
+            got = ARTmain.analyse_chain_list(chains, SP, DO, AO)
+        finally:
+            for k in real:
+                delattr(be, k)
+        # ONE call for the whole list, and none of the per-chain reductions it replaces
+        assert calls == {"analyse": 1, "other": 0}, calls
+        _, chains_b = _c3_list(rays, twists)
+        one = [ARTmain.run_ART(ch, SP, DO, AO, True) for ch in chains_b]
+        for (ch, det, tr, spot, dur), (_, det1, tr1, spot1, dur1) in zip(got, one):
+            assert tr == tr1 and spot == spot1 and dur == dur1
+            assert np.array_equal(det.centre, det1.centre) and np.array_equal(det.normal, det1.normal)
+            assert np.array_equal(det.refpoint, det1.refpoint)
+            # against the per-ray read-out on the optimised detector, reduced on the host
+            B = ch.get_output_rays()[-1]
+            w = B.intensities()
+            P = det.get_PointList2DCentre(B)
+            dl = det.get_Delays(B)
+            if auto:    # the autofocus of run_ART is intensity-weighted
+                assert abs(spot - mp.WeightedStandardDeviation(list(P), list(w))) <= 1e-9 * spot
+                assert abs(dur - mp.WeightedStandardDeviation(list(dl), list(w))) <= 1e-7 * dur
+            else:
+                assert abs(spot - mp.StandardDeviation(list(P))) <= 1e-9 * spot
+                assert abs(dur - mp.StandardDeviation(list(dl))) <= 1e-7 * dur
+                assert abs(det.get_distance() - 600) <= 1e-9
+            w_in = ch.source_rays.intensities()
+            assert abs(tr - 100 * w.sum() / w_in.sum()) <= 1e-10 * tr
+    # a manual detector through the same path
+    DOm = dict(DO, ManualDetector=True, DetectorCentre=got[0][1].centre, DetectorNormal=got[0][1].normal, AutoDetectorDistance=False)
+    AOq = dict(AO, verbose=False)
+    man = ARTmain.analyse_chain_list(chains[:1], SP, DOm, AOq)[0]
+    assert np.array_equal(man[1].centre, got[0][1].centre) and abs(man[3] - got[0][3]) <= 1e-12 * got[0][3]
+    # a scan through the last optic (Amplitude = the detector distance): evaluated position by position, like the reference
+    B = chains[2].get_output_rays()[-1]
+    det = got[2][1]
+    D1, s1, t1 = mp.FindOptimalDistance(det, B, "intensity", det.get_distance(), 1, True, False)
+    ana = det._analysis_of(B)
+    assert not ana.linear_over(-det.get_distance(), 0.0) and np.isfinite(s1) and np.isfinite(t1)
+    return got
+
+
+def run_guides():
+    """art_trace_guides (one launch moves the alignment rays of several chains through one element each) against the
+    element kernel, bit for bit, for every optic kind of the 8-element fixture, a dead guide and a missing one."""
+    import torch
+    import ART.ModuleProcessing as mp
+    from attosecondraytracing_amd import _lib
+    from attosecondraytracing_amd.bundle import RayBundle
+    be = _lib.get_backend()
+    s4, a4 = load_golden("c4_mixed8")
+    els = pc.build_elements(s4, a4)
+    src = pc.source_bundle(a4, s4)
+    outs = mp.RayTracingCalculation(src, els)
+    # guide j: a surviving ray in front of element j (slot of the last bundle's first survivor), 11 guides (> 8: two launches)
+    slot = int(outs[-1].index()[0].item())
+    befores = [src] + outs[:-1]
+    pick = [0, 1, 2, 3, 4, 5, 6, 7, 2, 3, 0]
+    rows = torch.stack([befores[k].data[:, slot] for k in pick]).contiguous().clone()
+    alive = torch.ones(len(pick), dtype=torch.uint8, device=rows.device)
+    alive[9] = 0                                             # a guide that is already dead stays dead and untouched
+    rows[10, 3:6] = -rows[10, 3:6]                           # a guide that runs away from its optic misses it
+    before = rows.clone()
+    be.trace_guides([mp.element_descriptor(els[k], True, be)[0] for k in pick], rows, alive)
+    got, al = rows.cpu().numpy(), alive.cpu().numpy()
+    assert list(al) == [1] * 9 + [0, 0]
+    for j, k in enumerate(pick[:9]):
+        ref = outs[k].data[:, slot].cpu().numpy()
+        assert np.array_equal(got[j], ref), (j, k, got[j], ref)
+    assert np.array_equal(got[9], before[9].cpu().numpy(), equal_nan=True) and np.array_equal(got[10], before[10].cpu().numpy(), equal_nan=True)

@@ -124,3 +124,28 @@ def test_bench_gpus_8_over_gloo():
     assert j["value"] > 0 and j["value_full_gather"] > 0
     # the gathered records are the survivors of the whole job: about two thirds of 8 x 1501 rays pass C3's mask
     assert 0.5 * 8 * 1501 < j["config"]["gather_survivors"] < 0.8 * 8 * 1501
+    # which of the two numbers the scaling target is judged on, and the link-rate bound of the other one
+    c = j["config"]
+    assert abs(c["gather_floor_ms"] - c["gather_bytes_per_rank"] / 153e9 * 1e3) <= 1e-9 and "xGMI" in c["gather_floor_note"]
+    assert "the number the >= 6x scaling target is judged on" in p.stderr and "gather_floor_ms" in p.stderr
+
+
+def test_launcher_wall_clock_limit_kills_all_workers():
+    """A rank that hangs (here: before the rendezvous) must not hold the job: the launcher's wall-clock limit ends every
+    worker -- fresh child processes, nothing re-exec'ed -- and the exit code says so."""
+    import time
+    t0 = time.time()
+    p = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--rays", "2000", "--cpu-sample", "0", "--time-limit", "20"],
+             ART_BENCH_BACKEND_HOOK="twin_backend:install_hanging_on_rank_1")
+    assert p.returncode == 4 and time.time() - t0 < 90, (p.returncode, p.stderr[-2000:])
+    assert "exceeded its wall-clock limit" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+
+
+def test_process_group_timeout_ends_a_rank_that_waits_alone():
+    """The collectives' own timeout (--pg-timeout): rank 0 waits in its first collective for a rank that never joins it
+    and gives up with an error instead of waiting for ever."""
+    p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--rays", "1000", "--cpu-sample", "0", "--pg-timeout", "5",
+              "--time-limit", "120"], ART_BENCH_BACKEND_HOOK="twin_backend:install_sleeping_on_rank_1")
+    assert p.returncode == 1, (p.returncode, p.stderr[-2000:])
+    assert not [l for l in p.stdout.splitlines() if l.strip().startswith("{")]

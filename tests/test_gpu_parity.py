@@ -586,30 +586,73 @@ def test_gpu_scene_program_replays(hip):
     scene_cases.run_chain_list_cache()
 
 
-def test_gpu_scene_program_chooses_its_output_placement(hip, monkeypatch):
-    """A program times its own launch into a few candidate allocations of its output bundles and keeps the fastest
-    (graph.SceneProgram._tune_placement): same results as a program that takes the first allocation, bit for bit."""
+def test_gpu_scene_program_placement_look_is_opt_in_and_bounded(hip, monkeypatch):
+    """graph.SceneProgram._tune_placement: off by default; when asked for, the program times its own launch into a few
+    candidate allocations of its output bundles and keeps the fastest (the first one unless another is 3 % faster) --
+    same results bit for bit; a failed allocation or a memory cap ends the look with what there is."""
     import torch
     import bench
     from attosecondraytracing_amd.graph import SceneProgram
     chain, _ = bench.build_scene(3)
     els = chain.optical_elements
-    n = 2_000_000                                        # 3 x 65 B x 2e6 = 390 MB of outputs: above the tuner's threshold
+    n = 2_000_000                                        # 3 x 65 B x 2e6 = 390 MB of outputs: above the look's threshold
     src = bench.device_source(n, 0, n, hip)
-    monkeypatch.setenv("ART_PLACEMENT_TRIES", "4")
-    tuned = SceneProgram([src], [els])
-    assert tuned.placement["tries"] == 4 and len(tuned.placement["launch_ms"]) == 4
-    assert tuned.placement["launch_ms"][tuned.placement["chosen"]] == min(tuned.placement["launch_ms"])
-    monkeypatch.setenv("ART_PLACEMENT_TRIES", "1")
+    monkeypatch.delenv("ART_PLACEMENT_TRIES", raising=False)
     first = SceneProgram([src], [els])
-    assert first.placement is None
-    a, b = tuned.run()[0], first.run()[0]
-    torch.cuda.synchronize()
-    for x, y in zip(a, b):
-        assert x.data.data_ptr() != y.data.data_ptr()
-        assert torch.equal(x.alive, y.alive) and torch.equal(x.data.view(torch.int64), y.data.view(torch.int64))
-    small = SceneProgram([bench.device_source(1000, 0, 1000, hip)], [els])
+    assert first.placement is None                       # default: the first allocation, no look
+    ref = [(b.alive.clone(), b.data.clone()) for b in first.run()[0]]
+
+    def same(prog):
+        outs = prog.run()[0]
+        torch.cuda.synchronize()
+        for (al, da), y in zip(ref, outs):
+            assert torch.equal(al, y.alive) and torch.equal(da.view(torch.int64), y.data.view(torch.int64))
+
+    tuned = SceneProgram([src], [els], placement_tries=4)
+    pl = tuned.placement
+    assert pl["tries"] == 4 and len(pl["launch_ms"]) == 4 and pl["allocation_failed"] is False
+    assert pl["launch_ms"][pl["chosen"]] <= 1.03 * min(pl["launch_ms"]) and pl["gain_vs_first"] >= 1.0
+    assert pl["passes"] in (1, 2)
+    same(tuned)
+    # the environment switch does the same
+    monkeypatch.setenv("ART_PLACEMENT_TRIES", "2")
+    assert SceneProgram([src], [els]).placement["tries"] == 2
+    monkeypatch.delenv("ART_PLACEMENT_TRIES")
+    # a memory cap below one candidate: no look, first block kept
+    monkeypatch.setenv("ART_PLACEMENT_MEM_CAP", "1000000")
+    capped = SceneProgram([src], [els], placement_tries=4)
+    assert capped.placement["tries"] == 1 and capped.placement["chosen"] == 0
+    same(capped)
+    monkeypatch.delenv("ART_PLACEMENT_MEM_CAP")
+    # the third candidate's allocation fails: the look goes on with two
+    real, calls = SceneProgram._alloc_outputs, {"n": 0}
+
+    def failing(self):
+        calls["n"] += 1
+        if calls["n"] >= 3:
+            raise torch.OutOfMemoryError("no room (test)")
+        return real(self)
+
+    monkeypatch.setattr(SceneProgram, "_alloc_outputs", failing)
+    short = SceneProgram([src], [els], placement_tries=4)
+    assert short.placement["tries"] == 2 and short.placement["allocation_failed"] is True
+    same(short)
+    monkeypatch.setattr(SceneProgram, "_alloc_outputs", real)
+    small = SceneProgram([bench.device_source(1000, 0, 1000, hip)], [els], placement_tries=4)
     assert small.placement is None                       # small bundles are not worth the look
+
+
+def test_gpu_list_analysis(hip):
+    """ARTmain.analyse_chain_list on the device (art_analyse_bundles, blockIdx.y = chain): ONE analysis call and one copy
+    back for a whole loop list; identical to run_ART chain by chain; against the per-ray read-out reduced on the host."""
+    import scene_cases
+    scene_cases.run_list_analysis(rays=200_003)
+
+
+def test_gpu_guide_rays(hip):
+    """art_trace_guides == the element kernel bit for bit (the alignment rays of OEPlacement's loop lists)."""
+    import scene_cases
+    scene_cases.run_guides()
 
 
 def test_gpu_loop_list_prefix_sharing(hip):

@@ -284,3 +284,14 @@ def test_lazy_history_is_bit_identical_and_traces_once(twin):
     assert np.array_equal(many[1][-1].points(), full[-1].points()) and np.array_equal(many[0][0].points(), full[0].points())
     with pytest.raises(ValueError):
         mp.RayTracingCalculation(src, els, history="sometimes")
+
+
+def test_list_analysis_on_the_twin(twin):
+    """ARTmain.analyse_chain_list: one device analysis for a whole loop list == run_ART chain by chain == NumPy."""
+    import scene_cases
+    scene_cases.run_list_analysis()
+
+
+def test_guide_rays_on_the_twin(twin):
+    import scene_cases
+    scene_cases.run_guides()

@@ -136,15 +136,49 @@ def _worker(rank, world, port, n_total, q):
         nb = [sg.start(b, r["X"], r["Y"], r["opl"], last.alive) for b in (0, 1, 0)]
         sg.drain()
         counts = [c for c, _ in sg.headers[0]]
-        assert nb[0] == nb[1] == nb[2] == max((16 + (24 if f else 28) * c + 15) // 16 * 16 for c, f in sg.headers[0])
+        exact = max((16 + (24 if f else 28) * c + 15) // 16 * 16 for c, f in sg.headers[0])
+        # the first step reads its own headers (exact size, the one host synchronisation); the following ones are sized
+        # from headers the host already holds, with a margin -- never below what was packed, never above the capacity
+        assert nb[0] == exact and sg.host_syncs == 1 and sg.overflows == 0
+        assert exact <= nb[1] <= sg.cap and exact <= nb[2] <= sg.cap
         assert [f for _, f in sg.headers[0]] == [int(c == sz) for c, sz in zip(counts, sizes)]    # dense iff nothing was lost
         assert sum(counts) < n_total and counts[rank] == int(last.alive.sum())
         surv = sg.assemble(0)
         everyone = torch.ones_like(last.alive)
         nbd = sg.start(1, r["X"], r["Y"], r["opl"], everyone)
         sg.drain()
-        assert [f for _, f in sg.headers[1]] == [1] * world and nbd == 16 + 24 * max(sizes) + (-24 * max(sizes)) % 16
+        # (whatever was predicted at start -- nbd -- the settled size covers the dense records)
+        assert [f for _, f in sg.headers[1]] == [1] * world and sg.nbytes[1] >= 16 + 24 * max(sizes) + (-24 * max(sizes)) % 16 >= 0 * nbd
         dense = sg.assemble(1)
+        # OVERFLOW: a gather sized from a step that lost most of its rays, followed by a step in which every ray survives
+        # (no margin, no slack: the prediction is the previous count).  The shipped size is too small; when that step's
+        # headers are settled the gather is issued again with the exact size -- on both ranks alike -- and the assembled
+        # result is the exact one.  A step that packs LESS than predicted is simply decoded by its own count.
+        few = torch.zeros_like(last.alive)
+        few[::10] = last.alive[::10]
+        tight = sharding.SurvivorGather(_lib.get_backend(), sizes[rank], world, rank, dst=0, buffers=2, specs=specs,
+                                        margin=0.0, slack=0)
+        n0 = tight.start(0, r["X"], r["Y"], r["opl"], few)
+        n1 = tight.start(1, r["X"], r["Y"], r["opl"], few)
+        assert n0 == n1 and tight.host_syncs == 1
+        n2 = tight.start(0, r["X"], r["Y"], r["opl"], everyone)          # predicted from `few`: too small
+        assert n2 == n0 and tight.overflows == 0
+        n3 = tight.start(1, r["X"], r["Y"], r["opl"], last.alive)        # (packs more than `few` as well)
+        tight.drain()
+        assert tight.overflows == 2 and tight.nbytes[0] == 16 + 24 * max(sizes) + (-24 * max(sizes)) % 16
+        over, after = tight.assemble(0), tight.assemble(1)
+        n4 = tight.start(0, r["X"], r["Y"], r["opl"], few)               # predicted from the big step: shrinks again
+        tight.drain()
+        small = tight.assemble(0)
+        assert n4 >= n0 and tight.overflows == 2
+        if rank == 0:
+            assert all(torch.equal(a_, b_) for a_, b_ in zip(over, dense))
+            assert all(torch.equal(a_, b_) for a_, b_ in zip(after, surv))
+            # the survivors of `few`: those of the full step whose slot index within their shard is a multiple of ten
+            offs = torch.tensor([sp[0] for sp in specs])
+            shard_of = torch.bucketize(surv[0], offs[1:], right=True)
+            mask_few = ((surv[0] - offs[shard_of]) % 10 == 0)
+            assert torch.equal(small[0], surv[0][mask_few]) and torch.equal(torch.stack(small[1:]), torch.stack(surv[1:])[:, mask_few])
         if rank == 0:
             assert torch.equal(dense[0], torch.arange(n_total)) and torch.equal(torch.stack(dense[1:]), XYO)
             q.put((stats.numpy(), XYO.numpy(), alive.numpy(), [t.numpy() for t in surv]))

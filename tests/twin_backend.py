@@ -153,6 +153,71 @@ class TwinBackend:
         for ro, last in (getattr(self, "_scene_ro", {}).get(dev_image.data_ptr()) or []):
             self._finish_readout(ro, last, n)
 
+    def trace_guides(self, descs, rays, alive):
+        count = len(descs)
+        darr = (_abi.ArtElementDesc * count)(*descs)
+        f = self.lib.art_cpu_trace_guides
+        f.restype, f.argtypes = C.c_int, [C.POINTER(_abi.ArtElementDesc), C.c_int32, C.c_void_p, C.c_void_p]
+        assert f(darr, count, rays.data_ptr(), alive.data_ptr()) == 0
+
+    def analyse_bundles(self, jobs, n):
+        """Layout of art_analyse_bundles (include/art_hip.h): sums and moments reduced with NumPy, the detector placed
+        by the same art_device.h code as on the device (art_cpu_analysis_place)."""
+        place = self.lib.art_cpu_analysis_place
+        place.restype = C.c_int
+        place.argtypes = [_abi.c_double_p, C.c_int32, C.c_double, _abi.c_double_p, _abi.c_double_p, _abi.c_double_p,
+                          _abi.c_double_p]
+        scan = self.lib.art_cpu_detector_scan_kink
+        scan.restype, scan.argtypes = C.c_int, [C.POINTER(_abi.ArtDetectorDesc), C.POINTER(_abi.ArtBundleView), C.c_int64] + [C.c_void_p] * 7
+        out = np.zeros((len(jobs), _abi.ART_ANALYSIS_DOUBLES))
+
+        def arr(ptr, ty=C.c_double):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ty)), shape=(max(n, 1),))[:n]
+        for j, jb in enumerate(jobs):
+            o = out[j]
+            o[53], o[54] = -np.inf, np.inf
+            o[[56, 58, 60]], o[[57, 59, 61]] = np.inf, -np.inf
+            v = jb.b
+            a = arr(v.alive, C.c_uint8).astype(bool) if n else np.zeros(0, bool)
+            w = arr(jb.w)[a] if (jb.w and n) else np.ones(int(a.sum()))
+            o[0] = a.sum()
+            for k, f_ in enumerate(("ox", "oy", "oz", "dx", "dy", "dz")):
+                o[1 + k] = arr(getattr(v, f_))[a].sum() if n else 0.0
+            o[7] = w.sum()
+            o[8] = arr(v.path)[a].sum() if n else 0.0
+            if jb.mode == _abi.ART_JOB_SUMS:
+                continue
+            if o[0] == 0:
+                o[10:20] = np.nan
+                continue
+            sums9 = (C.c_double * 9)(*o[:9])
+            res = (C.c_double * 22)()
+            assert place(sums9, jb.mode, jb.distance, jb.centre, jb.normal, jb.refpoint, res) == 0
+            res = np.array(res)
+            o[10:13], o[13:16], o[16:19], o[19] = res[0:3], res[3:6], res[15:18], res[21]
+            axis, co = res[18:21], res[21]
+            d = _abi.ArtDetectorDesc()
+            d.centre[:], d.normal[:], d.rot[:] = list(res[0:3]), list(res[3:6]), list(res[6:15])
+            arrs = [np.zeros(n) for _ in range(7)]
+            assert scan(C.byref(d), C.byref(v), n, *[x.ctypes.data for x in arrs]) == 0
+            X, Y, O, sx, sy, so, sk = (x[a] for x in arrs)
+            o[56:62] = [X.min(), X.max(), Y.min(), Y.max(), O.min(), O.max()]
+            o[53] = sk[sk <= 0].max() if (sk <= 0).any() else -np.inf
+            o[54] = sk[sk > 0].min() if (sk > 0).any() else np.inf
+            V = np.stack([arr(v.dx), arr(v.dy), arr(v.dz)], axis=1)[a]
+            u, vn = np.linalg.norm(axis), np.linalg.norm(V, axis=1)[:, None]
+            o[55] = (2 * np.arctan2(np.linalg.norm(axis[None, :] * vn - V * u, axis=1),
+                                    np.linalg.norm(axis[None, :] * vn + V * u, axis=1))).max()
+            O = O - co
+            so = so - 1.0
+            for base, wt in ((0, np.ones_like(w)), (16, w)):
+                o[20 + base] = wt.sum()
+                for k, (q0, sq) in enumerate(((X, sx), (Y, sy), (O, so))):
+                    p_ = 20 + base + 1 + 5 * k
+                    o[p_:p_ + 5] = [(wt * q0).sum(), (wt * sq).sum(), (wt * q0 * q0).sum(), (wt * q0 * sq).sum(),
+                                    (wt * sq * sq).sum()]
+        return torch.from_numpy(out)
+
     def pack_rays(self, points, vectors, path0, n, view):
         f = self.lib.art_cpu_pack_rays
         f.restype = C.c_int
@@ -341,4 +406,23 @@ def install_failing_on_rank_1():
     import os
     if os.environ.get("RANK") == "1":
         raise RuntimeError("rank 1 fails on purpose (launcher test)")
+    return install()
+
+
+def install_hanging_on_rank_1():
+    """Test hook target: rank 1 never gets anywhere (the launcher's wall-clock limit must end the job)."""
+    import os
+    import time
+    if os.environ.get("RANK") == "1":
+        time.sleep(3600)
+    return install()
+
+
+def install_sleeping_on_rank_1():
+    """Test hook target: rank 1 joins the process group but is late for the first collective by far more than the group's
+    timeout (rank 0 must give up with an error, not wait)."""
+    import os
+    import time
+    if os.environ.get("RANK") == "1":
+        time.sleep(60)
     return install()

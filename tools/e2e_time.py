@@ -1,7 +1,11 @@
 """Where the time of the end-to-end C3 workflow (examples/twisted_toroids_large.py) goes: scene construction, the one
-batched trace of all chains, and the per-chain analysis (transmission, detector placement, autofocus), first and second
-pass (the second pass reuses the caching allocator's blocks)."""
-import os, sys, time
+batched trace of all chains, and the analysis of the loop list (transmission, detector placement, autofocus), cold and
+warm pass (the second pass reuses the caching allocator's blocks).
+
+    python tools/e2e_time.py [rays] [batched|lazy|loop] [--profile] [--passes K]
+
+`--profile`: cProfile of the warm pass's construction and analysis (top of the cumulative list)."""
+import cProfile, os, pstats, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
@@ -9,8 +13,11 @@ import ART.ModuleMask as mmask, ART.ModuleMirror as mmirror, ART.ModuleProcessin
 import ART.ModuleOpticalChain as moc
 import ARTmain
 
-rays = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
-how = sys.argv[2] if len(sys.argv) > 2 else "batched"       # batched | lazy (batched, only the analysed bundle written) | loop
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+rays = int(float(args[0])) if len(args) > 0 else 10_000_000
+how = args[1] if len(args) > 1 else "lazy"       # batched | lazy (batched, only the analysed bundle written) | loop
+profile = "--profile" in sys.argv
+passes = int(sys.argv[sys.argv.index("--passes") + 1]) if "--passes" in sys.argv else 3
 batched = how in ("batched", "lazy")
 kw = {"history": "lazy"} if how == "lazy" else {}
 source = dict(Divergence=25e-3, SourceSize=0, Wavelength=50e-6, DeltaFT=0.5, NumberRays=rays)
@@ -20,9 +27,25 @@ mask = mmask.Mask(msupp.SupportRoundHole(30, 10.25, 0, 0))
 SP, DO, AO = ARTmain.complete_defaults(source, dict(ReflectionNumber=-1, ManualDetector=False, DistanceDetector=600,
                                                     AutoDetectorDistance=True, OptFor="intensity"),
                                        dict(verbose=False, save_results=False))
-for rep in range(2):
+
+
+def summary(res):
+    return np.array([[d.get_distance(), t, s, u] for (_, d, t, s, u) in res])
+
+
+def analyse(chains):
+    """The analysis as ARTmain.main runs it: all chains of the list at once where the package offers that."""
+    if hasattr(ARTmain, "analyse_chain_list") and batched:
+        return ARTmain.analyse_chain_list(chains, SP, DO, AO)
+    return [ARTmain.run_ART(ch, SP, DO, AO, True) for ch in chains]
+
+
+for rep in range(passes):
+    pr = cProfile.Profile() if (profile and rep == passes - 1) else None
     t0 = time.perf_counter()
+    if pr: pr.enable()
     chains = mp.OEPlacement(source, [mask, toroid, toroid], [500, 100, 600], [0, 80, -80], [0, 0, np.linspace(-90, 90, 10)], "C3")
+    if pr: pr.disable()
     torch.cuda.synchronize(); t1 = time.perf_counter()
     if batched:
         moc.trace_chain_list(chains, **kw)
@@ -30,8 +53,22 @@ for rep in range(2):
         for ch in chains:
             ch.get_output_rays()
     torch.cuda.synchronize(); t2 = time.perf_counter()
-    res = [ARTmain.run_ART(ch, SP, DO, AO, True) for ch in chains]
+    if pr: pr.enable()
+    res = analyse(chains)
+    if pr: pr.disable()
     torch.cuda.synchronize(); t3 = time.perf_counter()
     print(f"pass {rep} ({'one scene launch' + (', lazy history' if kw else '') if batched else 'chain by chain'}): construction {1e3*(t1-t0):.1f} ms, trace of 10 chains "
           f"{1e3*(t2-t1):.1f} ms, analysis {1e3*(t3-t2):.1f} ms ({1e2*(t3-t2):.2f} ms per chain)", flush=True)
+    if rep == passes - 1:
+        got = summary(res)
+        # the same chains analysed one by one (ARTmain.run_ART): the list analysis must give the same numbers
+        one = summary([ARTmain.run_ART(ch, SP, DO, AO, True) for ch in chains])
+        worst = np.abs(got - one).max(axis=0)
+        print("list analysis vs chain-by-chain run_ART: max |diff| distance %.3g mm, transmission %.3g %%, spot %.3g mm, "
+              "duration %.3g fs" % tuple(worst))
+        assert np.array_equal(got, one), "the list analysis differs from run_ART chain by chain"
+        for row in got:
+            print("   distance %.3f mm  transmission %.2f %%  spot sd %.4g um  duration sd %.4g fs" % (row[0], row[1], 1e3 * row[2], row[3]))
+    if pr:
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
     del chains, res
