@@ -127,18 +127,19 @@ class Detector:
         """What a read-out depends on besides the bundle: the detector plane and the provisional path centre."""
         return (self._centre.tobytes(), self._normal.tobytes(), float(path_centre))
 
-    def readout(self, RayList, points3d=False, sync=True, path_centre=0.0, store=True):
+    def readout(self, RayList, points3d=False, sync=True, path_centre=0.0, store=True, lite=False):
         """One fused pass on the device (art_detector_readout): per-slot tensors 'X', 'Y' (detector-plane coordinates
         about Detector.centre, ART/ModuleDetector.py:212-234), 'opl' (optical path to the detector, :272-275),
         optionally 'P3' (3-D hit points, :191-210), valid where the bundle is alive, and the 24 statistics
         ('stats': host array; with sync=False 'stats_dev', a device tensor, so that nothing blocks the host).
         `path_centre`: provisional centre for the second moments of the path (see include/art_hip.h);
-        store=False skips the per-ray outputs (statistics only)."""
+        store=False skips the per-ray outputs (statistics only); lite=True: the caller needs only count, sum of paths,
+        bounding box and path range of the statistics (a LITE fused read-out, ArtChainReadout.lite, may then be used)."""
         self._iscomplete()
         B = RayList if isinstance(RayList, RayBundle) else RayBundle.from_ray_list(RayList)
         fused = getattr(B, "_fused_readout", None)
         if fused is not None and not points3d and fused[0] == self._readout_key(path_centre) and fused[1] == B.version \
-                and (fused[2]["X"] is not None or not store):
+                and (fused[2]["X"] is not None or not store) and (lite or not fused[2].get("lite")):
             # computed in the launch that traced this bundle (RayTracingCalculation(..., detector=self))
             res = fused[2]
             if sync and "stats" not in res:
@@ -187,13 +188,13 @@ class Detector:
 
     def get_PointList2D(self, RayList):
         """(m,2) detector-plane points, origin at Detector.centre (ART/ModuleDetector.py:212-234)."""
-        r = self.readout(RayList)
+        r = self.readout(RayList, lite=True)
         idx = r["bundle"].index()
         return np.stack([r["X"].index_select(0, idx).cpu().numpy(), r["Y"].index_select(0, idx).cpu().numpy()], axis=1)
 
     def get_PointList2DCentre(self, RayList):
         """(m,2) points centred on their bounding box (ART/ModuleDetector.py:236-252; ModuleGeometry.py:222-245)."""
-        r = self.readout(RayList)
+        r = self.readout(RayList, lite=True)
         s = r["stats"]
         idx = r["bundle"].index()
         cx, cy = (s[3] + s[2]) * 0.5, (s[5] + s[4]) * 0.5
@@ -201,12 +202,12 @@ class Detector:
                          r["Y"].index_select(0, idx).cpu().numpy() - cy], axis=1)
 
     def get_OpticalPaths(self, RayList):
-        r = self.readout(RayList)
+        r = self.readout(RayList, lite=True)
         return r["opl"].index_select(0, r["bundle"].index()).cpu().numpy()
 
     def get_Delays(self, RayList):
         """Delays in fs relative to the mean travel time (ART/ModuleDetector.py:254-279)."""
-        r = self.readout(RayList)
+        r = self.readout(RayList, lite=True)
         s = r["stats"]
         opl = r["opl"].index_select(0, r["bundle"].index()).cpu().numpy()
         return (opl - s[1] / s[0]) / LightSpeed * 1e15

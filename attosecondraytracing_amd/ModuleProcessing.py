@@ -133,7 +133,7 @@ def _attach_readout(bundle, detector, path_centre, res):
 
 
 def RayTracingCalculation(source_rays, optical_elements, IgnoreDefects=True, mode=None, history=True, detector=None,
-                          path_centre=0.0):
+                          path_centre=0.0, readout_lite=False):
     """Propagate `source_rays` through `optical_elements` (ART/ModuleProcessing.py:250-313).
 
     Returns a list with one RayBundle per element: the rays *after* that element, in the lab frame.  Each
@@ -144,7 +144,9 @@ def RayTracingCalculation(source_rays, optical_elements, IgnoreDefects=True, mod
     detector: a placed `Detector` known BEFORE the trace (manual placement, a re-trace, a scan).  Its read-out of the
     last bundle (ART/ModuleDetector.py:191-279) is then computed in the same launch, while every ray is still in
     registers (art_trace_chain_readout): `detector.readout(outs[-1])` and the `get_*` methods find it ready instead of
-    re-reading the bundle.  Same values as the separate read-out (statistics to rounding: another summation order)."""
+    re-reading the bundle.  Same values as the separate read-out (statistics to rounding: another summation order).
+    readout_lite=True: the fused read-out reduces only what `Detector.get_Delays` / `get_PointList2D[Centre]` /
+    `get_OpticalPaths` consume (count, sum of paths, bounding box, path range: 8 of the 22 statistics, no weights)."""
     if isinstance(history, str):
         if history != "lazy":
             raise ValueError("history must be True, False or 'lazy'")
@@ -199,7 +201,7 @@ def RayTracingCalculation(source_rays, optical_elements, IgnoreDefects=True, mod
         ro = None
         if detector is not None and 0 < n <= be.MAX_FUSED_READOUT_RAYS:
             detector._iscomplete()
-            ro = be.new_chain_readout(detector._desc(), src.intensity, n, (0.0, 0.0, path_centre))
+            ro = be.new_chain_readout(detector._desc(), src.intensity, n, (0.0, 0.0, path_centre), lite=readout_lite)
         be.trace_chain(descs, src.view(), views, n, readout=ro)
         if ro is not None:
             _attach_readout(outs[-1], detector, path_centre, ro)
@@ -235,6 +237,9 @@ class LazyHistory:
 
     def __init__(self, source, elements, IgnoreDefects=True, mode=None, detector=None, path_centre=0.0, want=-1, first=None):
         self._src, self._els = _as_bundle(source), list(elements)
+        # what the bundle handed out below was traced through: poses / parameters of the elements (their hashes) and the
+        # source's contents (its version).  A later re-trace for the rest of the history must see the same scene.
+        self._scene_key = (_hash_list_of_objects(self._els), hash(self._src))
         self._opts = (bool(IgnoreDefects), mode, path_centre)
         m = len(self._els)
         self._bundles = [None] * m
@@ -253,6 +258,12 @@ class LazyHistory:
     def _materialise(self):
         if self._full:
             return
+        if (_hash_list_of_objects(self._els), hash(self._src)) != self._scene_key:
+            # the reference's history is computed eagerly and stays valid when the chain is modified afterwards; a lazy one
+            # cannot be completed from a scene that has changed: say so instead of mixing two scenes in one history
+            raise RuntimeError("lazy history: an optical element or the source bundle was modified after this history was "
+                               "handed out; its remaining bundles can no longer be traced.  Ask for the full history "
+                               "(get_output_rays() / history=True) before modifying the chain.")
         self._full = True
         ign, mode, pc_ = self._opts
         full = RayTracingCalculation(self._src, self._els, ign, mode, True, None, pc_)
@@ -264,8 +275,9 @@ class LazyHistory:
             else:
                 # the bundle handed out before stays THE bundle (callers hold it); the full trace must reproduce it
                 live = b.alive.bool()
-                assert torch.equal(have.alive, b.alive) and torch.equal(have.data[:, live].view(torch.int64), b.data[:, live].view(torch.int64)), \
-                    "lazy history: the re-trace differs from the bundle handed out earlier"
+                if not (torch.equal(have.alive, b.alive)
+                        and torch.equal(have.data[:, live].view(torch.int64), b.data[:, live].view(torch.int64))):
+                    raise RuntimeError("lazy history: the re-trace differs from the bundle handed out earlier")
                 have.parent = self._src if k == 0 else self._bundles[k - 1]
         for k in range(1, len(full)):
             if self._bundles[k] is full[k]:

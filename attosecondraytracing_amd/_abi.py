@@ -77,6 +77,8 @@ class ArtChainReadout(C.Structure):
         ("X", C.c_void_p), ("Y", C.c_void_p), ("opl", C.c_void_p),
         ("scratch", C.c_void_p),
         ("out24", C.c_void_p),
+        ("lite", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

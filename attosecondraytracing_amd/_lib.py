@@ -124,9 +124,10 @@ class HipBackend:
 
     MAX_FUSED_READOUT_RAYS = 1 << 28     # one launch (art_trace_chain_readout)
 
-    def new_chain_readout(self, ddesc, w, n, centres=(0.0, 0.0, 0.0), store=True, scratch=None):
+    def new_chain_readout(self, ddesc, w, n, centres=(0.0, 0.0, 0.0), store=True, scratch=None, lite=False):
         """Outputs + descriptor of a read-out fused behind a chain launch (ArtChainReadout): returns a dict with the
-        result tensors 'X', 'Y', 'opl' (None with store=False), 'stats_dev' and the ctypes 'struct'."""
+        result tensors 'X', 'Y', 'opl' (None with store=False), 'stats_dev' and the ctypes 'struct'.  lite=True: only
+        count, sum of paths, bounding box and path range are reduced (ArtChainReadout.lite)."""
         X = Y = opl = None
         if store:
             X, Y, opl = self.empty(n), self.empty(n), self.empty(n)
@@ -139,7 +140,8 @@ class HipBackend:
         ro.cx, ro.cy, ro.co = (float(v) for v in centres)
         ro.X, ro.Y, ro.opl = (None, None, None) if not store else (X.data_ptr(), Y.data_ptr(), opl.data_ptr())
         ro.scratch, ro.out24 = scratch.data_ptr(), out.data_ptr()
-        return {"struct": ro, "X": X, "Y": Y, "opl": opl, "P3": None, "stats_dev": out, "_keep": (w, scratch)}
+        ro.lite = 1 if lite else 0
+        return {"struct": ro, "X": X, "Y": Y, "opl": opl, "P3": None, "stats_dev": out, "_keep": (w, scratch), "lite": bool(lite)}
 
     def chain_readout_scratch(self, n, count):
         """`count` scratch areas for fused read-outs of `count` chains in one scene launch."""

@@ -295,6 +295,45 @@ __device__ __forceinline__ void wave_reduce24(const double (&acc)[kReadoutSlots]
   }
 }
 
+// The LITE tail's reduction: the two sums (rows 0, 1 of pass 0) and pass 2 (minima / maxima) of wave_reduce24; out[1] = 0
+// and the lanes of pass 0's other rows hold 0, so that the partial statistics written behind it have the full layout.
+__device__ __forceinline__ void wave_reduce_lite(const double (&acc)[kReadoutSlots], double* tile, const int l,
+                                                 double (&out)[3]) {
+  const int stat = l >> 3, part = l & 7;
+  __builtin_amdgcn_wave_barrier();
+  tile[0 * kTileStride + l] = acc[0];
+  tile[1 * kTileStride + l] = acc[1];
+  __builtin_amdgcn_wave_barrier();
+  {
+    const double* row = tile + (stat & 1) * kTileStride + part;
+    double v = row[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v += row[8 * k];
+    v += dpp_xchg<0xB1>(v);
+    v += dpp_xchg<0x4E>(v);
+    v += dpp_xchg<0x141>(v);
+    out[0] = (stat < 2) ? v : 0.0;
+  }
+  out[1] = 0.0;
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int g = kPassSlot[2][j];
+    tile[j * kTileStride + l] = (g >= kReadoutSlots) ? INFINITY : ((j >= 3) ? -acc[g] : acc[g]);
+  }
+  __builtin_amdgcn_wave_barrier();
+  {
+    const double* row = tile + stat * kTileStride + part;
+    double v = row[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v = min_raw(v, row[8 * k]);
+    v = min_raw(v, dpp_xchg<0xB1>(v));
+    v = min_raw(v, dpp_xchg<0x4E>(v));
+    v = min_raw(v, dpp_xchg<0x141>(v));
+    out[2] = (stat >= 3) ? -v : v;
+  }
+}
+
 template <int NS>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[NS], const int (&ops)[NS], double* dst) {
   __shared__ double s[kBlock / 64][NS];
@@ -392,6 +431,22 @@ __device__ __forceinline__ void readout_single(double (&acc)[kReadoutSlots], con
   acc[16] = ex * ex; acc[17] = ey * ey; acc[18] = eo * eo;
   acc[19] = ww * ex * ex; acc[20] = ww * ey * ey; acc[21] = ww * eo * eo;
   acc[22] = 0.0; acc[23] = 0.0;
+}
+// LITE tail (ArtChainReadout.lite): count, sum of paths, bounding box and path range only -- 8 of the 22 statistics, no
+// weights.  The other slots read 0.
+__device__ __forceinline__ void readout_single_lite(double (&acc)[kReadoutSlots], const bool live, const double x,
+                                                    const double y, const double o) {
+  acc[0] = live ? 1.0 : 0.0; acc[1] = live ? o : 0.0;
+  acc[2] = live ? x : INFINITY; acc[3] = live ? x : -INFINITY;
+  acc[4] = live ? y : INFINITY; acc[5] = live ? y : -INFINITY;
+  acc[12] = live ? o : INFINITY; acc[13] = live ? o : -INFINITY;
+}
+__device__ __forceinline__ void readout_accumulate_lite(double (&acc)[kReadoutSlots], const bool live, const double x,
+                                                        const double y, const double o) {
+  acc[0] += live ? 1.0 : 0.0; acc[1] += live ? o : 0.0;
+  acc[2] = fmin(acc[2], live ? x : INFINITY); acc[3] = fmax(acc[3], live ? x : -INFINITY);
+  acc[4] = fmin(acc[4], live ? y : INFINITY); acc[5] = fmax(acc[5], live ? y : -INFINITY);
+  acc[12] = fmin(acc[12], live ? o : INFINITY); acc[13] = fmax(acc[13], live ? o : -INFINITY);
 }
 #define ART_READOUT_OPS {RSUM, RSUM, RMIN, RMAX, RMIN, RMAX, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, \
                          RMIN, RMAX, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM}
@@ -557,7 +612,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
     // parked in LDS until the tail needs it -- held in registers across the chain it costs the 2 VGPRs that push the
     // 5-wave build into scratch, and a scratch reload at the end is a VMEM load behind 36 stores (see the tail).
     s_w[lane] = ld_f64(rsrc_of(const_cast<double*>(a.ro.w) + first,
-                                      ((a.flags & art::kFlagReadout) && a.ro.w) ? (unsigned)(n * 8) : 0u), (unsigned)i * 8u);
+                                      ((a.flags & art::kFlagReadout) && a.ro.w && !a.ro.lite) ? (unsigned)(n * 8) : 0u),
+                       (unsigned)i * 8u);
     bool ok = al != 0;
     const double* zk = s_zern;
     // do-while (n_elems >= 1, checked on the host): with a zero-trip path the ray loads above would still be in
@@ -600,9 +656,13 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
 #endif
       // re-read the parked weight through an index the compiler cannot prove equal to the one it was stored with
       // (flags has no bit 30), so that the value is neither kept in a register nor spilled
+      double tot[3];
+      if (a.ro.lite) {     // (wave-uniform: the flag sits in the descriptor)
+        readout_single_lite(acc, ok, x, y, o);
+        wave_reduce_lite(acc, s_red + (lane >> 6) * (8 * kTileStride), lane & 63, tot);
+      } else {
       readout_single(acc, ok, x, y, o, s_w[lane ^ ((unsigned)a.flags >> 30)], a.ro.w != nullptr, a.ro.cx, a.ro.cy,
                      a.ro.co);
-      double tot[3];
 #ifdef ART_DIAG_RO_NOREDUCE  // ... without the wave reduction, ...
       tot[0] = acc[0] + acc[1] + acc[6] + acc[7] + acc[8] + acc[9] + acc[10] + acc[11];
       tot[1] = acc[16] + acc[17] + acc[18] + acc[19] + acc[20] + acc[21];
@@ -610,6 +670,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
 #else
       wave_reduce24(acc, s_red + (lane >> 6) * (8 * kTileStride), lane & 63, tot);
 #endif
+      }
       // One partial per WORKGROUP (round 3; per wave before): the four wave totals meet in LDS behind a bare s_barrier --
       // __syncthreads() would also wait for the acknowledgement of the stores in flight -- and threads 0..21 fold them in
       // wave order and store row `thread` (= pass * 8 + stat, row_of_slot) of the scratch area.  A quarter of the partials:
@@ -669,7 +730,7 @@ __device__ __forceinline__ void chain_body2(const ChainArgs& a, const int64_t fi
     ok[0] = (al2 & 0xffu) != 0;
     ok[1] = (al2 & 0xff00u) != 0;
     const D2 wv = ld_2f64(rsrc_of(const_cast<double*>(a.ro.w) + first,
-                                  ((a.flags & art::kFlagReadout) && a.ro.w) ? (unsigned)(n * 8) : 0u), o16);
+                                  ((a.flags & art::kFlagReadout) && a.ro.w && !a.ro.lite) ? (unsigned)(n * 8) : 0u), o16);
     s_w[0][lane] = wv.a; s_w[1][lane] = wv.b;
     r[0].ox = ox.a; r[0].oy = oy.a; r[0].oz = oz.a; r[0].dx = dx.a; r[0].dy = dy.a; r[0].dz = dz.a; r[0].path = pa.a;
     r[1].ox = ox.b; r[1].oy = oy.b; r[1].oz = oz.b; r[1].dx = dx.b; r[1].dy = dy.b; r[1].dz = dz.b; r[1].path = pa.b;
@@ -708,10 +769,16 @@ __device__ __forceinline__ void chain_body2(const ChainArgs& a, const int64_t fi
     st_2f64(rsrc_of(a.ro.Y + first, a.ro.Y ? nb8 : 0u), off, y[0], y[1]);
     st_2f64(rsrc_of(a.ro.opl + first, a.ro.opl ? nb8 : 0u), off, o[0], o[1]);
     const unsigned li = lane ^ ((unsigned)a.flags >> 30);     // an index the compiler cannot prove equal to the parking one
-    readout_single(acc, ok[0], x[0], y[0], o[0], s_w[0][li], a.ro.w != nullptr, a.ro.cx, a.ro.cy, a.ro.co);
-    readout_accumulate(acc, ok[1], x[1], y[1], o[1], s_w[1][li], a.ro.w != nullptr, a.ro.cx, a.ro.cy, a.ro.co);
     double tot[3];
-    wave_reduce24(acc, s_red + (lane >> 6) * (8 * kTileStride), lane & 63, tot);
+    if (a.ro.lite) {
+      readout_single_lite(acc, ok[0], x[0], y[0], o[0]);
+      readout_accumulate_lite(acc, ok[1], x[1], y[1], o[1]);
+      wave_reduce_lite(acc, s_red + (lane >> 6) * (8 * kTileStride), lane & 63, tot);
+    } else {
+      readout_single(acc, ok[0], x[0], y[0], o[0], s_w[0][li], a.ro.w != nullptr, a.ro.cx, a.ro.cy, a.ro.co);
+      readout_accumulate(acc, ok[1], x[1], y[1], o[1], s_w[1][li], a.ro.w != nullptr, a.ro.cx, a.ro.cy, a.ro.co);
+      wave_reduce24(acc, s_red + (lane >> 6) * (8 * kTileStride), lane & 63, tot);
+    }
     if ((lane & 7) == 0) {
       const int stat = (lane & 63) >> 3, w = lane >> 6;
       s_part[w][stat] = tot[0];
@@ -1132,6 +1199,16 @@ __device__ __forceinline__ double angle_to_axis(const Axis3 ax, double vx, doubl
   return 2.0 * atan2(sqrt(art::dot3(ax_, ay_, az_, ax_, ay_, az_)), sqrt(art::dot3(bx_, by_, bz_, bx_, by_, bz_)));
 }
 
+// tan^2(angle / 2) of the same Kahan pair, |a v - v' u|^2 / |a v + v' u|^2: monotone in the angle, one division instead of
+// two square roots and an atan2 per ray -- for a MAXIMUM over rays the angle itself is formed once, from the largest ratio
+// (k_analysis_fold: 2 atan(sqrt(.))).
+__device__ __forceinline__ double tan2_half_angle_to_axis(const Axis3 ax, double vx, double vy, double vz) {
+  const double u = sqrt(art::dot3(ax.x, ax.y, ax.z, ax.x, ax.y, ax.z)), v = sqrt(art::dot3(vx, vy, vz, vx, vy, vz));
+  const double ax_ = ax.x * v - vx * u, ay_ = ax.y * v - vy * u, az_ = ax.z * v - vz * u;
+  const double bx_ = ax.x * v + vx * u, by_ = ax.y * v + vy * u, bz_ = ax.z * v + vz * u;
+  return art::dot3(ax_, ay_, az_, ax_, ay_, az_) / art::dot3(bx_, by_, bz_, bx_, by_, bz_);
+}
+
 __global__ __launch_bounds__(kBlock) void k_gauss_max_partial(const ArtBundleView b, const Axis3 ax, const int64_t n,
                                                               double* scratch) {
   const int ops[kSumSlots] = {RMAX, RMAX, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM};
@@ -1272,7 +1349,7 @@ __global__ __launch_bounds__(kBlock) void k_analysis_place(const ArtAnalysisJob*
   pl[18] = co;
 }
 
-__global__ __launch_bounds__(kBlock) void k_analysis_moments(const ArtAnalysisJob* __restrict__ jobs, const int64_t n,
+__global__ __launch_bounds__(kBlock, 4) void k_analysis_moments(const ArtAnalysisJob* __restrict__ jobs, const int64_t n,
                                                              const double* place, const double* out, double* scratch) {
   const int j = blockIdx.y;
   const ArtAnalysisJob& jb = jobs[j];
@@ -1304,7 +1381,7 @@ __global__ __launch_bounds__(kBlock) void k_analysis_moments(const ArtAnalysisJo
       acc[39] = fmin(acc[39], q0[2]); acc[40] = fmax(acc[40], q0[2]);
       acc[32] = fmax(acc[32], (sk <= 0.0) ? sk : -INFINITY);
       acc[33] = fmin(acc[33], (sk > 0.0) ? sk : INFINITY);
-      acc[34] = fmax(acc[34], angle_to_axis(ax, r.dx, r.dy, r.dz));
+      acc[34] = fmax(acc[34], tan2_half_angle_to_axis(ax, r.dx, r.dy, r.dz));
       q0[2] -= co;
       sq[2] -= 1.0;
       const double ww = w ? w[i] : 1.0;
@@ -1340,7 +1417,11 @@ __global__ __launch_bounds__(kBlock) void k_analysis_fold(const ArtAnalysisJob* 
     const double v = mine[(int64_t)blk * kAnaMom + q];
     acc[0] = (op == RSUM) ? acc[0] + v : (op == RMIN ? fmin(acc[0], v) : fmax(acc[0], v));
   }
-  block_reduce_store<1>(acc, op1, out + (int64_t)j * ART_ANALYSIS_DOUBLES + ana_mom_slot(q));
+  __shared__ double s_res[1];
+  block_reduce_store<1>(acc, op1, s_res);
+  __syncthreads();
+  // partial 34 carries tan^2(angle / 2) of the ray farthest from the mean direction: the angle is formed here, once
+  if (threadIdx.x == 0) out[(int64_t)j * ART_ANALYSIS_DOUBLES + ana_mom_slot(q)] = (q == 34) ? 2.0 * atan(sqrt(s_res[0])) : s_res[0];
 }
 
 // ------------------------------------------------------------------------------------------- compaction

@@ -53,13 +53,14 @@ class SceneProgram:
     `detector.readout(outputs[c][-1])` returns them).  `post`: optional callable `post(outputs)` captured right behind
     the trace; its return value is `self.post_result`.
 
+    `readout_lite=True`: the fused read-outs reduce only count, sum of paths, bounding box and path range (ArtChainReadout.lite).
     `placement_tries` (default: ART_PLACEMENT_TRIES, else 1 = off): opt-in look at where the output bundles lie, see
     `_tune_placement` below.
 
     Results are bit-identical to `RayTracingCalculation`; the returned bundles are overwritten by the next `run()`."""
 
     def __init__(self, sources, element_lists, IgnoreDefects=True, post=None, capture=True, detectors=None, history=True,
-                 placement_tries=None):
+                 placement_tries=None, readout_lite=False):
         from . import ModuleProcessing as mp
         from . import _abi
         from .bundle import RayBundle
@@ -80,6 +81,7 @@ class SceneProgram:
         self._history = bool(history)
         self._views_in = [s.view() for s in self.sources]
         self._bind(self._alloc_outputs())
+        self._readout_lite = bool(readout_lite)
         self.detectors, self.readouts = None, None
         if detectors is not None and self.n <= self.be.MAX_FUSED_READOUT_RAYS:
             if len(detectors) != self.c:
@@ -216,7 +218,8 @@ class SceneProgram:
             self.readouts = []
             for d, s, area in zip(self.detectors, self.sources, self._ro_scratch):
                 d._iscomplete()
-                self.readouts.append(self.be.new_chain_readout(d._desc(), s.intensity, self.n, scratch=area))
+                self.readouts.append(self.be.new_chain_readout(d._desc(), s.intensity, self.n, scratch=area,
+                                                               lite=self._readout_lite))
         else:
             for d, ro in zip(self.detectors, self.readouts):
                 d._iscomplete()

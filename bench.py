@@ -547,6 +547,10 @@ def worker(args):
     if on_gpu:
         be.count_from = n // 2          # count the full-size launches of the fused kernels from here on (see timed())
     src = device_source(n, first, n_total, be, src_kind, wl, step=stride)
+    if on_gpu:
+        # one launch with an exactly known byte count (49 B per ray read, every slot alive): what tools/summarize_profile.py
+        # calibrates the FETCH_SIZE counter of a profiled run on (k_make_source above does the same for WRITE_SIZE)
+        be.bundle_sums(src.view(), None, n)
     batched = n_chains > 1
     # The whole step (trace + read-outs) is replayed from a HIP graph (graph.SceneProgram, the product's compiled-scene
     # path): small bundles are launch-bound without it, and at 1e7 rays -- where the eager step is GPU-bound on a quiet
@@ -585,8 +589,10 @@ def worker(args):
     inter_per_step_rank = int(entering)
     del outs0
 
+    lite = args.readout == "lite"      # the fused tail with 8 of its 22 statistics (ArtChainReadout.lite): a measurement option
+
     def readouts(outs):
-        return [d.readout(o[-1], sync=False) for d, o in zip(dets, outs)]
+        return [d.readout(o[-1], sync=False, lite=lite) for d, o in zip(dets, outs)]
 
     # the detectors are in place before the timed region, so their read-out rides on the tracing launch (the ray is
     # still in registers: 24 B/ray of outputs instead of a second pass that re-reads 57 B/ray); --readout separate
@@ -595,7 +601,7 @@ def worker(args):
     # C3 3.97 vs 5.14 ms (many chains, a third to a half of the rays stopped by the mask: the fused tail skips them and
     # replaces 10-11 small read-out launches), relay4 0.77 vs 0.80 ms, C4 1.56-1.58 vs 1.64-1.66 ms (behind eight
     # elements the tail used to cost more than the saved re-read; since its instruction count went down it wins there too).
-    fuse = mode == "chain" and args.readout in ("fused", "auto")
+    fuse = mode == "chain" and args.readout in ("fused", "auto", "lite")
     # Python's cyclic collector: a full (generation-2) pass walks the ~1e6 objects that importing torch/numpy leaves
     # behind and stops the host for ~40 ms -- once per run, at an arbitrary step; in a 20-step timed region of 0.8-ms
     # steps that is the difference between 1.6 and 2.1 ms per step (tools/host_timing.py).  Everything alive now is
@@ -608,21 +614,21 @@ def worker(args):
     if batched or use_graph:
         program = SceneProgram([src] * n_chains, element_lists, IgnoreDefects=ignore_defects,
                                post=readouts, capture=use_graph, detectors=dets if fuse else None,
-                               placement_tries=args.placement_tries)
+                               placement_tries=args.placement_tries, readout_lite=lite)
 
     # the same step WITHOUT the intermediate bundles (what ARTmain's lazy history traces: the analysed bundle + its
     # read-out; the rest of the history only when somebody looks at it) -- reported beside `value`, never as `value`
     program_lazy = None
     if (batched or use_graph) and n_elems <= 8 and world == 1:
         program_lazy = SceneProgram([src] * n_chains, element_lists, IgnoreDefects=ignore_defects, post=readouts,
-                                    capture=use_graph, detectors=dets if fuse else None, history=False)
+                                    capture=use_graph, detectors=dets if fuse else None, history=False, readout_lite=lite)
 
     def trace_and_readout_lazy():
         if program_lazy is not None:
             o = program_lazy.run()
             return o, program_lazy.post_result
         o = [mp.RayTracingCalculation(src, element_lists[0], IgnoreDefects=ignore_defects, mode=mode, history=False,
-                                      detector=dets[0] if fuse else None)]
+                                      detector=dets[0] if fuse else None, readout_lite=lite)]
         return o, readouts(o)
 
     def trace_and_readout():
@@ -630,7 +636,7 @@ def worker(args):
             o = program.run()
             return o, program.post_result
         o = [mp.RayTracingCalculation(src, element_lists[0], IgnoreDefects=ignore_defects, mode=mode,
-                                      detector=dets[0] if fuse else None)]
+                                      detector=dets[0] if fuse else None, readout_lite=lite)]
         return o, readouts(o)
 
     # ------------------------------------------------------------------ N > 1 exchanges
@@ -812,14 +818,22 @@ def worker(args):
                            program.placement, note="OPT-IN (--placement-tries): the program allocated `tries` candidate blocks "
                            "for its output bundles, timed its own launch into each (launch_ms) and kept the first unless another "
                            "was 3 % faster; gain_vs_first = launch time in the first block / in the chosen one"),
-                       "readout": "fused into the tracing launch" if fuse else "separate launch",
+                       "readout": ("fused into the tracing launch" + (" (LITE: count, sum of paths, bounding box, path range only)"
+                                                                      if lite else "")) if fuse else "separate launch",
                        "step": "RayTracingCalculation + Detector.readout"
                                + (f" + ONE RCCL all-gather of every shard's 24 statistics and a {sample_k * world}-ray sample "
                                   f"of the read-out, folded on the device" if use_dist else ""),
                        "step_full_gather": None if not use_dist else
                        "the same + ONE RCCL gather of every SURVIVING ray's read-out (number:int32, X, Y, optical path; 28 B "
                        "per survivor, 24 B in shards that lost nothing) to rank 0 in every step, double-buffered behind the "
-                       "next step's tracing (value_full_gather)",
+                       "next step's tracing (value_full_gather); the gather's size is predicted from the counts of two steps "
+                       "earlier (a 16-byte header all-gather per step that nobody waits for), so no step blocks the host: "
+                       "three collectives per step in all (statistics all-gather, header all-gather, payload gather)",
+                       "gather_host_syncs": None if not use_dist else gather.host_syncs,
+                       "gather_overflows": None if not use_dist else gather.overflows,
+                       "gather_host_syncs_note": None if not use_dist else
+                       "steps of this run whose gather read its own headers synchronously (the very first one: nothing to "
+                       "predict from) + gathers re-issued because a shard packed more than predicted",
                        "gather_bytes_per_rank": None if not use_dist else state["gather_bytes"],
                        # one xGMI link per peer into the root (the mesh is point to point): a shard's records cannot
                        # arrive faster than bytes / link rate, whatever the tracing does
@@ -852,17 +866,22 @@ def worker(args):
             defects = any(len(getattr(oe.type, "DeformationList", [])) > 0 for els in element_lists for oe in els)
             # the body is chosen by the library (two rays per lane for chains with a mask): match either name
             tf = "true" if defects else "false"
+            # (the library's rule, csrc/art_kernels.hip chain_rpl(): ART_CHAIN_RPL=1|2, else two rays per lane exactly where a
+            # mask is part of a launch without defects -- used for the LABEL when no profile names the kernel)
+            has_mask = any(oe.type.type == "Mask" for els in element_lists for oe in els)
+            rpl_env = os.environ.get("ART_CHAIN_RPL", "")
+            two = (rpl_env == "2" or (rpl_env != "1" and has_mask)) and not defects
             if program is not None:
-                kprefix, kpat = f"k_trace_scene[2]<{tf}", rf"k_trace_scene2?<{tf}"
+                kprefix, kpat = f"k_trace_scene{'2' if two else ''}<{tf}", rf"k_trace_scene2?<{tf}"
             elif mode == "chain" and (n_elems > 1 or fuse):
-                kprefix, kpat = f"k_trace_chain[2]<{tf}", rf"k_trace_chain2?<{tf}"
+                kprefix, kpat = f"k_trace_chain{'2' if two else ''}<{tf}", rf"k_trace_chain2?<{tf}"
             else:                       # per-element launches; a one-element chain without read-out is that kernel too
                 kprefix, kpat = "k_trace_element<", r"k_trace_element<"
             # profiles/r0N_<config>.json: the configuration as bench runs it by default; the other read-out mode is
             # profiled as r0N_<config>_fused.json / _separate.json
             auto_fuse = True
             base = f"relay{args.mirrors}" if cfg == "relay4" else cfg        # (profiles exist for the 4-mirror headline)
-            pkey = base if fuse == auto_fuse else base + ("_fused" if fuse else "_separate")
+            pkey = (base + "_lite") if lite else (base if fuse == auto_fuse else base + ("_fused" if fuse else "_separate"))
             tr, tr_note = profiled_traffic(pkey, kpat, n)
             # 128 B per intersection, + 88 B per ray of read-out when that rides on the same launch
             algo_bytes = ALGO_BYTES_PER_INTERSECTION * inter_per_launch + (ALGO_BYTES_READOUT * n * n_chains / launches if fuse else 0.0)
@@ -872,7 +891,7 @@ def worker(args):
             # read-out -- and writes, per element, 64 B per LIVE slot (8 fp64 streams; pairs of dead slots are dropped by
             # the range check) + the alive byte of every slot; a fused read-out adds 24 B per surviving ray and 22 doubles
             # per workgroup of partial statistics.  Per-element launches (--mode element) re-read every bundle.
-            has_w = fuse and src.intensity is not None
+            has_w = fuse and src.intensity is not None and not lite
             comp = 0.0
             for lv in live:
                 if mode == "chain" or program is not None:
@@ -1001,9 +1020,10 @@ def main(argv=None):
                     help="replay the step from a HIP graph (auto = on); off: eager launches")
     ap.add_argument("--shard", default="blocks", choices=["blocks", "strided"],
                     help="N > 1: contiguous index ranges per rank (default) or rank r traces rays r, r + N, ...")
-    ap.add_argument("--readout", default="auto", choices=["auto", "fused", "separate"],
+    ap.add_argument("--readout", default="auto", choices=["auto", "fused", "separate", "lite"],
                     help="fused: the detector read-out rides on the tracing launch; separate: its own kernel afterwards; "
-                         "auto (default) = fused")
+                         "auto (default) = fused; lite: fused, but only 8 of the 22 statistics are reduced (what a plain "
+                         "get_Delays / get_PointList2DCentre caller consumes) -- a measurement option, never the default")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="rays of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--placement-tries", type=int, default=1,
                     help="opt-in: let the step's program time its launch into N candidate output allocations and keep the "

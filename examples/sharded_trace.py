@@ -7,8 +7,15 @@ per survivor, one collective (sharding.SurvivorGather) -- and prints the global 
         examples/sharded_trace.py [total_rays]
 (also runs with --nproc-per-node 1)
 """
+import datetime
 import os
 import sys
+
+# Multi-process GPU jobs on this pool need the ROCr runtime's dmabuf IPC: RCCL opens its peers' buffers through
+# hipIpcGetMemHandle / hipIpcOpenMemHandle, which fail with "invalid argument" in the runtime's LEGACY IPC mode as soon as
+# two ranks of one node set up their xGMI transport (bench.py: multi_process_env).  Set before torch initialises HIP;
+# setdefault: an explicit choice in the caller's environment wins.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 import torch
@@ -20,7 +27,8 @@ rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("WORL
 torch.cuda.set_device(local)
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29511")
-dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local),
+                        timeout=datetime.timedelta(seconds=300))      # a rank that never arrives ends the job, not hangs it
 
 import ART.ModuleMask as mmask                      # noqa: E402
 import ART.ModuleMirror as mmirror                  # noqa: E402

@@ -180,6 +180,11 @@ typedef struct ArtChainReadout {
   double* opl;
   double* scratch;       /* DEVICE, art_chain_readout_scratch_doubles(n) doubles                    */
   double* out24;         /* DEVICE, 24 doubles: slot layout of art_detector_readout                 */
+  int32_t lite;          /* 1: only count [0], sum opl [1], bounding box [2..5] and path range [12..13] are formed -- what
+                            Detector.get_Delays / get_PointList2DCentre consume (ART/ModuleDetector.py:236-279); the sums
+                            [6..11] and the second moments [16..21] read 0 and the weights `w` are not touched.  The tail
+                            then costs 8 instead of 22 statistics per ray.  0: all 22 (default)     */
+  int32_t reserved;
 } ArtChainReadout;
 int64_t art_chain_readout_scratch_doubles(int64_t n);
 int art_trace_chain_readout(const ArtElementDesc* elems, int32_t n_elems, const ArtBundleView* in,

@@ -172,7 +172,20 @@ def pose_noise(e):
 # and incidence follow the hit point: an error dP turns the normal of a surface with curvature radius rc by dP / rc and
 # the reflected direction by twice that, so their bar is 5e-12 + 4 dP / rc with the MEASURED dP of the same element
 # (local_dir_tol below): a direction error without a hit-point error behind it fails at 5e-12.
+#
+# FROZEN (round 4): these bars -- LOCAL_TOL 3e-12 / 5e-12 (+ 4 dP / rc for directions and incidences), STRICT_TOL 1e-10
+# with truth adjudication -- are CONTRACT, not tuning parameters.  They followed a measurement four times in rounds 1-3
+# (last: seed 3016796, 1.115e-12 on a toroid, 1e-12 -> 3e-12); from here on an exceedance is a FINDING to be explained and
+# fixed in the kernels (or recorded as a named, explained regression case below), never a reason to move a bar.
+# tests/test_fuzz_differential.py::test_fuzz_bars_are_frozen pins the numbers.
 LOCAL_TOL = {"pos": 3e-12, "dir": 5e-12, "seg": 3e-12, "inc": 5e-12}
+# Seeds that moved a bar or needed the truth to adjudicate in earlier rounds: part of every differential run from now on.
+#   3016796   toroid r = 37 mm under grazing incidence in a 1300-mm scene: local position error 1.115e-12 (the torus
+#             solver's stopping criterion), the case behind the 3e-12 bar
+#   60039358  near-antiparallel frame axes: oracle and kernels 5e-10 apart in every direction, adjudicated by the truth
+#   65        product vs oracle beyond 1e-10 on an ill-conditioned chain, product within the bar of the truth
+#   20797, 23917, 40030221   earlier adjudicated seeds (round 2)
+REGRESSION_SEEDS = (3016796, 60039358, 65, 20797, 23917, 40030221)
 
 
 def curvature_radius(e):

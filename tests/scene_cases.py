@@ -248,6 +248,34 @@ def run_fused_readout():
         ref_out = mp.RayTracingCalculation(srcs[0], els[j])
         same_readout(dets[j].readout(o[-1], sync=False), dets[j].copy_detector().readout(ref_out[-1], sync=False), o[-1].alive)
         assert dets[j].readout(o[-1], sync=False)["X"] is prog.readouts[0]["X"]
+    # the LITE tail (ArtChainReadout.lite): per-ray outputs and the 8 statistics it forms equal the full tail's bit for
+    # bit (same reduction tree), the others read 0; the list-of-survivors API accepts it, a caller of the full statistics
+    # gets a real read-out instead
+    for mode in ("chain", None):
+        full_o = mp.RayTracingCalculation(src, e, detector=D)
+        lite_o = mp.RayTracingCalculation(src, e, detector=D, readout_lite=True)
+        ff, fl = full_o[-1]._fused_readout[2], lite_o[-1]._fused_readout[2]
+        assert fl["lite"] and not ff["lite"]
+        m_ = lite_o[-1].alive.cpu().numpy().astype(bool)
+        for key in ("X", "Y", "opl"):
+            assert np.array_equal(fl[key].cpu().numpy()[m_], ff[key].cpu().numpy()[m_])
+        sl, sf = fl["stats_dev"].cpu().numpy(), ff["stats_dev"].cpu().numpy()
+        for k in (0, 1, 2, 3, 4, 5, 12, 13):
+            assert sl[k] == sf[k], (k, sl[k], sf[k])
+        assert not sl[6:12].any() and not sl[14:].any()
+        calls = []
+        be.detector_readout = lambda *x, **k: calls.append(1) or real(*x, **k)
+        try:
+            assert np.array_equal(D.get_Delays(lite_o[-1]), D.get_Delays(full_o[-1])) and not calls
+            assert np.array_equal(D.get_PointList2DCentre(lite_o[-1]), D.get_PointList2DCentre(full_o[-1])) and not calls
+            st_full = D.readout(lite_o[-1])["stats"]          # all 22 statistics wanted: not what the lite tail formed
+            assert len(calls) == 1 and st_full[16] > 0
+        finally:
+            be.detector_readout = real
+    prog_l = SceneProgram([srcs[0]], [els[0]], detectors=[dets[0]], readout_lite=True)
+    o = prog_l.run()[0]
+    assert prog_l.readouts[0]["lite"] and np.array_equal(dets[0].get_Delays(o[-1]),
+                                                          dets[0].copy_detector().get_Delays(mp.RayTracingCalculation(srcs[0], els[0])[-1]))
     # empty and all-dead bundles: reduction identities
     dead = src.copy()
     dead.alive.zero_()

@@ -26,9 +26,19 @@ def test_fuzz_twin_vs_oracle(twin, block):
 
 
 def test_fuzz_regressions(twin):
-    """Seeds that once failed: 20797 / 23917 = self-intersecting torus with the ray origin inside the inner "lemon"
-    next to its tip, outside the sphere of radius r - R that was wrongly used to bound it."""
-    fz.run_differential([20797, 23917])
+    """Seeds that once failed or moved a bar (fuzz_common.REGRESSION_SEEDS, each named there): 20797 / 23917 =
+    self-intersecting torus with the ray origin inside the inner "lemon" next to its tip, outside the sphere of radius
+    r - R that was wrongly used to bound it; 3016796 = the toroid behind the 3e-12 position bar; 60039358 = near-antiparallel
+    frame axes; 65 = ill-conditioned chain adjudicated by the truth."""
+    fz.run_differential(list(fz.REGRESSION_SEEDS))
+
+
+def test_fuzz_bars_are_frozen():
+    """The bars are contract since round 4 (fuzz_common.py): a new exceedance is a finding, not a tuning input."""
+    import parity_common as pc
+    assert fz.LOCAL_TOL == {"pos": 3e-12, "dir": 5e-12, "seg": 3e-12, "inc": 5e-12}
+    assert fz.STRICT_TOL == {"pos": 1e-10, "dir": 1e-10, "path": 1e-10, "inc": 1e-9} and pc.REL_TOL == 1e-10
+    assert set(fz.REGRESSION_SEEDS) >= {3016796, 60039358, 65}
 
 
 def test_fuzz_detector_readout(twin):

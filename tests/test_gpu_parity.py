@@ -249,7 +249,7 @@ def test_gpu_fuzz_differential(hip):
     """300 random scenes (every optic x aperture kind, arbitrary poses) on the GPU against the pinned oracle."""
     import fuzz_common as fz
     st = {}
-    res = fz.run_differential(list(range(300)) + [20797, 23917, 60039358, 40030221], stats=st)
+    res = fz.run_differential(list(range(300)) + list(fz.REGRESSION_SEEDS), stats=st)     # (seed 65 is in range(300) too)
     assert res["scenes_with_hits"] >= 250, res
     report(f"[gpu fuzz, {st['scenes']} scenes] local error vs long-double truth: " + "  ".join(f"{k} {v:.1e}" for k, v in st["local_worst"].items())
            + f"; adjudicated by truth: seeds {sorted(set(st['adjudicated_seeds']))}, product {st['adjudicated_worst']['product']:.1e} vs oracle "
@@ -745,15 +745,20 @@ def test_gpu_batched_full_size_c2(hip):
         assert 0.4 < len(o[-1]) / 1e6 < 0.6          # SURVEY: C2 1e6 -> 4.9e5
 
 
-def test_gpu_dropped_store_pairs_touch_nothing(hip):
+@pytest.mark.parametrize("rpl", ["1", "2"])
+def test_gpu_dropped_store_pairs_touch_nothing(hip, monkeypatch, rpl):
     """The fused kernels store pairs of neighbouring slots with one 16-byte access and drop a pair of dead rays through
     the range check of the buffer descriptor (offset 2^31).  Output arrays pre-filled with a sentinel: a pair of dead
     slots keeps the sentinel in all eight streams, live slots -- slots 0 and 1 of every stream in particular, where a
-    wrapped-around offset would land -- equal the per-element kernel's 8-byte stores bit for bit."""
+    wrapped-around offset would land -- equal the per-element kernel's 8-byte stores bit for bit.  The ray count is ODD
+    and every row is padded (bundle.RayBundle._rows): the GUARD slots behind the last ray of every stream -- where the
+    second half of the last 16-byte store, or the second byte of a 16-bit alive access, would land -- keep the sentinel
+    too, for both bodies of the fused kernel (one ray per lane / two rays per lane)."""
     import torch
     import ART.ModuleProcessing as mp
     from attosecondraytracing_amd.bundle import RayBundle
     import bench
+    monkeypatch.setenv("ART_CHAIN_RPL", rpl)
     element_lists, _, _ = bench.scene_c3()
     els = element_lists[3]
     n = 100_001
@@ -762,11 +767,14 @@ def test_gpu_dropped_store_pairs_touch_nothing(hip):
     descs = [mp.element_descriptor(oe, True, hip)[0] for oe in els]
     outs = RayBundle.allocate_many(n, len(els), src, hip)
     sentinel = torch.tensor([0x7FF8DEADBEEF0123], dtype=torch.int64, device=hip.device).view(torch.float64)
-    for b in outs:
-        b.data[:] = sentinel
-        b.alive.fill_(7)
+    rows, flags = outs[0].data._base, outs[0].alive._base          # [m, 8, pitch] and [m, pitch]: the whole allocations
+    assert rows.shape[-1] > n and flags.shape[-1] > n               # padded: guard slots exist behind every stream
+    rows[:] = sentinel
+    flags.fill_(7)
     hip.trace_chain(descs, src.view(), [b.view() for b in outs], n)
     torch.cuda.synchronize()
+    assert bool((rows[..., n:].view(torch.int64) == sentinel.view(torch.int64)).all()), "a store landed behind a stream's end"
+    assert bool((flags[..., n:] == 7).all()), "an alive byte landed behind the array's end"
     lost = 0
     for k, (b, r) in enumerate(zip(outs, ref)):
         assert torch.equal(b.alive, r.alive)

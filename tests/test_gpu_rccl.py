@@ -1,6 +1,6 @@
 """GPU (-m gpu): the N > 1 code path of bench.py through RCCL itself.  A test box has ONE GPU, so the process group has
 one rank (ART_FORCE_DIST=1) -- but it is a real `nccl` group on the device: init_process_group, the per-step all-gather
-(statistics + sample, pipelined), the header all-gather and the ONE gather of the survivor records, the stream ordering
+(statistics + sample, pipelined), the header all-gather nobody waits for and the ONE gather of the survivor records, the stream ordering
 between torch's stream and the communicator's, all run as they do at N = 8; only the peers are missing.  Each run is a
 FRESH child process (never a re-exec of the pytest process).  Plus the survivor-record kernel against torch."""
 import json
@@ -36,7 +36,13 @@ def _check_line(j, name):
     # the survivor records: 28 B per surviving ray (24 B when the shard lost nothing), header included
     s = c["gather_survivors"]
     dense = s == c["rays_per_gpu"]
-    assert c["gather_bytes_per_rank"] == (16 + (24 if dense else 28) * s + 15) // 16 * 16
+    exact = (16 + (24 if dense else 28) * s + 15) // 16 * 16
+    roomy = exact if dense else (16 + 28 * min(c["rays_per_gpu"], s + max(1024, s // 16 + 1)) + 15) // 16 * 16
+    # sized from the previous steps' counts with a margin -- never below what was packed; and only the very first gather
+    # of the run read its headers synchronously
+    assert exact <= c["gather_bytes_per_rank"] <= roomy, (exact, c["gather_bytes_per_rank"], roomy)
+    assert c["gather_host_syncs"] == 1 and c["gather_overflows"] == 0
+    assert abs(c["gather_floor_ms"] - c["gather_bytes_per_rank"] / 153e9 * 1e3) < 1e-9
     # parity stays on the N > 1 line
     par = j["parity"]
     assert par["survivor_indices_equal"] and par["delay_max_rel_err"] <= 1e-10 and par["position_max_rel_err"] <= 1e-10

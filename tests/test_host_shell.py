@@ -284,6 +284,17 @@ def test_lazy_history_is_bit_identical_and_traces_once(twin):
     assert np.array_equal(many[1][-1].points(), full[-1].points()) and np.array_equal(many[0][0].points(), full[0].points())
     with pytest.raises(ValueError):
         mp.RayTracingCalculation(src, els, history="sometimes")
+    # a chain that is modified AFTER its lazy history was handed out: the bundle already traced stays what it was, the
+    # rest of the history can no longer be traced from the old scene -- a real exception, not a silently mixed history
+    moved = moc.OpticalChain(src, els)
+    held = moved.get_output_rays(history="lazy")
+    before = held[-1].points()
+    moved.optical_elements[1].shift_along_normal(0.25)
+    with pytest.raises(RuntimeError, match="modified after this history was handed out"):
+        held[0]
+    assert np.array_equal(held[-1].points(), before)
+    fresh = moved.get_output_rays(history="lazy")           # the chain itself re-traces the modified scene
+    assert fresh is not held and not np.array_equal(fresh[-1].points(), before) and len(fresh[0]) == len(full[0])
 
 
 def test_list_analysis_on_the_twin(twin):

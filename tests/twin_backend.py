@@ -68,7 +68,7 @@ class TwinBackend:
 
     MAX_FUSED_READOUT_RAYS = 1 << 28
 
-    def new_chain_readout(self, ddesc, w, n, centres=(0.0, 0.0, 0.0), store=True, scratch=None):
+    def new_chain_readout(self, ddesc, w, n, centres=(0.0, 0.0, 0.0), store=True, scratch=None, lite=False):
         X, Y, opl = (torch.empty(n, dtype=torch.float64) for _ in range(3))     # the twin always computes them
         out = torch.empty(24, dtype=torch.float64)
         ro = _abi.ArtChainReadout()
@@ -77,8 +77,9 @@ class TwinBackend:
         ro.cx, ro.cy, ro.co = (float(v) for v in centres)
         ro.X, ro.Y, ro.opl = X.data_ptr(), Y.data_ptr(), opl.data_ptr()
         ro.scratch, ro.out24 = out.data_ptr(), out.data_ptr()
+        ro.lite = 1 if lite else 0
         return {"struct": ro, "X": X if store else None, "Y": Y if store else None, "opl": opl if store else None,
-                "P3": None, "stats_dev": out, "_keep": (w, X, Y, opl), "_w": w, "_centres": centres}
+                "P3": None, "stats_dev": out, "_keep": (w, X, Y, opl), "_w": w, "_centres": centres, "lite": bool(lite)}
 
     def chain_readout_scratch(self, n, count):
         return [None] * count
@@ -95,6 +96,9 @@ class TwinBackend:
         ex, ey, eo = X.numpy()[a] - c[0], Y.numpy()[a] - c[1], O.numpy()[a] - c[2]
         out[16:22] = [(ex ** 2).sum(), (ey ** 2).sum(), (eo ** 2).sum(), (ww * ex ** 2).sum(), (ww * ey ** 2).sum(),
                       (ww * eo ** 2).sum()]
+        if ro.get("lite"):          # ArtChainReadout.lite: only count, sum of paths, bounding box, path range
+            out[6:12] = 0.0
+            out[16:22] = 0.0
         ro["stats_dev"].copy_(torch.from_numpy(out))
 
     def trace_chain(self, descs, vin, vouts, n, readout=None):

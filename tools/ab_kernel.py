@@ -7,7 +7,8 @@ runs of the same build differ by up to 6 % in kernel time on this pool).
     python tools/ab_kernel.py [--config relay4|C2|C3|C4] [--rounds 12] [--launches 20] [--readout fused|none]
                               [--variants "ART_CHAIN_RPL=1;ART_CHAIN_RPL=2 ART_CHAIN_WAVES=4;LIB=build/variants/libart_x.so"]
 (`LIB=path`: a diagnostic BUILD of the library, loaded beside the default one; its results may be wrong by design;
- `RO=none|fused`: the read-out of this variant)
+ `RO=none|fused|lite`: the read-out of this variant; lite = the fused tail with 8 instead of 22 statistics,
+ ArtChainReadout.lite -- single chains only)
 Prints per variant the median / min of the per-round mean launch time and the ratio to the first variant."""
 import argparse
 import os
@@ -64,8 +65,9 @@ def main():
         if many:
             return mp.RayTracingCalculationMany([src] * len(element_lists), element_lists, IgnoreDefects=ign,
                                                 detectors=dets if fused else None)
+        lite = state["readout"] == "lite"
         return mp.RayTracingCalculation(src, element_lists[0], IgnoreDefects=ign, mode=args.mode,
-                                        detector=dets[0] if fused else None)
+                                        detector=dets[0] if (fused or lite) else None, readout_lite=lite)
 
     variants = [v.strip() for v in args.variants.split(";")]
     knobs = sorted({kv.split("=")[0] for v in variants for kv in v.split() if "=" in kv} - {"LIB", "RO"})

@@ -97,6 +97,7 @@ def main():
         rg = regs.get(k, ("?", "?", big[0][4], "?"))
         out.append(f"| {k} | {len(d)} | {sum(d)/len(d)/1e3:.1f} | {min(d)/1e3:.1f} | {max(d)/1e3:.1f} | {g} | {rg[0]} | {rg[1]} | {rg[2]} | {rg[3]} |")
     out.append("")
+    timed_stat = {}
     # the timed region: bench.py reports which of its full-size fused-kernel launches lie inside it
     # (roofline.timed_region_launches, in issue order); cut the trace to them
     try:
@@ -108,6 +109,15 @@ def main():
         full = [t for t in fused if t[2] >= gmax // 2]     # full-size launches (the two-ray body's grid is half a one-ray grid)
         cut = [t[1] for t in full[lo:hi]]
         if cut and hi <= len(full):
+            # per kernel name: average duration of ITS launches inside the timed region (what the byte counts below, cut to
+            # the same launches of their own passes, are divided by)
+            named = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["Grid_Size_X"]),
+                            short(r["Kernel_Name"])) for r in rows if short(r["Kernel_Name"]).startswith(("k_trace_chain", "k_trace_scene"))),
+                           key=lambda t: t[0])
+            named = [t for t in named if t[2] >= gmax // 2][lo:hi]
+            for k in {t[3] for t in named}:
+                d = [t[1] for t in named if t[3] == k]
+                timed_stat[k] = (len(d), sum(d) / len(d))
             out.append(f"timed region of this pass (launches {lo}..{hi - 1} of {len(full)} full-size fused launches, "
                        f"`roofline.timed_region_launches`): average {sum(cut)/len(cut)/1e3:.1f} us, first {cut[0]/1e3:.1f}, "
                        f"max {max(cut)/1e3:.1f}, last {cut[-1]/1e3:.1f} us -- the clock ramp of the driver's protocol (DESIGN.md 5); "
@@ -156,23 +166,32 @@ def main():
     fe, wr = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
     out += ["## HBM traffic per launch (`--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separate passes)", "",
             "(fused kernels: averaged over the launches inside the timed region of each pass -- " + "; ".join(cut_note.values()) + ")", ""]
+    # (bench.py launches k_bundle_sums_partial once on its all-alive source bundle for exactly this calibration)
     cal_r = fe.get("k_bundle_sums_partial", 0) / (49.0 * n) if fe.get("k_bundle_sums_partial") else None
     cal_w = wr.get("k_make_source", 0) / (65.0 * n) if wr.get("k_make_source") else None
     out.append(f"calibration on known byte counts ({n} rays): FETCH_SIZE/true read bytes = "
                f"{cal_r if cal_r is None else round(cal_r, 4)} (k_bundle_sums_partial, 49 B/ray; guide says 0.5 on gfx950), "
                f"WRITE_SIZE/true written bytes = {cal_w if cal_w is None else round(cal_w, 4)} (k_make_source, 65 B/ray).")
-    out += ["", "| kernel | FETCH_SIZE raw MB | read MB (x2 gfx950 correction) | WRITE_SIZE MB | total MB | avg us (trace pass) | HBM GB/s |",
-            "|---|---:|---:|---:|---:|---:|---:|"]
+    out += ["", "Durations and bytes of one row come from the SAME launches: for the fused kernels those inside the timed region of "
+            "each pass (`avg us, timed region`; `HBM GB/s` and `frac` = total MB / that time / 8000 GB/s -- the figure bench.py's "
+            "`roofline` is to be compared with); the average over ALL launches of the trace pass (lazy-history steps, warm-up, "
+            "event-bracketed passes included) is kept beside it for reference only.", "",
+            "| kernel | FETCH_SIZE raw MB | read MB (x2 gfx950 correction) | WRITE_SIZE MB | total MB | avg us, timed region | HBM GB/s | frac of 8 TB/s | avg us, all launches |",
+            "|---|---:|---:|---:|---:|---:|---:|---:|---:|"]
+    traffic = {}
     for k in fe:
         if k not in stat or fe[k] + wr.get(k, 0) < 5e6:
             continue
         rd = 2.0 * fe[k]
         w = wr.get(k, 0.0)
-        us = stat[k][1] / 1e3
-        out.append(f"| {k} | {fe[k]/1e6:.1f} | {rd/1e6:.1f} | {w/1e6:.1f} | {(rd+w)/1e6:.1f} | {us:.1f} | {(rd+w)/us/1e3:.0f} |")
+        us_all = stat[k][1] / 1e3
+        us = timed_stat[k][1] / 1e3 if k in timed_stat else us_all
+        gbs = (rd + w) / us / 1e3
+        out.append(f"| {k} | {fe[k]/1e6:.1f} | {rd/1e6:.1f} | {w/1e6:.1f} | {(rd+w)/1e6:.1f} | {us:.1f} | {gbs:.0f} | {gbs/8000.0:.3f} | {us_all:.1f} |")
+        traffic[k] = {"read_bytes": rd, "write_bytes": w, "total_bytes": rd + w, "avg_us_timed_region": us,
+                      "hbm_gbs_timed_region": gbs, "frac_timed_region": gbs / 8000.0, "avg_us_all_launches": us_all,
+                      "cut_to_timed_region": k in timed_stat}
     out.append("")
-    traffic = {k: {"read_bytes": 2.0 * fe[k], "write_bytes": wr.get(k, 0.0), "total_bytes": 2.0 * fe[k] + wr.get(k, 0.0),
-                   "avg_us_trace_pass": stat[k][1] / 1e3} for k in fe if k in stat and fe[k] + wr.get(k, 0) >= 5e6}
     box = None
     bs = os.path.join(src, "box_state.txt")
     if os.path.exists(bs):
