@@ -604,7 +604,7 @@ def worker(args):
     fuse = mode == "chain" and args.readout in ("fused", "auto", "lite")
     # Python's cyclic collector: a full (generation-2) pass walks the ~1e6 objects that importing torch/numpy leaves
     # behind and stops the host for ~40 ms -- once per run, at an arbitrary step; in a 20-step timed region of 0.8-ms
-    # steps that is the difference between 1.6 and 2.1 ms per step (tools/host_timing.py).  Everything alive now is
+    # steps that is the difference between 1.6 and 2.1 ms per step (profiles/HISTORY.md, round 2).  Everything alive now is
     # moved to the permanent generation; the steps themselves create no reference cycles.  Done HERE, before the step's
     # programs are built, so that the device is not left idle for those ~50 ms right in front of the warm-up steps.
     import gc
@@ -742,7 +742,7 @@ def worker(args):
 
     # The contract's region above starts W steps after an idle device.  An MI355X needs ~40 ms of load to reach its
     # sustained clocks: 20 timed steps after 5 warm-up steps run at 0.80 ms, after 50 at 0.72, after 200 at 0.69
-    # (round-2 batch 11; tools/ramp_probe.py).  `value` stays what the contract defines; the SAME K steps timed again once the device has
+    # (round-2 batch 11, profiles/HISTORY.md).  `value` stays what the contract defines; the SAME K steps timed again once the device has
     # been busy for SETTLE_SECONDS are reported beside it as `value_sustained`.
     dt_sus = kernel_ms_sus = None
     if on_gpu:
