@@ -35,10 +35,11 @@ def trace_chain_list(chains, **kwargs):
 
 class OpticalChain:
     def __init__(self, source_rays, optical_elements, description="", loop_variable_name=None,
-                 loop_variable_value=None, *, _alias_source=False):
-        # _alias_source (OEPlacement's loop lists): this chain's source is a bundle object of its own over the SAME device
-        # arrays as the other chains' (bundle.RayBundle.alias) instead of a private copy of 65 bytes per ray
-        self.source_rays = source_rays.alias() if _alias_source else copy.deepcopy(source_rays)
+                 loop_variable_value=None, *, _placed=False):
+        # _placed (OEPlacement's loop lists): this chain's source is a bundle object of its own over the SAME device arrays
+        # as the other chains' (bundle.RayBundle.alias) instead of a private copy of 65 bytes per ray.  The elements are
+        # deep-copied either way, as in the reference: the chains of a list share their optic objects until here.
+        self.source_rays = source_rays.alias() if _placed else copy.deepcopy(source_rays)
         self.optical_elements = copy.deepcopy(optical_elements)
         self.description = description
         self.loop_variable_name = loop_variable_name

@@ -21,7 +21,7 @@ ART_ZERN_RECURRENCE_MAX_ORDER = 64
 ART_ZERN_MAX_ORDER = 16
 ART_ZERN_DIM = ART_ZERN_MAX_ORDER + 1
 ART_ZERN_STRIDE = 2 + 3 * ART_ZERN_DIM * ART_ZERN_DIM
-ART_MAX_DEFECTS = 4
+ART_MAX_DEFECTS = 16
 
 c_double_p = C.POINTER(C.c_double)
 c_uint8_p = C.POINTER(C.c_uint8)

@@ -480,7 +480,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_element(const ElemArg ea, cons
   const ArtElementDesc& e = ea.e[blockIdx.y];
   const double* zern = e.zern;
 #ifdef ART_ZERN_LDS
-  __shared__ double s_zern[DEFECT ? ART_MAX_DEFECTS * ART_ZERN_STRIDE : 2];
+  __shared__ double s_zern[DEFECT ? 4 * ART_ZERN_STRIDE : 2];   // (comparison build: at most 4 tables per element)
   if (DEFECT) {
     stage_tables(e.zern, s_zern, e.n_defects * ART_ZERN_STRIDE);
     __syncthreads();
@@ -1626,6 +1626,9 @@ int check_elem(const ArtElementDesc* e) {
   if (e->kind < 0 || e->kind >= ART_NUM_KINDS) return fail(ART_ERR_BAD_ARG, "unknown optic kind");
   if (e->support_kind < 0 || e->support_kind > ART_SUP_RECTRECTHOLE) return fail(ART_ERR_BAD_ARG, "unknown support kind");
   if (e->n_defects < 0 || e->n_defects > ART_MAX_DEFECTS) return fail(ART_ERR_UNSUPPORTED, "too many defects on one mirror");
+#ifdef ART_ZERN_LDS
+  if (e->n_defects > 4) return fail(ART_ERR_UNSUPPORTED, "ART_ZERN_LDS comparison build: at most 4 Zernike tables per element");
+#endif
   if (e->n_defects > 0 && e->kind == ART_MASK) return fail(ART_ERR_BAD_ARG, "a mask cannot carry defects");
   if (e->n_defects > 0 && !e->zern) return fail(ART_ERR_BAD_ARG, "n_defects > 0 but zern table is NULL");
   if (e->n_grid < 0 || e->n_grid > ART_MAX_DEFECTS) return fail(ART_ERR_UNSUPPORTED, "too many gridded defects on one mirror");

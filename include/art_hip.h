@@ -81,7 +81,7 @@ enum ArtSupportKind {
 #define ART_ZERN_MAX_ORDER 16
 #define ART_ZERN_DIM (ART_ZERN_MAX_ORDER + 1)                      /* 17 */
 #define ART_ZERN_STRIDE (2 + 3 * ART_ZERN_DIM * ART_ZERN_DIM)      /* 869 */
-#define ART_MAX_DEFECTS 4
+#define ART_MAX_DEFECTS 16   /* tables (Zernike: one per normalisation radius) / height maps per mirror; the kernels loop */
 
 /* Gridded height-map defect (ART/ModuleDefects.py `Fourrier` :69-146; offset lookup :131-137 through SciPy's
  * RegularGridInterpolator(method="linear")): h[ix * ny + iy] on the regular grid x = x0 + ix*dx, y = y0 + iy*dy,

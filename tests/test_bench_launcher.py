@@ -111,6 +111,23 @@ def test_profile_of_another_build_is_dropped(monkeypatch):
     assert len(sh.__dict__["FILES"]) == 4 and all(os.path.exists(os.path.join(ROOT, f)) for f in sh.FILES)
 
 
+def test_masked_configurations_find_their_profile(monkeypatch):
+    """C2 / C3 contain a mask, so the library launches the two-rays-per-lane body (k_trace_scene2<false, 4>): the bench
+    line's kernel pattern must match that name in the committed profile of the same build."""
+    import glob
+    sys.path.insert(0, ROOT)
+    import bench
+    import tools.source_hash as sh
+    for cfg in ("C2", "C3"):
+        profs = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{cfg}.json")))
+        assert profs, f"no committed {cfg} profile"
+        newest = json.load(open(profs[-1]))
+        assert any(k.startswith("k_trace_scene2<false") for k in newest["per_launch"]), list(newest["per_launch"])
+        monkeypatch.setattr(sh, "source_hash", lambda root=None, h=newest["source_hash"]: h)
+        hit, note = bench.profiled_traffic(cfg, r"k_trace_scene2?<false", newest["rays_per_gpu"])
+        assert hit is not None and hit[2].startswith("k_trace_scene2<false") and hit[0] > 1e8 and note is None
+
+
 def test_bench_gpus_8_over_gloo():
     """The driver's largest case, rehearsed with CPU ranks: eight ranks (an odd ray count per rank, strided shards of a
     masked loop-list scene), every rank in the all-gather and in the ONE survivor gather."""

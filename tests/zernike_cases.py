@@ -7,13 +7,14 @@ import pytest
 from oracle import art_oracle as orc
 
 
-def _scene(coeff_dicts, support_R=20.0):
+def _scene(coeff_dicts, support_R=20.0, radii=None):
+    """radii: one normalisation radius per defect (each defined on a round support of its own), default the mirror's."""
     import ART.ModuleDefects as mdef
     import ART.ModuleMirror as mmirror
     import ART.ModuleSupport as msupp
     import ART.ModuleOpticalElement as moe
     S = msupp.SupportRound(support_R)
-    Zs = [mdef.Zernike(S, c) for c in coeff_dicts]
+    Zs = [mdef.Zernike(S if radii is None else msupp.SupportRound(radii[k]), c) for k, c in enumerate(coeff_dicts)]
     M = mmirror.MirrorSpherical(500, S)
     oe = moe.OpticalElement(mmirror.DeformedMirror(M, Zs), np.array([0.0, 0.0, 100.0]), np.array([0.1, 0.0, -1.0]),
                             np.array([1.0, 0.0, 0.1]))
@@ -89,4 +90,12 @@ def run_high_order():
     res["7 defects, one above order 16"] = _compare(*_scene(many + [{(18, 4): 1e-5}]))
     with pytest.raises(NotImplementedError):
         mdef.Zernike(msupp.SupportRound(20), {(_abi.ART_ZERN_RECURRENCE_MAX_ORDER + 1, 3): 1e-5})
+    # six defects with six DIFFERENT normalisation radii: one table each (more than the 4 of rounds 1-3; the reference
+    # takes any list, ART/ModuleMirror.py:945-961)
+    assert _abi.ART_MAX_DEFECTS >= 16
+    six = [{(2 + k % 3, k % 2): 2e-5 * (k + 1), (4, 2): 1e-6 * k} for k in range(6)]
+    oe, Eo = _scene(six, radii=[20.0 + k for k in range(6)])
+    d, _ = __import__("ART.ModuleProcessing", fromlist=["x"]).element_descriptor(oe, False)
+    assert d.n_defects == 6
+    res["6 radii"] = _compare(oe, Eo)
     return res
