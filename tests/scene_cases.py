@@ -441,3 +441,39 @@ def run_guides():
         ref = outs[k].data[:, slot].cpu().numpy()
         assert np.array_equal(got[j], ref), (j, k, got[j], ref)
     assert np.array_equal(got[9], before[9].cpu().numpy(), equal_nan=True) and np.array_equal(got[10], before[10].cpu().numpy(), equal_nan=True)
+
+
+def run_lockstep_placement():
+    """OEPlacement with a list-valued argument places its chains in lockstep (one guide-ray launch per optic for all
+    chains): the same poses, bit for bit, as placing every value alone; 11 chains (two guide launches of <= 8 rays), a
+    mask in front (its open stand-in is traced too) and a convex mirror among the optics."""
+    import ART.ModuleMask as mmask
+    import ART.ModuleMirror as mmirror
+    import ART.ModuleProcessing as mp
+    import ART.ModuleSupport as msupp
+    source = dict(Divergence=25e-3, SourceSize=0, Wavelength=50e-6, DeltaFT=0.5, NumberRays=500)
+    R, r = mmirror.ReturnOptimalToroidalRadii(500, 80)
+    tor = mmirror.MirrorToroidal(R, r, msupp.SupportRectangle(150, 32))
+    mask = mmask.Mask(msupp.SupportRoundHole(20, 7, 0, 0))
+    cx = mmirror.MirrorSpherical(-4000, msupp.SupportRound(40))
+    optics = [mask, tor, cx, tor]
+    for which, values in (("distance", np.linspace(300, 700, 11).tolist()), ("incidence", [70.0, 75.0, 80.0]), ("incplane", [0.0, 45.0, 180.0])):
+        dist_, inc, plane = [400, 100, 250, 300], [0, 80, 10, -80], [0, 0, 30, 0]
+        lists = {"distance": dist_, "incidence": inc, "incplane": plane}
+        lists[which][3] = list(values)
+        chains = mp.OEPlacement(source, optics, dist_, inc, plane, "lockstep")
+        assert len(chains) == len(values)
+        for ch, x in zip(chains, values):
+            d1, i1, p1 = list(dist_), list(inc), list(plane)
+            {"distance": d1, "incidence": i1, "incplane": p1}[which][3] = x
+            one = mp.OEPlacement(source, optics, d1, i1, p1, "alone")
+            assert ch.loop_variable_value == x
+            for a, b in zip(ch.optical_elements, one.optical_elements):
+                for f in ("position", "normal", "majoraxis"):
+                    assert np.array_equal(np.asarray(getattr(a, f), float), np.asarray(getattr(b, f), float)), (which, x, f)
+            assert ch.source_rays.content_key() == one.source_rays.content_key()
+    # elements are private to every chain (deep-copied as in the reference): moving one chain's mirror leaves the others alone
+    before = np.array(chains[1].optical_elements[1].position, dtype=float)
+    chains[0].optical_elements[1].shift_along_normal(1.0)
+    assert np.array_equal(np.asarray(chains[1].optical_elements[1].position, float), before)
+    assert chains[0].optical_elements[1].type is not chains[1].optical_elements[1].type

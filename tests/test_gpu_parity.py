@@ -655,6 +655,12 @@ def test_gpu_guide_rays(hip):
     scene_cases.run_guides()
 
 
+def test_gpu_lockstep_placement(hip):
+    """OEPlacement's loop lists placed in lockstep (art_trace_guides) == every value placed alone, bit for bit."""
+    import scene_cases
+    scene_cases.run_lockstep_placement()
+
+
 def test_gpu_loop_list_prefix_sharing(hip):
     """Loop lists from OEPlacement share the trace of their common prefix (mask + first toroid in C2 / C3)."""
     import scene_cases

@@ -306,3 +306,8 @@ def test_list_analysis_on_the_twin(twin):
 def test_guide_rays_on_the_twin(twin):
     import scene_cases
     scene_cases.run_guides()
+
+
+def test_lockstep_placement_on_the_twin(twin):
+    import scene_cases
+    scene_cases.run_lockstep_placement()
