@@ -477,3 +477,40 @@ def run_lockstep_placement():
     chains[0].optical_elements[1].shift_along_normal(1.0)
     assert np.array_equal(np.asarray(chains[1].optical_elements[1].position, float), before)
     assert chains[0].optical_elements[1].type is not chains[1].optical_elements[1].type
+
+
+def run_list_analysis_edges():
+    """analyse_chain_list beyond the plain loop list: an inner bundle analysed (ReflectionNumber = 1), chains with
+    different sources (a source loop list), different ray counts in one list, a chain whose analysed bundle is empty."""
+    import ARTmain
+    import ART.ModuleProcessing as mp
+    import ART.ModuleOpticalChain as moc
+    source, chains = _c3_list(2001, [-30.0, 40.0])
+    SP, DO, AO = ARTmain.complete_defaults(source, dict(ReflectionNumber=1, ManualDetector=False, DistanceDetector=100,
+                                                        AutoDetectorDistance=False, OptFor="intensity"),
+                                           dict(verbose=False, save_results=False))
+    got = ARTmain.analyse_chain_list(chains, SP, DO, AO)
+    for (ch, det, tr, spot, dur) in got:
+        B = ch.get_output_rays()[1]                                     # the bundle behind the first toroid
+        assert abs(det.get_distance() - 100) <= 1e-9
+        assert abs(spot - mp.StandardDeviation(list(det.get_PointList2DCentre(B)))) <= 1e-9 * spot
+        assert abs(tr - 100 * B.intensities().sum() / ch.source_rays.intensities().sum()) <= 1e-10 * tr
+        assert np.allclose(det.refpoint, B.points().mean(axis=0), rtol=0, atol=1e-9)
+    # a source loop list (every chain its own source) + a chain with another ray count in the same list
+    DO["ReflectionNumber"] = -1
+    DO["DistanceDetector"] = 600
+    tilted = chains[0].get_source_loop_list("tilt_in_plane", [0.0, 0.01])
+    _, other = _c3_list(777, [10.0])
+    mixed = tilted + other
+    res = ARTmain.analyse_chain_list(mixed, SP, DO, AO)
+    for (ch, det, tr, spot, dur), alone in zip(res, [ARTmain.run_ART(c.copy_chain(), SP, DO, AO) for c in mixed]):
+        assert tr == alone[2] and spot == alone[3] and dur == alone[4]
+    assert len({r[0].source_rays.n_slots for r in res}) == 2
+    # nothing reaches the detector: the reference fails on the mean of an empty list; here the Detector's own TypeError
+    dead = chains[1].copy_chain()
+    dead.optical_elements[1].shift_along_major(1000.0)                  # the first toroid is no longer under the beam
+    try:
+        ARTmain.analyse_chain_list([dead], SP, DO, AO)
+        raise AssertionError("an empty bundle was analysed")
+    except TypeError as e:
+        assert "Detector Normal" in str(e)

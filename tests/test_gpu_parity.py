@@ -649,6 +649,11 @@ def test_gpu_list_analysis(hip):
     scene_cases.run_list_analysis(rays=200_003)
 
 
+def test_gpu_list_analysis_edges(hip):
+    import scene_cases
+    scene_cases.run_list_analysis_edges()
+
+
 def test_gpu_guide_rays(hip):
     """art_trace_guides == the element kernel bit for bit (the alignment rays of OEPlacement's loop lists)."""
     import scene_cases

@@ -303,6 +303,11 @@ def test_list_analysis_on_the_twin(twin):
     scene_cases.run_list_analysis()
 
 
+def test_list_analysis_edges_on_the_twin(twin):
+    import scene_cases
+    scene_cases.run_list_analysis_edges()
+
+
 def test_guide_rays_on_the_twin(twin):
     import scene_cases
     scene_cases.run_guides()

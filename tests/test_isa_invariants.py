@@ -118,7 +118,9 @@ def test_vector_instruction_budget(kernels):
     torus = _valu(kernels["k_trace_element<3, false>"]["code"])
     chain = _valu(kernels["k_trace_chain<false, 5>"]["code"])
     assert len(torus) <= 730, len(torus)            # 694 (mid-round: 838 with one solver path less)
-    assert len(chain) <= 2170, len(chain)           # 2066 (mid-round: 2558)
+    # round 4: 2203 = 2066 + the LITE tail's block (ArtChainReadout.lite), which the default path branches around -- the
+    # EXECUTED count per wave is unchanged (SQ_INSTS_VALU 1324 per wave in profiles/r04_relay4_sq.md, 1321 in round 3)
+    assert len(chain) <= 2260, len(chain)           # 2203 (round 3: 2066; mid-round-2: 2558)
     # no IEEE division / sqrt expansions on the torus path (the quadrics keep ONE IEEE division on purpose: q / a with a
     # leading coefficient that may be 1e-34)
     assert not [i for i in torus if i.startswith(("v_div_scale", "v_div_fmas", "v_div_fixup", "v_sqrt_f32"))]

@@ -71,4 +71,5 @@ for rep in range(passes):
             print("   distance %.3f mm  transmission %.2f %%  spot sd %.4g um  duration sd %.4g fs" % (row[0], row[1], 1e3 * row[2], row[3]))
     if pr:
         pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+        pstats.Stats(pr).sort_stats("tottime").print_stats(25)
     del chains, res
