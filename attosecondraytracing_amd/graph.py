@@ -91,16 +91,17 @@ class SceneProgram:
         self.host, self.dev = self.be.scene_alloc(self.c, self.m)
         self._uploaded = None
         self._signature = None
+        self._stepwise = None
         self.post, self.post_result = post, None
         self.update(element_lists)
         self.placement = None
         if placement_tries is None:
             import os
             placement_tries = int(os.environ.get("ART_PLACEMENT_TRIES", "1"))
-        if self.be.name == "hip" and placement_tries > 1:
+        if self.be.name == "hip" and placement_tries > 1 and not self._stepwise:
             self._tune_placement(element_lists, int(placement_tries))
         self.graph = None
-        if capture and self.be.name == "hip":
+        if capture and self.be.name == "hip" and not self._stepwise:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -241,8 +242,8 @@ class SceneProgram:
         if len(element_lists) != self.c or any(len(e) != self.m for e in element_lists):
             return False
         descs = [self._mp.element_descriptor(oe, self.IgnoreDefects, self.be)[0] for els in element_lists for oe in els]
-        return (self._structure(element_lists, descs) == self._signature
-                and not any(d.nonfinite or (d.flags & self._abi.ART_FLAG_ZERN_RECURRENCE) for d in descs))
+        return (self._structure(element_lists, descs) == self._signature and not any(d.nonfinite for d in descs)
+                and any(d.flags & self._abi.ART_FLAG_ZERN_RECURRENCE for d in descs) == self._stepwise)
 
     def update(self, element_lists):
         """New poses / parameters for the same optics: re-pack the table and copy it over the device image."""
@@ -252,15 +253,28 @@ class SceneProgram:
                 d, k = self._mp.element_descriptor(oe, self.IgnoreDefects, self.be)
                 if d.nonfinite:
                     raise ValueError("an element has non-finite parameters")
-                if d.flags & self._abi.ART_FLAG_ZERN_RECURRENCE:
-                    raise ValueError("a Zernike defect above order 16 is traced element by element (RayTracingCalculation): "
-                                     "it cannot be part of a SceneProgram")
                 descs.append(d)
                 keep.append(k)
         sig = self._structure(element_lists, descs)
         if self._signature is not None and sig != self._signature:
             raise ValueError("SceneProgram.update: the optics changed (kinds / counts / defects); build a new program")
         self._signature = sig
+        # A Zernike defect above order 16 runs the reference's recurrences per ray in a kernel of its own (art_trace_element
+        # only: per-lane row storage): a program that contains one is STEPWISE -- one launch per element into the same
+        # preallocated bundles, descriptors as kernel arguments (so: eager launches, no captured graph, no fused read-out)
+        stepwise = any(d.flags & self._abi.ART_FLAG_ZERN_RECURRENCE for d in descs)
+        if stepwise and (not self._history or self.readouts is not None):
+            raise ValueError("a SceneProgram with a Zernike defect above order 16 is traced element by element: it needs "
+                             "history=True and cannot carry fused read-outs (detectors=None; Detector.readout works)")
+        if self._stepwise is not None and stepwise != self._stepwise:
+            raise ValueError("SceneProgram.update: the optics changed (a Zernike order crossed 16); build a new program")
+        self._stepwise = stepwise
+        if stepwise:
+            self._descs, self._keep = descs, keep
+            for outs in self.outputs:
+                for b in outs:
+                    b.touch()
+            return
         if self._uploaded is not None:
             self._uploaded.synchronize()       # the previous copy has read the pinned image
         self.flags = self.be.scene_pack(descs, self._views_in, self._views_out, self.c, self.m, self.host, self.readouts)
@@ -282,7 +296,15 @@ class SceneProgram:
                 self._mp._attach_readout(outs[-1], self.detectors[ci], 0.0, self.readouts[ci])
 
     def _launch(self):
-        self.be.trace_scene(self.dev, self.host, self.n, segments=-(-self.m // 8))
+        if self._stepwise:
+            for ci in range(self.c):
+                vin = self._views_in[ci]
+                for k in range(self.m):
+                    vout = self._views_out[ci * self.m + k]
+                    self.be.trace_element(self._descs[ci * self.m + k], vin, vout, self.n)
+                    vin = vout
+        else:
+            self.be.trace_scene(self.dev, self.host, self.n, segments=-(-self.m // 8))
         self._mark()
         if self.post is not None:
             self.post_result = self.post(self.outputs)
