@@ -306,6 +306,7 @@ class SurvivorGather:
         self.hdr = [torch.zeros((self.world, 2), dtype=torch.int64, device=dev) for _ in range(buffers)]
         pin = torch.device(dev).type == "cuda"
         self._hdr_host = [torch.zeros((self.world, 2), dtype=torch.int64, pin_memory=pin) for _ in range(buffers)]
+        self._side = torch.cuda.Stream(device=dev) if pin else None
         self._hdr_event = [None] * buffers    # the headers of set b are on the host once this event has completed
         self._settled = [True] * buffers      # headers read and the shipped size checked against them
         self.headers = [None] * buffers       # host copies: [[count, flags]] per rank (valid once set b is settled)
@@ -373,15 +374,26 @@ class SurvivorGather:
         first, step, _ = self.specs[self.rank]
         self.be.pack_survivors(alive, X, Y, opl, number, first, step, self.send[b])
         mine = self.send[b][:16].view(torch.int64)
-        if dist.is_available() and dist.is_initialized():
-            w = dist.all_gather_into_tensor(self.hdr[b].view(-1), mine, async_op=True)
-            w.wait()                          # RCCL: the caller's STREAM waits; gloo (CPU tests): the host does
-        else:
-            self.hdr[b][0].copy_(mine)
-        self._hdr_host[b].copy_(self.hdr[b], non_blocking=True)
-        if self._hdr_host[b].is_pinned():
-            self._hdr_event[b] = torch.cuda.Event()
-            self._hdr_event[b].record()
+        if self._side is not None:
+            # the headers travel on the communicator's stream BEHIND the previous step's payload gather, and their copy to
+            # the host on a side stream behind that: the caller's stream (the next trace) never waits for either
+            if dist.is_available() and dist.is_initialized():
+                w = dist.all_gather_into_tensor(self.hdr[b].view(-1), mine, async_op=True)
+                with torch.cuda.stream(self._side):
+                    w.wait()                  # the SIDE stream waits for the collective
+            else:
+                self.hdr[b][0].copy_(mine)
+                self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                self._hdr_host[b].copy_(self.hdr[b], non_blocking=True)
+                self._hdr_event[b] = torch.cuda.Event()
+                self._hdr_event[b].record()
+        else:                                 # CPU tensors (gloo tests): everything is synchronous
+            if dist.is_available() and dist.is_initialized():
+                dist.all_gather_into_tensor(self.hdr[b].view(-1), mine)
+            else:
+                self.hdr[b][0].copy_(mine)
+            self._hdr_host[b].copy_(self.hdr[b])
         self._settled[b] = False
         if self._known is None or not self.predict:
             self.host_syncs += 1              # nothing to predict from: this step's own headers, synchronously
@@ -402,7 +414,10 @@ class SurvivorGather:
 
     def result(self, b):
         """On dst: [(number int64 [c], X [c], Y [c], path [c])] per rank (views of receive set b; the numbers of a dense
-        shard are generated).  None elsewhere."""
+        shard are generated).  None elsewhere.  With more than one rank, call drain() on EVERY rank first: settling a set
+        may re-issue its gather (overflow), which is a collective."""
+        if not self._settled[b] and self.world > 1 and dist.is_available() and dist.is_initialized():
+            raise RuntimeError("SurvivorGather.result: set %d is not settled yet -- call drain() on every rank first" % b)
         if self.work[b] is not None:
             self.work[b].wait()
             self.work[b] = None
