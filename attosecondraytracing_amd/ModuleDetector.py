@@ -53,6 +53,14 @@ class Detector:
             raise TypeError("Detector RefPoint must a 3D-vector, given as numpy.ndarray of shape (3,).")
         self._refpoint = RefPoint
 
+    def __getstate__(self):
+        """Archive form (mp.save_compressed): the pose only -- not the device analysis attached by autoplace (it holds the
+        analysed bundle) nor the cached rotation."""
+        st = dict(self.__dict__)
+        st.pop("_analysis", None)
+        st.pop("_rot_cache", None)
+        return st
+
     # ------------------------------------------------------------------ placement
     def copy_detector(self):
         d = Detector(self.refpoint, self.centre, self.normal)
