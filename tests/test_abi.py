@@ -43,6 +43,10 @@ int main(void) {
          offsetof(ArtElementDesc, sp), offsetof(ArtElementDesc, zern), sizeof(ArtBundleView),
          sizeof(ArtDetectorDesc), (size_t)ART_ZERN_STRIDE, sizeof(ArtChainReadout), offsetof(ArtChainReadout, w),
          offsetof(ArtChainReadout, X), offsetof(ArtChainReadout, out24));
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %d %d %d\n", offsetof(ArtChainReadout, lite), sizeof(ArtAnalysisJob),
+         offsetof(ArtAnalysisJob, w), offsetof(ArtAnalysisJob, distance), offsetof(ArtAnalysisJob, mode),
+         offsetof(ArtAnalysisJob, centre), offsetof(ArtAnalysisJob, normal), offsetof(ArtAnalysisJob, refpoint),
+         ART_ANALYSIS_DOUBLES, ART_GUIDES_MAX, ART_MAX_DEFECTS);
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as td:
@@ -53,9 +57,12 @@ int main(void) {
         vals = [int(v) for v in subprocess.check_output([exe]).split()]
     E = _abi.ArtElementDesc
     R = _abi.ArtChainReadout
+    J = _abi.ArtAnalysisJob
     assert vals == [C.sizeof(E), E.fwd.offset, E.sp.offset, E.zern.offset, C.sizeof(_abi.ArtBundleView),
                     C.sizeof(_abi.ArtDetectorDesc), _abi.ART_ZERN_STRIDE, C.sizeof(R), R.w.offset, R.X.offset,
-                    R.out24.offset]
+                    R.out24.offset,
+                    R.lite.offset, C.sizeof(J), J.w.offset, J.distance.offset, J.mode.offset, J.centre.offset,
+                    J.normal.offset, J.refpoint.offset, _abi.ART_ANALYSIS_DOUBLES, _abi.ART_GUIDES_MAX, _abi.ART_MAX_DEFECTS]
 
 
 def test_no_cpu_fallback():

@@ -126,3 +126,50 @@ def test_prepared_descriptor_slots():
     d.mp[0], d.mp[1] = 100.0, 150.0                             # r > R: the "lemon" flag
     lib.art_cpu_prepare_element(C.byref(d), C.byref(out))
     assert out.flags & 0x80000000
+
+
+def test_detector_placement_on_the_device_matches_the_host_shell():
+    """analysis_place (art_device.h, what art_analyse_bundles runs between its passes): the detector of
+    Detector.autoplace (ART/ModuleDetector.py:109-137) from the bundle's sums -- normal, centre, reference point -- and the
+    matrix of RotationPoint(., normal, ez) with its special cases (ART/ModuleGeometry.py:333-343), against the host shell's
+    NumPy versions; the provisional path centre is the mean path + the mean ray's distance to the detector."""
+    import ART.ModuleGeometry as mgeo
+    lib = C.CDLL(twin_backend.build_twin())
+    place = lib.art_cpu_analysis_place
+    place.restype = C.c_int
+    place.argtypes = [_abi.c_double_p, C.c_int32, C.c_double, _abi.c_double_p, _abi.c_double_p, _abi.c_double_p, _abi.c_double_p]
+    rng = np.random.default_rng(5)
+    ez = np.array([0.0, 0.0, 1.0])
+    specials = [np.array([0.0, 0.0, -1.0]), np.array([0.0, 0.0, 1.0]), _unit(np.array([1e-11, 0.0, -1.0])),
+                _unit(np.array([0.0, 3e-11, 1.0])), _unit(np.array([1e-9, 0.0, -1.0])), np.array([1.0, 0.0, 0.0])]
+    worst = 0.0
+    for k in range(300):
+        cnt = float(rng.integers(1, 10 ** 7))
+        mv = specials[k] if k < len(specials) else _unit(rng.normal(size=3)) * rng.uniform(0.9, 1.0)
+        mp_ = rng.normal(size=3) * 500
+        D = float(rng.uniform(1, 2000))
+        mean_path = float(rng.uniform(0, 3000))
+        sums = np.concatenate([[cnt], mp_ * cnt, mv * cnt, [cnt * 0.7], [mean_path * cnt]])
+        out = (C.c_double * 22)()
+        zero = (C.c_double * 3)()
+        assert place((C.c_double * 9)(*sums), 0, D, zero, zero, zero, out) == 0
+        o = np.array(out)
+        # the host shell's sequence: mean vector -> Ray.vector setter -> negated -> Detector.normal setter
+        pt, v = sums[1:4] / cnt, sums[4:7] / cnt
+        v = v / np.linalg.norm(v)
+        n = -v
+        n = n / np.linalg.norm(n)
+        assert np.abs(o[3:6] - n).max() <= 4.5e-16 and np.abs(o[15:18] - pt).max() <= 1e-12
+        assert np.abs(o[0:3] - (pt - n * D)).max() <= 1e-12 * max(1.0, D)
+        assert np.abs(o[18:21] - v).max() <= 4.5e-16          # (2 ulp: the norm is an fma chain on the device side)
+        M = mgeo.rotation_matrix(n, ez)
+        worst = max(worst, np.abs(o[6:15].reshape(3, 3) - M).max())
+        assert np.abs(o[6:15].reshape(3, 3) @ o[3:6] - (M @ n)).max() <= 2e-15          # (a few ulp of 1)
+        assert abs(o[21] - (mean_path + D)) <= 1e-12 * (mean_path + D)
+    assert worst <= 2e-15, worst          # entries of the rotation: the device's Kahan angle (polynomial atan) then sin / cos of half of it
+    # manual mode: pose used bit for bit
+    c_, n_, r_ = np.array([1.0, 2.0, 3.0]), _unit(np.array([0.3, -0.2, 0.9])), np.array([4.0, 5.0, 6.0])
+    out = (C.c_double * 22)()
+    assert place((C.c_double * 9)(*sums), 1, 0.0, (C.c_double * 3)(*c_), (C.c_double * 3)(*n_), (C.c_double * 3)(*r_), out) == 0
+    o = np.array(out)
+    assert np.array_equal(o[0:3], c_) and np.array_equal(o[3:6], n_) and np.array_equal(o[15:18], r_)
