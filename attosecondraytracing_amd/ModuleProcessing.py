@@ -29,6 +29,8 @@ DEFAULT_TRACE_MODE = os.environ.get("ART_TRACE_MODE", "chain")
 
 # ------------------------------------------------------------------------------------------- descriptors
 _DESC_CACHE = {}
+_DESC_F64_OFFSET = _abi.ArtElementDesc.fwd.offset
+assert (_abi.ArtElementDesc.mp.offset - _DESC_F64_OFFSET) == 30 * 8 and _abi.ArtElementDesc.mp.size == 32
 
 
 def element_descriptor(oe, IgnoreDefects=True, backend=None):
@@ -56,17 +58,21 @@ def _build_descriptor(oe, IgnoreDefects, backend):
     d.kind = int(kind)
     d.support_kind = int(optic.support._abi_kind)
     fwd, bwd = mgeo.frame_maps(oe.normal, oe.majoraxis)
-    d.fwd[:] = [float(v) for v in fwd.reshape(9)]
-    d.bwd[:] = [float(v) for v in bwd.reshape(9)]
-    d.pos[:] = [float(v) for v in oe.position]          # OEPlacement builds integer-typed positions
-    d.centre[:] = [float(v) for v in optic.get_centre()]
-    sp = [float(v) for v in optic.support._abi_params()]
-    d.sp[:] = sp + [0.0] * (6 - len(sp))
-    mp_ = [float(v) for v in optic._abi_params()]
-    d.mp[:] = mp_ + [0.0] * (4 - len(mp_))
+    # the 34 doubles fwd[9] bwd[9] pos[3] centre[3] sp[6] mp[4] lie back to back behind the four leading int32: written
+    # through ONE NumPy view of the struct (element-wise ctypes assignment from Python lists cost 20 us per descriptor,
+    # and a loop list builds 60 of them)
+    buf = np.frombuffer(d, dtype=np.float64, count=34, offset=_DESC_F64_OFFSET)
+    buf[0:9] = fwd.reshape(9)
+    buf[9:18] = bwd.reshape(9)
+    buf[18:21] = oe.position                            # OEPlacement builds integer-typed positions
+    buf[21:24] = optic.get_centre()
+    sp = optic.support._abi_params()
+    buf[24:24 + len(sp)] = sp
+    mp_ = optic._abi_params()
+    buf[30:30 + len(mp_)] = mp_
     # e.g. MirrorEllipsoidal parameters without a surface point under the off-axis angle: see RayTracingCalculation
     d.nonfinite = bool(d.kind not in (_abi.ART_PLANE, _abi.ART_MASK)
-                       and not np.isfinite(list(d.centre) + mp_ + list(d.pos)).all())
+                       and not (np.isfinite(buf[18:24]).all() and np.isfinite(buf[30:34]).all()))
     keep = None
     d.n_defects = 0
     d.n_grid = 0
