@@ -912,24 +912,31 @@ ART_HD void detector_ray_scan(const ArtDetectorDesc& d, const Ray& r, double spa
   crosses = t0 * fma(span, dt, t0) < 0.0;
 }
 
-// The same with the shift at which the hit point passes through the ray's origin instead of a yes/no for a given span:
-// t(s) = t0 + s * dt vanishes at s_kink = -t0 / dt (no such shift for a ray parallel to the normal's plane: +inf).
-ART_HD void detector_ray_scan_kink(const ArtDetectorDesc& d, const Ray& r, double& X, double& Y, double& opl, double& sx,
-                                   double& sy, double& so, double& s_kink) {
-  double Ix, Iy, Iz;
-  detector_ray(d, r, Ix, Iy, Iz, X, Y, opl);
-  const double den = dot3(r.dx, r.dy, r.dz, d.normal[0], d.normal[1], d.normal[2]);
-  const double nn = dot3(d.normal[0], d.normal[1], d.normal[2], d.normal[0], d.normal[1], d.normal[2]);
-  const double dt = -nn / den;
-  double rx, ry, rz;
-  mat3_apply(d.rot, fma(dt, r.dx, d.normal[0]), fma(dt, r.dy, d.normal[1]), fma(dt, r.dz, d.normal[2]), rx, ry, rz);
-  sx = rx; sy = ry;
+// The same for art_analyse_bundles, with the shift at which the hit point passes through the ray's origin instead of a
+// yes/no for a given span (t(s) = t0 + s dt vanishes at s_kink = -t0 / dt = (n.(C - A)) / (n.n): no division by u.n), and
+// |u|, which the caller needs again.  ONE reciprocal of u.n serves t0, dt and the slopes; (X, Y, opl) at shift 0 are
+// detector_ray's to rounding (t = num * (1 / den) with one residual correction, as div_full does).
+ART_HD void detector_ray_scan_kink(const ArtDetectorDesc& d, const Ray& r, double inv_nn, double& X, double& Y, double& opl,
+                                   double& sx, double& sy, double& so, double& s_kink, double& un) {
   const double num = dot3(d.normal[0], d.normal[1], d.normal[2], d.centre[0] - r.ox, d.centre[1] - r.oy,
                           d.centre[2] - r.oz);
-  const double t0 = num / den;
-  const double sgn = (t0 >= 0.0) ? 1.0 : -1.0;
-  so = sgn * dt * sqrt(dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz));
-  s_kink = (dt != 0.0) ? -t0 / dt : INFINITY;
+  const double den = dot3(r.dx, r.dy, r.dz, d.normal[0], d.normal[1], d.normal[2]);
+  const double iden = rcp_full(den);
+  const double q = num * iden;
+  const double t = fma(fma(-den, q, num), iden, q);          // = div_full(num, den)
+  const double Ix = fma(t, r.dx, r.ox), Iy = fma(t, r.dy, r.oy), Iz = fma(t, r.dz, r.oz);
+  double rx, ry, rz;
+  mat3_apply(d.rot, Ix - d.centre[0], Iy - d.centre[1], Iz - d.centre[2], rx, ry, rz);
+  X = rx; Y = ry;
+  double iun;
+  sqrt_rsqrt_coarse(dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz), un, iun);
+  opl = fma(fabs(t), un, r.path);
+  const double nn = dot3(d.normal[0], d.normal[1], d.normal[2], d.normal[0], d.normal[1], d.normal[2]);
+  const double dt = -nn * iden;                               // d t / d s: the plane recedes by s * normal
+  mat3_apply(d.rot, fma(dt, r.dx, d.normal[0]), fma(dt, r.dy, d.normal[1]), fma(dt, r.dz, d.normal[2]), rx, ry, rz);
+  sx = rx; sy = ry;
+  so = ((t >= 0.0) ? dt : -dt) * un;                          // opl = |t| |u| + path
+  s_kink = (den != 0.0) ? num * inv_nn : INFINITY;
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -1199,14 +1199,15 @@ __device__ __forceinline__ double angle_to_axis(const Axis3 ax, double vx, doubl
   return 2.0 * atan2(sqrt(art::dot3(ax_, ay_, az_, ax_, ay_, az_)), sqrt(art::dot3(bx_, by_, bz_, bx_, by_, bz_)));
 }
 
-// tan^2(angle / 2) of the same Kahan pair, |a v - v' u|^2 / |a v + v' u|^2: monotone in the angle, one division instead of
+// tan^2(angle / 2) of the same Kahan pair, |a v - v' u|^2 / |a v + v' u|^2: monotone in the angle, one reciprocal instead of
 // two square roots and an atan2 per ray -- for a MAXIMUM over rays the angle itself is formed once, from the largest ratio
 // (k_analysis_fold: 2 atan(sqrt(.))).
-__device__ __forceinline__ double tan2_half_angle_to_axis(const Axis3 ax, double vx, double vy, double vz) {
-  const double u = sqrt(art::dot3(ax.x, ax.y, ax.z, ax.x, ax.y, ax.z)), v = sqrt(art::dot3(vx, vy, vz, vx, vy, vz));
+__device__ __forceinline__ double tan2_half_angle_to_axis(const Axis3 ax, const double u, double vx, double vy, double vz,
+                                                          const double v) {     // u = |axis|, v = |vector|
   const double ax_ = ax.x * v - vx * u, ay_ = ax.y * v - vy * u, az_ = ax.z * v - vz * u;
   const double bx_ = ax.x * v + vx * u, by_ = ax.y * v + vy * u, bz_ = ax.z * v + vz * u;
-  return art::dot3(ax_, ay_, az_, ax_, ay_, az_) / art::dot3(bx_, by_, bz_, bx_, by_, bz_);
+  // (the denominator is ~4 |u|^2 |v|^2 for the small angles this is about: a refined reciprocal, not an IEEE division)
+  return art::dot3(ax_, ay_, az_, ax_, ay_, az_) * art::rcp_full(art::dot3(bx_, by_, bz_, bx_, by_, bz_));
 }
 
 __global__ __launch_bounds__(kBlock) void k_gauss_max_partial(const ArtBundleView b, const Axis3 ax, const int64_t n,
@@ -1366,6 +1367,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_analysis_moments(const ArtAnalysi
 #pragma unroll
     for (int k = 0; k < 9; ++k) d.rot[k] = pl[6 + k];
     const Axis3 ax = {pl[15], pl[16], pl[17]};
+    const double au = sqrt(art::dot3(ax.x, ax.y, ax.z, ax.x, ax.y, ax.z));      // |axis|: once, not per ray
+    const double inv_nn = 1.0 / art::dot3(d.normal[0], d.normal[1], d.normal[2], d.normal[0], d.normal[1], d.normal[2]);
     const double co = pl[18];
     const ArtBundleView b = jb.b;
     const double* w = jb.w;
@@ -1374,14 +1377,14 @@ __global__ __launch_bounds__(kBlock, 4) void k_analysis_moments(const ArtAnalysi
       if (b.alive[i] == 0) continue;
       art::Ray r;
       load_ray(b, i, r);
-      double q0[3], sq[3], sk;
-      art::detector_ray_scan_kink(d, r, q0[0], q0[1], q0[2], sq[0], sq[1], sq[2], sk);
+      double q0[3], sq[3], sk, un;
+      art::detector_ray_scan_kink(d, r, inv_nn, q0[0], q0[1], q0[2], sq[0], sq[1], sq[2], sk, un);
       acc[35] = fmin(acc[35], q0[0]); acc[36] = fmax(acc[36], q0[0]);
       acc[37] = fmin(acc[37], q0[1]); acc[38] = fmax(acc[38], q0[1]);
       acc[39] = fmin(acc[39], q0[2]); acc[40] = fmax(acc[40], q0[2]);
       acc[32] = fmax(acc[32], (sk <= 0.0) ? sk : -INFINITY);
       acc[33] = fmin(acc[33], (sk > 0.0) ? sk : INFINITY);
-      acc[34] = fmax(acc[34], tan2_half_angle_to_axis(ax, r.dx, r.dy, r.dz));
+      acc[34] = fmax(acc[34], tan2_half_angle_to_axis(ax, au, r.dx, r.dy, r.dz, un));
       q0[2] -= co;
       sq[2] -= 1.0;
       const double ww = w ? w[i] : 1.0;

@@ -242,7 +242,9 @@ int art_cpu_detector_scan_kink(const ArtDetectorDesc* d, const ArtBundleView* b,
     if (b->alive[i] == 0) continue;
     art::Ray r;
     load_ray(*b, i, r);
-    art::detector_ray_scan_kink(*d, r, X[i], Y[i], O[i], sx[i], sy[i], so[i], skink[i]);
+    double un;
+    const double inv_nn = 1.0 / art::dot3(d->normal[0], d->normal[1], d->normal[2], d->normal[0], d->normal[1], d->normal[2]);
+    art::detector_ray_scan_kink(*d, r, inv_nn, X[i], Y[i], O[i], sx[i], sy[i], so[i], skink[i], un);
   }
   return 0;
 }
