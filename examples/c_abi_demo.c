@@ -2,7 +2,9 @@
  * through include/art_hip.h.  A point source (1e6 rays, 20 mrad half-angle) at the origin looks along +x at a plane
  * mirror 500 mm away under 45 degrees; the reflected bundle (travelling along +y) is read out on a detector 300 mm
  * behind the mirror.  Known answers: every ray survives, and since a plane mirror only folds the beam, every
- * optical path to the detector plane equals the straight distance from the mirror image of the source.
+ * optical path to the detector plane equals the straight distance from the mirror image of the source.  Then the two
+ * entry points of ABI v10: the bundle analysed with a detector placed by the library (art_analyse_bundles) and one
+ * alignment ray through the mirror (art_trace_guides).
  *
  *   gcc -O2 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude examples/c_abi_demo.c \
  *       -L/opt/rocm/lib -lamdhip64 attosecondraytracing_amd/libart_hip.so -lm -o build/c_abi_demo
@@ -94,6 +96,60 @@ int main(void) {
   printf("rays %lld  alive %.0f  mean path %.9f mm  max |path - distance from image| %.3e mm\n", (long long)n, st[0],
          st[1] / st[0], worst);
   if (st[0] != (double)n || worst > 1e-9) { fprintf(stderr, "C_ABI_DEMO_FAILED\n"); return 4; }
+
+  /* ABI v10, part 1 -- art_analyse_bundles: the same bundle analysed WITHOUT a given detector.  The library places one on
+   * the mean ray, 300 mm from the mean hit point (Detector.autoplace), and returns the read-out moments on it.  For this
+   * symmetric cone the mean direction behind the mirror is +y exactly, the mean hit point lies in the mirror plane
+   * (y = x - 500; a little beyond its centre: the footprint of a cone on a tilted plane is lopsided, by 500 <a^2> = 0.05
+   * mm), so the detector comes out parallel to the one above, shifted by that much, and the mean path longer by the shift. */
+  ArtAnalysisJob job;
+  memset(&job, 0, sizeof(job));
+  job.b = out;
+  job.mode = ART_JOB_AUTOPLACE;
+  job.distance = 300.0;
+  ArtAnalysisJob* job_dev;
+  double *ana_scratch, *ana_out;
+  CHECK_HIP(hipMalloc((void**)&job_dev, sizeof(job)));
+  CHECK_HIP(hipMemcpy(job_dev, &job, sizeof(job), hipMemcpyHostToDevice));
+  CHECK_HIP(hipMalloc((void**)&ana_scratch, (size_t)art_analysis_scratch_doubles(1) * sizeof(double)));
+  CHECK_HIP(hipMalloc((void**)&ana_out, ART_ANALYSIS_DOUBLES * sizeof(double)));
+  CHECK_ART(art_analyse_bundles(job_dev, &job, 1, n, ana_scratch, ana_out, NULL));
+  double row[ART_ANALYSIS_DOUBLES];
+  CHECK_HIP(hipMemcpy(row, ana_out, sizeof(row), hipMemcpyDeviceToHost));
+  const double mean_opl = row[19] + row[20 + 11] / row[20];            /* co + sum(opl - co) / count */
+  printf("analysis: count %.0f  detector centre (%.6f, %.6f, %.6f) normal (%.6f, %.6f, %.6f)  mean path %.9f mm  "
+         "largest angle to the mean ray %.6f rad\n", row[0], row[10], row[11], row[12], row[13], row[14], row[15], mean_opl, row[55]);
+  const double shift = row[11] - 300.0;
+  /* (a Vogel spiral of 1e6 rays is symmetric to ~1e-8 only: the tolerances below are those of the discretisation) */
+  if (row[0] != (double)n || shift < 0.0 || shift > 0.2 || fabs((row[10] - 500.0) - shift) > 1e-4 || fabs(row[12]) > 1e-4 ||
+      fabs(row[13]) > 1e-6 || fabs(row[14] + 1.0) > 1e-9 || fabs(mean_opl - st[1] / st[0] - shift) > 1e-4 ||
+      fabs(row[55] - 0.02) > 1e-5) {
+    fprintf(stderr, "C_ABI_DEMO_FAILED (analysis)\n");
+    return 5;
+  }
+
+  /* ABI v10, part 2 -- art_trace_guides: one alignment ray along +x through the same mirror: it must leave along +y
+   * from (500, 0, 0) with a path of 500 mm and an incidence angle of 45 degrees. */
+  const double guide[8] = {0, 0, 0, 1, 0, 0, 0, 0};
+  double* guide_dev;
+  uint8_t* guide_alive;
+  const uint8_t one = 1;
+  CHECK_HIP(hipMalloc((void**)&guide_dev, sizeof(guide)));
+  CHECK_HIP(hipMalloc((void**)&guide_alive, 1));
+  CHECK_HIP(hipMemcpy(guide_dev, guide, sizeof(guide), hipMemcpyHostToDevice));
+  CHECK_HIP(hipMemcpy(guide_alive, &one, 1, hipMemcpyHostToDevice));
+  CHECK_ART(art_trace_guides(&e, 1, guide_dev, guide_alive, NULL));
+  double g[8];
+  uint8_t ga;
+  CHECK_HIP(hipMemcpy(g, guide_dev, sizeof(g), hipMemcpyDeviceToHost));
+  CHECK_HIP(hipMemcpy(&ga, guide_alive, 1, hipMemcpyDeviceToHost));
+  printf("guide ray: alive %d  point (%.9f, %.9f, %.9f)  direction (%.9f, %.9f, %.9f)  path %.9f  incidence %.9f rad\n", ga, g[0],
+         g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
+  if (ga != 1 || fabs(g[0] - 500.0) > 1e-9 || fabs(g[1]) > 1e-9 || fabs(g[3]) > 1e-12 || fabs(g[4] - 1.0) > 1e-12 ||
+      fabs(g[6] - 500.0) > 1e-9 || fabs(g[7] - 0.78539816339744831) > 1e-12) {
+    fprintf(stderr, "C_ABI_DEMO_FAILED (guide ray)\n");
+    return 6;
+  }
   printf("C_ABI_DEMO_OK\n");
   return 0;
 }
