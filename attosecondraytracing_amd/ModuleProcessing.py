@@ -648,14 +648,14 @@ def _scan(ana, detector0, RayList, s_centre, Amplitude, Step, OptFor, IntensityW
 
 
 def _spot_duration_at(m, shifts, weighted):
-    """analysis.spot_duration_from_moments for an array of shifts (the same operations in the same order)."""
+    """analysis.spot_duration_from_moments for an array of shifts: the same operations in the same order per element, the
+    three quantities (X, Y, path) as rows of one broadcast instead of three loops."""
     from .analysis import LightSpeed
     m = m[16:] if weighted else m[:16]
-    var = []
-    for k in range(3):
-        q, sq, qq, qs, ss = m[1 + 5 * k: 6 + 5 * k]
-        mean = (q + shifts * sq) / m[0]
-        var.append(np.maximum((qq + 2 * shifts * qs + shifts * shifts * ss) / m[0] - mean * mean, 0.0))
+    c = m[1:16].reshape(3, 5)                                       # rows X, Y, O: q, sq, qq, qs, ss
+    q, sq, qq, qs, ss = (c[:, k:k + 1] for k in range(5))
+    mean = (q + shifts * sq) / m[0]
+    var = np.maximum((qq + 2 * shifts * qs + shifts * shifts * ss) / m[0] - mean * mean, 0.0)
     return np.sqrt(var[0] + var[1]), np.sqrt(var[2]) / LightSpeed * 1e15
 
 

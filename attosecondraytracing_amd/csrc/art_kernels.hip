@@ -168,6 +168,27 @@ __device__ __forceinline__ void load_slot(const BundleRsrc& b, int64_t i, art::R
   r.dx = ld_f64(b.dx, o8); r.dy = ld_f64(b.dy, o8); r.dz = ld_f64(b.dz, o8);
   r.path = ld_f64(b.path, o8);
 }
+// The same loads with the DEFAULT cache policy: for an input that other workgroups are about to read again (the shared
+// input of a chain-interleaved scene launch) -- a non-temporal load does not leave its line in the caches.
+__device__ __forceinline__ double ld_f64_keep(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  const v2i32 d = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0);
+  double v;
+  __builtin_memcpy(&v, &d, 8);
+  return v;
+}
+__device__ __forceinline__ D2 ld_2f64_keep(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  const v4i32 d = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+  D2 v;
+  __builtin_memcpy(&v, &d, 16);
+  return v;
+}
+__device__ __forceinline__ void load_slot_keep(const BundleRsrc& b, int64_t i, art::Ray& r, uint8_t& alive) {
+  const unsigned o1 = (unsigned)i, o8 = o1 * 8u;
+  alive = __builtin_amdgcn_raw_buffer_load_b8(b.alive, (int)o1, 0, 0);
+  r.ox = ld_f64_keep(b.ox, o8); r.oy = ld_f64_keep(b.oy, o8); r.oz = ld_f64_keep(b.oz, o8);
+  r.dx = ld_f64_keep(b.dx, o8); r.dy = ld_f64_keep(b.dy, o8); r.dz = ld_f64_keep(b.dz, o8);
+  r.path = ld_f64_keep(b.path, o8);
+}
 __device__ __forceinline__ void store_slot(const BundleRsrc& b, int64_t i, const art::Ray& r, bool ok) {
   const unsigned o1 = (unsigned)i;
 #ifdef ART_DIAG_NOSTORE   // timing-only build: keep the compute, drop the 8 data stores (results are wrong)
@@ -568,9 +589,11 @@ __device__ __forceinline__ void store_tile_lds4(const ArtBundleView& v, const in
 // Whole chain with the ray resident in registers; history written for every element whose view is non-null.
 // `a` lives in kernel arguments (k_trace_chain) or in the device-resident scene table (k_trace_scene): either way
 // its fields are wave-uniform and fetched by scalar loads where they are used.  Rays [first, first + n) of every view.
+// `bx` / `nbx`: this workgroup's index among the launch's tile workgroups and their number -- blockIdx.x / gridDim.x in the
+// tile-major launches, blockIdx.y / gridDim.y in the chain-interleaved scene launch (k_trace_scene, `transposed`).
 template <bool DEFECT>
 __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t first, const int64_t n, const int xmap,
-                                           double* s_zern) {
+                                           double* s_zern, const unsigned bx, const unsigned nbx, const bool keep_in = false) {
 #ifdef ART_ZERN_LDS
   if (DEFECT) {
     int off = 0;
@@ -591,9 +614,9 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
   __shared__ uint8_t s_al[kBlock];
 #endif
   __shared__ double s_part[kBlock / 64][kReadoutSlots];   // wave totals of the fused read-out, combined per workgroup
-  const int64_t tile = tile_of(blockIdx.x, gridDim.x, xmap);
+  const int64_t tile = tile_of(bx, nbx, xmap);
   const BundleRsrc bi = make_rsrc(a.in, n, first);
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const int64_t stride = (int64_t)nbx * kBlock;
   int64_t i0 = tile * kBlock + threadIdx.x;
   do {
     // One register identifies the lane from here on: the slot index, made opaque so that the compiler derives both the
@@ -607,7 +630,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
     art::Ray r;
     r.inc = 0.0;
     uint8_t al;
-    load_slot(bi, i, r, al);
+    if (keep_in) load_slot_keep(bi, i, r, al);      // (wave-uniform: the launch's grid shape)
+    else load_slot(bi, i, r, al);
     // Weight of the fused read-out: fetched with the ray (a zero-length descriptor without read-out or weights) and
     // parked in LDS until the tail needs it -- held in registers across the chain it costs the 2 VGPRs that push the
     // 5-wave build into scratch, and a scratch reload at the end is a VMEM load behind 36 stores (see the tail).
@@ -693,7 +717,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
           const double q = s_part[j][lane];
           v = (lane < 16) ? v + q : (lane < 19 ? fmin(v, q) : fmax(v, q));    // rows 16-18: minima, 19-21: maxima
         }
-        a.ro.scratch[(int64_t)lane * gridDim.x + blockIdx.x] = v;
+        a.ro.scratch[(int64_t)lane * nbx + bx] = v;
       }
     }
     i0 += stride;
@@ -707,11 +731,12 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
 // hardware range checks as before (a pair of dead rays is dropped by its offset, the odd tail by the per-dword check).
 // The two rays of a lane are traced one after the other; a wave carries 128 rays.
 template <bool DEFECT>
-__device__ __forceinline__ void chain_body2(const ChainArgs& a, const int64_t first, const int64_t n, const int xmap) {
+__device__ __forceinline__ void chain_body2(const ChainArgs& a, const int64_t first, const int64_t n, const int xmap,
+                                            const unsigned bx, const unsigned nbx, const bool keep_in = false) {
   __shared__ double s_w[2][kBlock];   // per-lane parking slots of the two weights (no barrier: a lane reads what it wrote)
   __shared__ __attribute__((aligned(16))) double s_red[(kBlock / 64) * 8 * kTileStride];   // wave-private tiles of wave_reduce24
   __shared__ double s_part[kBlock / 64][kReadoutSlots];
-  const int64_t tile = tile_of(blockIdx.x, gridDim.x, xmap);
+  const int64_t tile = tile_of(bx, nbx, xmap);
   const BundleRsrc bi = make_rsrc(a.in, n, first);
   unsigned pair = (unsigned)(tile * kBlock + threadIdx.x);
   asm volatile("" : "+v"(pair));                      // ONE register identifies the lane (see chain_body)
@@ -720,9 +745,16 @@ __device__ __forceinline__ void chain_body2(const ChainArgs& a, const int64_t fi
   art::Ray r[2];
   bool ok[2];
   {
-    const D2 ox = ld_2f64(bi.ox, o16), oy = ld_2f64(bi.oy, o16), oz = ld_2f64(bi.oz, o16);
-    const D2 dx = ld_2f64(bi.dx, o16), dy = ld_2f64(bi.dy, o16), dz = ld_2f64(bi.dz, o16);
-    const D2 pa = ld_2f64(bi.path, o16);
+    D2 ox, oy, oz, dx, dy, dz, pa;
+    if (keep_in) {       // the shared input of a chain-interleaved scene launch: default cache policy (see ld_f64_keep)
+      ox = ld_2f64_keep(bi.ox, o16); oy = ld_2f64_keep(bi.oy, o16); oz = ld_2f64_keep(bi.oz, o16);
+      dx = ld_2f64_keep(bi.dx, o16); dy = ld_2f64_keep(bi.dy, o16); dz = ld_2f64_keep(bi.dz, o16);
+      pa = ld_2f64_keep(bi.path, o16);
+    } else {
+      ox = ld_2f64(bi.ox, o16); oy = ld_2f64(bi.oy, o16); oz = ld_2f64(bi.oz, o16);
+      dx = ld_2f64(bi.dx, o16); dy = ld_2f64(bi.dy, o16); dz = ld_2f64(bi.dz, o16);
+      pa = ld_2f64(bi.path, o16);
+    }
     // The two alive bytes with ONE 16-bit load.  A 16-bit access straddling the end of an odd-length array is dropped as a
     // whole: for odd n (wave-uniform) the lane that holds the last slot fetches its byte separately.
     unsigned al2 = __builtin_amdgcn_raw_buffer_load_b16(bi.alive, (int)o2, 0, ART_LD_AUX);
@@ -793,7 +825,7 @@ __device__ __forceinline__ void chain_body2(const ChainArgs& a, const int64_t fi
         const double q = s_part[j][lane];
         t = (lane < 16) ? t + q : (lane < 19 ? fmin(t, q) : fmax(t, q));
       }
-      a.ro.scratch[(int64_t)lane * gridDim.x + blockIdx.x] = t;
+      a.ro.scratch[(int64_t)lane * nbx + bx] = t;
     }
   }
 }
@@ -908,26 +940,34 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain(const ChainArgs, 
   // usually makes of it: the element index is a run-time value, and one build of the defect kernel came out with the
   // whole 3.3 KB copied to scratch at entry and 452 vector loads from there.
   typedef const ChainArgs __attribute__((address_space(4)))* kernarg_t;
-  chain_body<DEFECT>(*(const ChainArgs*)(kernarg_t)__builtin_amdgcn_kernarg_segment_ptr(), 0, n, xmap, s_dyn);
+  chain_body<DEFECT>(*(const ChainArgs*)(kernarg_t)__builtin_amdgcn_kernarg_segment_ptr(), 0, n, xmap, s_dyn, blockIdx.x,
+                     gridDim.x);
 }
 
 template <bool DEFECT, int WAVES>
 __global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain2(const ChainArgs, const int64_t n, const int xmap) {
   typedef const ChainArgs __attribute__((address_space(4)))* kernarg_t;
-  chain_body2<DEFECT>(*(const ChainArgs*)(kernarg_t)__builtin_amdgcn_kernarg_segment_ptr(), 0, n, xmap);
+  chain_body2<DEFECT>(*(const ChainArgs*)(kernarg_t)__builtin_amdgcn_kernarg_segment_ptr(), 0, n, xmap, blockIdx.x, gridDim.x);
 }
 template <bool DEFECT, int WAVES>
 __global__ __launch_bounds__(kBlock, WAVES) void k_trace_scene2(const ChainArgs* __restrict__ tab, const int64_t first,
-                                                                const int64_t n, const int xmap) {
-  chain_body2<DEFECT>(tab[blockIdx.y], first, n, xmap);
+                                                                const int64_t n, const int xmap, const int transposed) {
+  const unsigned bx = transposed ? blockIdx.y : blockIdx.x, nbx = transposed ? gridDim.y : gridDim.x;
+  chain_body2<DEFECT>(tab[transposed ? blockIdx.x : blockIdx.y], first, n, xmap, bx, nbx, (transposed & 2) != 0);
 }
 
-// Many chains in one launch: blockIdx.y = chain, descriptors in the device-resident scene table (art_scene.h).
+// Many chains in one launch, descriptors in the device-resident scene table (art_scene.h).  Two grid shapes:
+//   tile-major   grid (tiles, chains): blockIdx.y = chain -- the dispatcher works through one chain's tiles after the other;
+//   transposed   grid (chains, tiles): blockIdx.x = chain -- the workgroups of ONE tile of ALL chains are dispatched together.
+// The second is for scenes whose chains all read the SAME input bundle (a loop list traced from one source or from its
+// shared prefix, art_scene.h kFlagSharedIn): the tile of the input that chain 0 fetches from HBM is still in the memory-side
+// cache when chains 1 .. C-1 ask for it a few microseconds later, instead of being streamed from HBM once per chain.
 template <bool DEFECT, int WAVES>
 __global__ __launch_bounds__(kBlock, WAVES) void k_trace_scene(const ChainArgs* __restrict__ tab, const int64_t first,
-                                                               const int64_t n, const int xmap) {
+                                                               const int64_t n, const int xmap, const int transposed) {
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-  chain_body<DEFECT>(tab[blockIdx.y], first, n, xmap, s_dyn);
+  const unsigned bx = transposed ? blockIdx.y : blockIdx.x, nbx = transposed ? gridDim.y : gridDim.x;   // (ONE copy of the body)
+  chain_body<DEFECT>(tab[transposed ? blockIdx.x : blockIdx.y], first, n, xmap, s_dyn, bx, nbx, (transposed & 2) != 0);
 }
 
 // ------------------------------------------------------------------------------------------- AoS -> SoA
@@ -1755,6 +1795,23 @@ inline int chain_rpl(const bool has_mask) {
   const int v = e ? atoi(e) : 0;
   return (v == 1 || v == 2) ? v : (has_mask ? 2 : 1);
 }
+// Grid shape of a scene launch whose chains share their input: chain-interleaved (transposed) by default.
+// ART_SCENE_ORDER=tile forces the tile-major grid, =chain the interleaved one for every scene (read per launch: A/B).
+inline bool scene_order(const bool shared_in) {
+  const char* e = getenv("ART_SCENE_ORDER");
+  if (e && e[0] == 't') return false;
+  if (e && e[0] == 'c') return true;
+  return shared_in;
+}
+// ... and whether that shared input is loaded with the default cache policy instead of non-temporal loads: worth it while
+// the input (57 B per slot) fits the 256-MB memory-side cache -- measured in-process (profiles/r04_experiments.md, batch 8):
+// 11 chains x 1e6 rays -10 %, 10 chains x 4e6 rays (228 MB) -15 %, but 10 chains x 1e7 rays (570 MB) +6 ... +8 %, where the
+// interleaved grid with non-temporal loads is the fastest form (-4 %).  ART_SCENE_KEEP=0|1 overrides (A/B).
+inline bool scene_keep(const int64_t n) {
+  const char* e = getenv("ART_SCENE_KEEP");
+  if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+  return n * 57 <= ((int64_t)256 << 20);
+}
 // ART_CHAIN_DYN_LDS=<bytes>: unused dynamic LDS per workgroup of the fused kernel, i.e. FEWER resident workgroups per CU
 // (20 KB static + 20480 -> 4, + 33000 -> 3).  An experiment knob: the bare access pattern gains 3-7 % of bandwidth with 2-3
 // instead of 8 workgroups per CU (tools/stream_floor.hip); the kernel needs its waves to hide latency.
@@ -1903,7 +1960,7 @@ int art_trace_scene(const void* image_dev, const void* image_host, int64_t n, vo
   if (h.magic != art::kSceneMagic) return fail(ART_ERR_BAD_ARG, "host image was not written by art_scene_pack");
   const int32_t n_chains = h.n_chains, n_elems = h.n_elems, flags = h.flags;
   if (n_chains <= 0 || n_chains > 65535 || n_elems <= 0 || h.n_segments != art::scene_segments(n_elems) ||
-      (flags & ~(art::kFlagDefects | art::kFlagReadout | art::kFlagMask)))
+      (flags & ~(art::kFlagDefects | art::kFlagReadout | art::kFlagMask | art::kFlagSharedIn)))
     return fail(ART_ERR_BAD_ARG, "scene header is corrupt");
   if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
 #ifdef ART_ZERN_LDS
@@ -1925,19 +1982,25 @@ int art_trace_scene(const void* image_dev, const void* image_host, int64_t n, vo
     const int64_t cnt = (n - off < chunk) ? n - off : chunk;
     const int xm = xcd_map();
     const bool two = !(flags & 1) && chain_rpl((flags & art::kFlagMask) != 0) == 2;
-    const dim3 g(grid_stream_mapped(two ? (cnt + 1) / 2 : cnt, xm), n_chains), b(kBlock);
+    const int tiles = grid_stream_mapped(two ? (cnt + 1) / 2 : cnt, xm);
     for (int sg = 0; sg < S; ++sg) {
       const ChainArgs* seg = tab + (int64_t)sg * n_chains;
+      // chains that share their input (first segment only: later segments read their own hand-over bundles) are
+      // interleaved tile by tile (see k_trace_scene); ART_SCENE_ORDER=tile|chain overrides (A/B)
+      // bit 0: interleaved grid; bit 1: the shared input is loaded with the default cache policy (scene_keep)
+      int tr = (scene_order((flags & art::kFlagSharedIn) != 0 && sg == 0 && n_chains > 1) && tiles <= 65535) ? 1 : 0;
+      if (tr && scene_keep(cnt)) tr |= 2;
+      const dim3 g = tr ? dim3(n_chains, tiles) : dim3(tiles, n_chains), b(kBlock);
       if (flags & 1)
-        hipLaunchKernelGGL((k_trace_scene<true, 4>), g, b, 0, s, seg, off, cnt, xm);
+        hipLaunchKernelGGL((k_trace_scene<true, 4>), g, b, 0, s, seg, off, cnt, xm, tr);
       else if (two)
-        hipLaunchKernelGGL((k_trace_scene2<false, 4>), g, b, 0, s, seg, off, cnt, xm);
+        hipLaunchKernelGGL((k_trace_scene2<false, 4>), g, b, 0, s, seg, off, cnt, xm, tr);
       else if (waves == 6)
-        hipLaunchKernelGGL((k_trace_scene<false, 6>), g, b, 0, s, seg, off, cnt, xm);
+        hipLaunchKernelGGL((k_trace_scene<false, 6>), g, b, 0, s, seg, off, cnt, xm, tr);
       else
-        hipLaunchKernelGGL((k_trace_scene<false, 5>), g, b, 0, s, seg, off, cnt, xm);
+        hipLaunchKernelGGL((k_trace_scene<false, 5>), g, b, 0, s, seg, off, cnt, xm, tr);
       if ((flags & art::kFlagReadout) && sg == S - 1)
-        launch_fold_scene(seg, n_chains, (int64_t)g.x, s);
+        launch_fold_scene(seg, n_chains, (int64_t)tiles, s);
     }
   }
   hipError_t err = hipGetLastError();

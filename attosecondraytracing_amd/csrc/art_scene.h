@@ -31,6 +31,7 @@ struct ChainArgs {
 };
 constexpr int kFlagDefects = 1, kFlagReadout = 2;
 constexpr int kFlagMask = 4;     // scene header only: some chain contains a mask (selects the body of the launch)
+constexpr int kFlagSharedIn = 8; // scene header only: every chain reads the SAME input bundle (selects the grid shape)
 
 inline bool readout_ok(const ArtChainReadout& r) {
   const int outs = (r.X != nullptr) + (r.Y != nullptr) + (r.opl != nullptr);
@@ -111,6 +112,9 @@ inline int scene_pack(const ArtElementDesc* elems, int n_chains, int n_elems, co
       }
     }
   }
+  bool shared = n_chains > 1;
+  for (int c = 1; c < n_chains && shared; ++c) shared = memcmp(&ins[c], &ins[0], sizeof(ArtBundleView)) == 0;
+  if (shared) h.flags |= kFlagSharedIn;
   memcpy(image, &h, sizeof(h));
   return h.flags;
 }
