@@ -70,7 +70,10 @@ def test_two_rays_per_lane_body(kernels):
         assert k["vgpr"] <= 128 and k["scratch"] == 0 and k["lds"] <= 32 * 1024, (name, k["vgpr"], k["scratch"], k["lds"])
         code = k["code"]
         assert sum("s_barrier" in l for l in code) == 1, name
-        assert sum("buffer_store_dwordx4" in l for l in code) == 11 and sum("buffer_load_dwordx4" in l for l in code) == 8, name
+        # 8 16-byte loads (7 ray streams + the weights); the scene kernel carries the 7 ray streams a second time with the
+        # default cache policy (the shared input of a chain-interleaved launch, round 4), behind a wave-uniform branch
+        assert sum("buffer_store_dwordx4" in l for l in code) == 11, name
+        assert sum("buffer_load_dwordx4" in l for l in code) == (15 if "scene" in name else 8), name
         assert not _after_first_store(code, r"s_waitcnt.*vmcnt"), name
         assert not _after_first_store(code, r"\b(buffer_load|global_load|flat_load|scratch_load)\b"), name
 
@@ -90,10 +93,13 @@ def test_scene_descriptors_are_scalar_loads(kernels):
         code = kernels[name]["code"]
         assert sum("s_load" in l for l in code) > 100, name
         assert not [l for l in code if re.search(r"\b(global_load|flat_load)\b", l) and "grid" in name], name
-    # without gridded defects there is no vector load besides the ray's own 9 streams
+    # without gridded defects there is no vector load besides the ray's own 9 streams (7 ray streams + alive + weight) --
+    # and, since round 4, a second copy of the 8 ray / alive loads with the default cache policy (the shared input of a
+    # chain-interleaved launch), behind a wave-uniform branch
     code = kernels["k_trace_scene<false, 5>"]["code"]
     assert not [l for l in code if re.search(r"\b(global_load|flat_load)\b", l)]
-    assert sum("buffer_load" in l for l in code) == 9
+    assert sum("buffer_load" in l for l in code) == 17
+    assert sum("buffer_load" in l for l in kernels["k_trace_chain<false, 5>"]["code"]) == 9
 
 
 def test_zernike_coefficients_stay_scalar(kernels):
