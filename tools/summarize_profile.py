@@ -49,6 +49,12 @@ def short(name):
     return name.split("(")[0]
 
 
+def grid_threads(r):
+    """Threads of a dispatch in the kernel trace: all three grid dimensions (a chain-interleaved scene launch has its tiles
+    in y: its x alone is chains x 256)."""
+    return int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)
+
+
 def profiled_hash(src):
     """The hash tools/prof.sh recorded on the GPU box beside the passes (the build that ran); the tree's otherwise."""
     f = os.path.join(src, "source_hash.txt")
@@ -78,7 +84,7 @@ def main():
     rows = list(csv.DictReader(open(kt)))
     byk = collections.defaultdict(list)
     for r in rows:
-        byk[short(r["Kernel_Name"])].append((int(r["Grid_Size_X"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]),
+        byk[short(r["Kernel_Name"])].append((grid_threads(r), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]),
                                             r.get("VGPR_Count", ""), r.get("SGPR_Count", ""), r.get("LDS_Block_Size", "")))
     regs = code_object_registers()
     out += ["## kernel trace (`rocprofv3 --kernel-trace --stats`), full-size launches only", "",
@@ -103,7 +109,7 @@ def main():
     try:
         bl = json.loads(open(bj).read().strip().splitlines()[-1])
         lo, hi = bl["roofline"]["timed_region_launches"]
-        fused = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["Grid_Size_X"]))
+        fused = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), grid_threads(r))
                         for r in rows if short(r["Kernel_Name"]).startswith(("k_trace_chain", "k_trace_scene"))), key=lambda t: t[0])
         gmax = max(t[2] for t in fused)
         full = [t for t in fused if t[2] >= gmax // 2]     # full-size launches (the two-ray body's grid is half a one-ray grid)
@@ -111,7 +117,7 @@ def main():
         if cut and hi <= len(full):
             # per kernel name: average duration of ITS launches inside the timed region (what the byte counts below, cut to
             # the same launches of their own passes, are divided by)
-            named = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["Grid_Size_X"]),
+            named = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), grid_threads(r),
                             short(r["Kernel_Name"])) for r in rows if short(r["Kernel_Name"]).startswith(("k_trace_chain", "k_trace_scene"))),
                            key=lambda t: t[0])
             named = [t for t in named if t[2] >= gmax // 2][lo:hi]
