@@ -920,6 +920,10 @@ def worker(args):
                 "compulsory_formula": "per chain: n (57 + 8 w) read + sum_k (64 live_k + n) written + fused read-out 24 live_last + "
                                       "176 B per workgroup; from this run's survivor counts",
                 "counted_over_compulsory": None if tr is None else tr[0] / comp,
+                "shared_input_note": None if not (program is not None and n_chains > 1) else
+                "all chains of this scene read the SAME source bundle: the launch is chain-interleaved (grid (chains, tiles)) and, "
+                "while 57 B x rays <= 256 MiB, loads the source with the default cache policy, so it comes from HBM about once "
+                "instead of once per chain -- counted bytes may lie below compulsory_bytes, which charges every chain its own read",
                 "achieved_algorithmic": algo, "frac_algorithmic": algo / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_intersection": ALGO_BYTES_PER_INTERSECTION,
                 "algorithmic_bytes_per_read_out_ray": ALGO_BYTES_READOUT if fuse else None,
