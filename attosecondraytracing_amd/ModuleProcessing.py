@@ -518,7 +518,15 @@ def _placeChains(SourceProperties, OpticsList, variants, Description):
                     raise IndexError("list index out of range")     # the reference indexes an empty survivor list here
                 v = host[j, 3:6]
                 central[j] = v / np.linalg.norm(v)                  # (the Ray.vector setter, ModuleOpticalRay.py:85-90)
-    return [moc.OpticalChain(Source, els, Description, _placed=True) for els in elements]
+    chains = [moc.OpticalChain(Source, els, Description, _placed=True) for els in elements]
+    # the chains hold deep copies of the elements placed above (as in the reference): hand the descriptors built for the
+    # guide rays over to the copies, whose contents -- and therefore hashes -- are the same (the trace finds them cached)
+    for els, ch in zip(elements, chains):
+        for old, new in zip(els, ch.optical_elements):
+            hit = _DESC_CACHE.get((id(old), True))
+            if hit is not None and hit[3] is old and hit[0] == hash(new):
+                _DESC_CACHE[(id(new), True)] = (hit[0], hit[1], hit[2], new)
+    return chains
 
 
 def _singleOEPlacement(SourceProperties, OpticsList, DistanceList, IncidenceAngleList, IncidencePlaneAngleList,
