@@ -642,6 +642,46 @@ def test_gpu_scene_program_placement_look_is_opt_in_and_bounded(hip, monkeypatch
     assert small.placement is None                       # small bundles are not worth the look
 
 
+def test_gpu_scene_grid_shapes_give_identical_results(hip, monkeypatch):
+    """A scene whose chains share their input is launched chain-interleaved (grid (chains, tiles)), with the input loaded
+    through the caches while it fits them; ART_SCENE_ORDER / ART_SCENE_KEEP force the other forms: all three give the same
+    bundles and read-outs bit for bit (the grid shape and the cache policy change the dispatch order, not the work), for an
+    odd ray count, chains with a mask (two-rays-per-lane body) and without (one-ray body), with fused read-outs."""
+    import torch
+    import bench
+    import ART.ModuleDetector as mdet
+    import ART.ModuleProcessing as mp
+    lists_m, kind_m, dist_m = bench.scene_c3()                      # mask + 2 toroids, 10 chains
+    relay, _ = bench.build_scene(3)
+    lists_p = [relay.optical_elements] * 4                          # no mask: the one-ray body, 4 chains
+    for lists, kind, dist, n in ((lists_m[:5], kind_m, dist_m, 300_001), (lists_p, ("point", 0.02), 600.0, 200_003)):
+        src = bench.device_source(n, 0, n, hip, kind)
+        dets = []
+        for els in lists:
+            d = mdet.Detector(np.asarray(els[-1].position, dtype=float))
+            d.autoplace(mp.RayTracingCalculation(src, els, history=False)[-1], dist)
+            dets.append(d)
+        ref = None
+        for order, keep in (("tile", "0"), ("chain", "0"), ("chain", "1")):
+            monkeypatch.setenv("ART_SCENE_ORDER", order)
+            monkeypatch.setenv("ART_SCENE_KEEP", keep)
+            outs = mp.RayTracingCalculationMany([src] * len(lists), lists, detectors=dets)
+            got = [(b.alive.clone(), b.data.clone()) for o in outs for b in o]
+            ros = [torch.stack([d.readout(o[-1], sync=False)[k] for k in ("X", "Y", "opl")]).clone() for d, o in zip(dets, outs)]
+            stats = [d.readout(o[-1], sync=False)["stats_dev"].clone() for d, o in zip(dets, outs)]
+            if ref is None:
+                ref = (got, ros, stats)
+                continue
+            for (a0, d0), (a1, d1) in zip(ref[0], got):
+                live = a0.bool()
+                assert torch.equal(a0, a1) and torch.equal(d0[:, live].view(torch.int64), d1[:, live].view(torch.int64)), (order, keep)
+            for r0, r1, o in zip(ref[1], ros, outs):
+                live = o[-1].alive.bool()
+                assert torch.equal(r0[:, live].view(torch.int64), r1[:, live].view(torch.int64)), (order, keep)
+            for s0, s1 in zip(ref[2], stats):
+                assert torch.equal(s0.view(torch.int64), s1.view(torch.int64)), (order, keep)      # same partials, same fold order
+
+
 def test_gpu_list_analysis(hip):
     """ARTmain.analyse_chain_list on the device (art_analyse_bundles, blockIdx.y = chain): ONE analysis call and one copy
     back for a whole loop list; identical to run_ART chain by chain; against the per-ray read-out reduced on the host."""
