@@ -7,6 +7,8 @@ from . import ModuleGeometry as mgeo
 
 
 class Mask:
+    __deepcopy__ = mgeo.flat_deepcopy
+
     _abi_kind = _abi.ART_MASK
 
     def __init__(self, Support):

@@ -36,6 +36,8 @@ def _ReflectionMirrorRay(Mirror, PointMirror, Ray):
 
 
 class _Mirror:
+    __deepcopy__ = mgeo.flat_deepcopy
+
     _abi_kind = None
 
     def _abi_params(self):

@@ -16,6 +16,8 @@ class OpticalElement:
     """Pose = position of the optic's centre point, unit normal, unit major axis (perpendicular to the normal).
     Assigning a new normal carries the major axis along so that the two stay perpendicular; assigning a major axis
     that is not perpendicular to the normal is an error (ART/ModuleOpticalElement.py:107-160)."""
+    __deepcopy__ = mgeo.flat_deepcopy
+
 
     def __init__(self, Type, Position, Normal, MajorAxis):
         self._type = Type

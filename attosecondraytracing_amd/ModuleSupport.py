@@ -14,6 +14,8 @@ from . import ModuleGeometry as mgeo
 
 class Support(ABC):
     """Abstract base class for optics supports."""
+    __deepcopy__ = mgeo.flat_deepcopy
+
 
     _abi_kind = None
 
