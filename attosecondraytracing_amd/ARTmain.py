@@ -87,15 +87,19 @@ def optimize_detector(RayListAnalysed, Detector, DetectorOptions, verbose=True, 
     det, spot, dur = mp.FindOptimalDistance(Detector, rays, DetectorOptions["OptFor"], Amplitude, Precision,
                                             IntensityWeighted, verbose)
     if verbose:
-        s = f"The optimal detector distance is {det.get_distance():.3f} mm, with"
-        if IntensityWeighted:
-            s += " intensity-weighted"
-        if DetectorOptions["OptFor"] in ["intensity", "spotsize"]:
-            s += f" spatial std of {spot*1e3:.3g} μm"
-        if DetectorOptions["OptFor"] in ["intensity", "duration"]:
-            s += f" temporal std of {dur:.3g} fs."
-        print(s, flush=True)
+        _report_optimum(det, spot, dur, DetectorOptions["OptFor"], IntensityWeighted)
     return det, spot, dur
+
+
+def _report_optimum(det, spot, dur, OptFor, IntensityWeighted):
+    s = f"The optimal detector distance is {det.get_distance():.3f} mm, with"
+    if IntensityWeighted:
+        s += " intensity-weighted"
+    if OptFor in ["intensity", "spotsize"]:
+        s += f" spatial std of {spot*1e3:.3g} μm"
+    if OptFor in ["intensity", "duration"]:
+        s += f" temporal std of {dur:.3g} fs."
+    print(s, flush=True)
 
 
 def make_plots(OpticalChain, RayListAnalysed, Detector, SourceProperties, DetectorOptions, AnalysisOptions):
@@ -149,12 +153,26 @@ def analyse_chain_list(OpticalChainList, SourceProperties, DetectorOptions, Anal
             src_slot[key] = len(requests)
             requests.append((ch.source_rays, "sums", None))
     res = analysis.analyse(requests)
+    # every chain's detector, then (AutoDetectorDistance) the autofocus search of ALL chains at once: each scan level
+    # evaluates the positions of every chain in one broadcast (mp._optimise_many, arithmetic on the analyses' 64 doubles)
+    detectors = []
+    for i, ch in enumerate(chains):
+        if DetectorOptions["ManualDetector"]:
+            Detector = requests[i][2]
+            Detector._analysis = res[i]
+        else:
+            Detector = mdet.Detector(np.asarray(ch.optical_elements[k_an].position, dtype=float))
+            Detector._adopt(res[i])
+        detectors.append(Detector)
+    optima = None
+    if DetectorOptions["AutoDetectorDistance"]:
+        optima = mp._optimise_many([(d, B, res[i]) for i, (d, B) in enumerate(zip(detectors, analysed))],
+                                   DetectorOptions["OptFor"], None, 3, True, False)
     results = []
     for i, (ch, B) in enumerate(zip(chains, analysed)):
         if announce:
             print("Optical Chain " + str(i) + "/" + str(len(chains)) + " ", end="", flush=True)
-        ana = res[i]
-        ETransmission = 100 * float(ana.sum_w) / float(res[src_slot[ch.source_rays.content_key()]].sum_w)
+        ETransmission = 100 * float(res[i].sum_w) / float(res[src_slot[ch.source_rays.content_key()]].sum_w)
         if AnalysisOptions["verbose"]:
             print(_NICELINE, flush=True)
             if isinstance(ch.description, str) and len(ch.description) > 0:
@@ -162,16 +180,12 @@ def analyse_chain_list(OpticalChainList, SourceProperties, DetectorOptions, Anal
             if ch.loop_variable_name is not None and ch.loop_variable_value is not None:
                 print("For " + ch.loop_variable_name + " = " + "{:f}".format(ch.loop_variable_value) + ":\n")
                 print("The optical setup has an energy transmission of " + "{:.1f}".format(ETransmission) + "%.\n")
-        if DetectorOptions["ManualDetector"]:
-            Detector = requests[i][2]
-            Detector._analysis = ana
+        if optima is not None:
+            Detector, SpotSizeSD, DurationSD = optima[i]
+            if AnalysisOptions["verbose"]:
+                _report_optimum(Detector, SpotSizeSD, DurationSD, DetectorOptions["OptFor"], True)
         else:
-            Detector = mdet.Detector(np.asarray(ch.optical_elements[k_an].position, dtype=float))
-            Detector._adopt(ana)
-        if DetectorOptions["AutoDetectorDistance"]:
-            Detector, SpotSizeSD, DurationSD = optimize_detector(B, Detector, DetectorOptions, AnalysisOptions["verbose"],
-                                                                 maxRaystoConsider=None, IntensityWeighted=True)
-        else:
+            Detector = detectors[i]
             SpotSizeSD, DurationSD = mplots.GetResultSummary(Detector, B, AnalysisOptions["verbose"])
         if AnalysisOptions["verbose"]:
             print(_NICELINE + "\n")

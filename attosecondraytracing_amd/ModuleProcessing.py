@@ -623,77 +623,108 @@ def ReturnAiryRadius(Wavelength: float, NumericalAperture: float) -> float:
 
 
 # ------------------------------------------------------------------------------------------- autofocus
-def _scan(ana, detector0, RayList, s_centre, Amplitude, Step, OptFor, IntensityWeighted):
-    """One pass of the detector scan (ART/ModuleProcessing.py:317-366) about the shift `s_centre` of `detector0` (shifts
-    as in Detector.shiftByDistance): positions s_centre - Amplitude + i Step, i < int(2 Amplitude / Step).  The read-out
-    of every ray is linear in the shift, so spot size and duration at all positions follow from the ONE set of moment
-    sums of the device analysis `ana` (analysis.BundleAnalysis, taken at detector0) instead of one pass over the bundle
-    per position.  Returns (best shift, spot size there, duration there)."""
+def _spot_duration_at(M, shifts, weighted):
+    """analysis.spot_duration_from_moments for MANY bundles and an array of shifts each: M [c, 33] moment rows, shifts [c, n]
+    -> (spot sizes [c, n], durations [c, n]).  The same +, -, *, /, sqrt per element in the same order as the scalar
+    function (exactly rounded operations: the same bits whether a bundle is evaluated alone or in a list)."""
+    from .analysis import LightSpeed
+    M = M[:, 16:32] if weighted else M[:, :16]
+    m0 = M[:, 0].reshape(-1, 1, 1)
+    c = M[:, 1:16].reshape(-1, 3, 5)                               # per bundle: rows X, Y, O; columns q, sq, qq, qs, ss
+    q, sq, qq, qs, ss = (c[:, :, k:k + 1] for k in range(5))
+    s = shifts[:, None, :]
+    mean = (q + s * sq) / m0
+    var = np.maximum((qq + 2 * s * qs + s * s * ss) / m0 - mean * mean, 0.0)
+    return np.sqrt(var[:, 0] + var[:, 1]), np.sqrt(var[:, 2]) / LightSpeed * 1e15
+
+
+def _optimise_many(items, OptFor, Amplitude, Precision, IntensityWeighted, verbose=False):
+    """The search of FindOptimalDistance (ART/ModuleProcessing.py:317-460) for MANY (Detector, RayList, analysis) triples at
+    once: every scan level evaluates the positions of all bundles in one broadcast.  The read-out of every ray is linear
+    in a shift of the detector along its normal, so spot size and duration at all positions follow from the ONE set of
+    moment sums of each device analysis (analysis.BundleAnalysis, taken at its detector) instead of one pass over the
+    bundle per position: arithmetic on 64 doubles per bundle.  Returns [(moved detector, spot size, duration)].
+
+    Scan levels as in the reference: positions centre - A_k + i Step_k, i < int(2 A_k / Step_k) (19 or 20, by rounding:
+    per bundle), A_k = Amplitude 0.1^k, k <= Precision; the best position of a level is the centre of the next."""
+    if OptFor not in ["intensity", "size", "duration"]:
+        raise NameError("I don`t recognize what you want to optimize the detector distance for. OptFor must be "
+                        "either 'intensity', 'size' or 'duration'.")
+    c = len(items)
+    first, amp = np.empty(c), np.empty(c)
+    for j, (det, _, ana) in enumerate(items):
+        first[j] = det.get_distance()
+        if Amplitude is None:
+            SizeSpot = 2 * ana.spot_duration(0.0, False)[0]
+            NumericalAperture = float(np.sin(ana.max_angle) * 1)
+            amp[j] = min(4 * np.ceil(SizeSpot / np.tan(np.arcsin(NumericalAperture))), first[j])
+        else:
+            amp[j] = Amplitude
+    step = amp / 10
+    if verbose:
+        for j in range(c):
+            print(f"Searching optimal detector position for *{OptFor}* within [{first[j]-amp[j]:.3f}, "
+                  f"{first[j]+amp[j]:.3f}] mm...", end="", flush=True)
     if OptFor not in ("intensity", "duration", "spotsize"):
         # FindOptimalDistance lets "size" through, but the reference's scan only knows "spotsize": its fitness is
         # then never assigned (ART/ModuleProcessing.py:342-348)
         raise UnboundLocalError("local variable 'Fitness' referenced before assignment")
-    start = s_centre - Amplitude
-    n = int(2 * Amplitude / Step)
-    shifts = start + np.arange(n) * Step
-    # A scan that carries the detector through the last optic (Amplitude clipped to the detector distance: the scan
-    # starts AT the optic) meets rays whose hit lies behind their origin; the reference's path |I - A| has a kink
-    # there and is no longer linear in the shift.  Those scans are evaluated position by position (still on the
-    # device, still all rays), exactly as the reference's loop does.
-    exact = OptFor in ("intensity", "duration") and n > 0 and not ana.linear_over(shifts[0], shifts[-1])
-    if exact:
-        sizes, durations = np.empty(n), np.empty(n)
-        for i in range(n):
-            here = detector0.copy_detector()
-            here.shiftByDistance(float(shifts[i]))
-            sizes[i], durations[i] = here._spot_duration_from_moments(here._scan_moments(RayList), 0.0, IntensityWeighted)
-    else:
-        sizes, durations = _spot_duration_at(ana.moments, shifts, IntensityWeighted)
-    fitness = sizes ** 2 * durations if OptFor == "intensity" else (durations if OptFor == "duration" else sizes)
-    ind = int(np.argmin(fitness))
-    return (float(shifts[ind]), float(sizes[ind]) if OptFor in ("intensity", "spotsize") else np.nan,
-            float(durations[ind]) if OptFor in ("intensity", "duration") else np.nan)
-
-
-def _spot_duration_at(m, shifts, weighted):
-    """analysis.spot_duration_from_moments for an array of shifts: the same operations in the same order per element, the
-    three quantities (X, Y, path) as rows of one broadcast instead of three loops."""
-    from .analysis import LightSpeed
-    m = m[16:] if weighted else m[:16]
-    c = m[1:16].reshape(3, 5)                                       # rows X, Y, O: q, sq, qq, qs, ss
-    q, sq, qq, qs, ss = (c[:, k:k + 1] for k in range(5))
-    mean = (q + shifts * sq) / m[0]
-    var = np.maximum((qq + 2 * shifts * qs + shifts * shifts * ss) / m[0] - mean * mean, 0.0)
-    return np.sqrt(var[0] + var[1]), np.sqrt(var[2]) / LightSpeed * 1e15
+    M = np.stack([ana.moments for _, _, ana in items])
+    shift = np.zeros(c)
+    spot, dur = np.full(c, np.nan), np.full(c, np.nan)
+    for k in range(Precision + 1):
+        A, St = amp * 0.1 ** k, step * 0.1 ** k
+        start = shift - A
+        with np.errstate(invalid="ignore", divide="ignore"):
+            ratio = 2 * A / St
+        if not np.isfinite(ratio).all():
+            raise ValueError("cannot convert float NaN to integer")        # (int(nan) in the scalar form: a zero amplitude)
+        n = ratio.astype(np.int64)                                          # int(): truncation
+        nmax = int(n.max())
+        if nmax == 0:
+            raise ValueError("attempt to get argmin of an empty sequence")  # (np.argmin([]) in the scalar form)
+        shifts = start[:, None] + np.arange(nmax)[None, :] * St[:, None]
+        sizes, durations = _spot_duration_at(M, shifts, IntensityWeighted)
+        # A scan that carries the detector through the last optic (Amplitude clipped to the detector distance: the scan
+        # starts AT the optic) meets rays whose hit lies behind their origin; the reference's path |I - A| has a kink
+        # there and is no longer linear in the shift.  Those scans are evaluated position by position (still on the
+        # device, still all rays), exactly as the reference's loop does.
+        if OptFor in ("intensity", "duration"):
+            for j, (det, rays, ana) in enumerate(items):
+                if n[j] > 0 and not ana.linear_over(shifts[j, 0], shifts[j, n[j] - 1]):
+                    for i in range(int(n[j])):
+                        here = det.copy_detector()
+                        here.shiftByDistance(float(shifts[j, i]))
+                        sizes[j, i], durations[j, i] = here._spot_duration_from_moments(here._scan_moments(rays), 0.0,
+                                                                                        IntensityWeighted)
+        fitness = sizes ** 2 * durations if OptFor == "intensity" else (durations if OptFor == "duration" else sizes)
+        fitness = np.where(np.arange(nmax)[None, :] < n[:, None], fitness, np.inf)
+        if (n == 0).any():
+            raise ValueError("attempt to get argmin of an empty sequence")
+        ind = np.argmin(fitness, axis=1)
+        rows = np.arange(c)
+        shift = shifts[rows, ind]
+        if OptFor in ("intensity", "spotsize"):
+            spot = sizes[rows, ind]
+        if OptFor in ("intensity", "duration"):
+            dur = durations[rows, ind]
+    results = []
+    for j, (det, _, _) in enumerate(items):
+        moving = det.copy_detector()
+        moving.shiftByDistance(float(shift[j]))
+        if not first[j] - amp[j] + 10 ** -Precision < moving.get_distance() < first[j] + amp[j] - 10 ** -Precision:
+            print("There`s no minimum-size/duration focus in the searched range.")
+        if verbose:
+            print("\r\033[K", end="", flush=True)
+        results.append((moving, np.nan if OptFor == "duration" else float(spot[j]), float(dur[j])))
+    return results
 
 
 def _optimise_from_analysis(Detector, RayList, ana, OptFor, Amplitude, Precision, IntensityWeighted, verbose):
-    """The search of FindOptimalDistance on a device analysis of RayList taken at `Detector` (ana): arithmetic on 64
-    doubles, no pass over the bundle (unless a scan crosses the last optic, see _scan)."""
-    if OptFor not in ["intensity", "size", "duration"]:
-        raise NameError("I don`t recognize what you want to optimize the detector distance for. OptFor must be "
-                        "either 'intensity', 'size' or 'duration'.")
-    FirstDistance = Detector.get_distance()
-    SizeSpot = 2 * ana.spot_duration(0.0, False)[0]
-    NumericalAperture = float(np.sin(ana.max_angle) * 1)
-    if Amplitude is None:
-        Amplitude = min(4 * np.ceil(SizeSpot / np.tan(np.arcsin(NumericalAperture))), FirstDistance)
-    Step = Amplitude / 10
-    if verbose:
-        print(f"Searching optimal detector position for *{OptFor}* within [{FirstDistance-Amplitude:.3f}, "
-              f"{FirstDistance+Amplitude:.3f}] mm...", end="", flush=True)
-    shift = 0.0
-    for k in range(Precision + 1):
-        shift, OptSpotSize, OptDuration = _scan(ana, Detector, RayList, shift, Amplitude * 0.1 ** k, Step * 0.1 ** k,
-                                                OptFor, IntensityWeighted)
-    moving = Detector.copy_detector()
-    moving.shiftByDistance(shift)
-    if not FirstDistance - Amplitude + 10 ** -Precision < moving.get_distance() < FirstDistance + Amplitude - 10 ** -Precision:
-        print("There`s no minimum-size/duration focus in the searched range.")
+    """One bundle through _optimise_many (the same code path as a list: the same bits)."""
+    out = _optimise_many([(Detector, RayList, ana)], OptFor, Amplitude, Precision, IntensityWeighted, verbose)[0]
     print("\r\033[K", end="", flush=True)
-    if OptFor == "duration":
-        OptSpotSize = np.nan
-    return moving, OptSpotSize, OptDuration
+    return out
 
 
 def FindOptimalDistance(Detector, RayList, OptFor="intensity", Amplitude: float = None, Precision: int = 3,
