@@ -40,7 +40,14 @@ def analyse(chains):
     return [ARTmain.run_ART(ch, SP, DO, AO, True) for ch in chains]
 
 
+import gc
 for rep in range(passes):
+    if rep == 1:
+        # Python's cyclic collector: a full pass walks the ~1e6 objects torch / numpy leave behind and stops the host for
+        # 40-60 ms at an arbitrary point (a warm pass once read "trace 63.5 ms"): what is alive after the cold pass moves
+        # to the permanent generation, as bench.py does before its timed region
+        gc.collect()
+        gc.freeze()
     pr = cProfile.Profile() if (profile and rep == passes - 1) else None
     t0 = time.perf_counter()
     if pr: pr.enable()
