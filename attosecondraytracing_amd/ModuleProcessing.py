@@ -230,6 +230,30 @@ def RayTracingCalculation(source_rays, optical_elements, IgnoreDefects=True, mod
     return outs
 
 
+class _ParentResolver:
+    """What a bundle handed out by a lazy history keeps in order to get its parents back: a WEAK reference to the history
+    (a strong one would close a cycle bundle -> history -> bundle, and every traced bundle -- 650 MB per 1e7 rays -- would
+    stay on the device until Python's cyclic collector happens to run) plus the recipe of the trace, so that the parents
+    can still be re-traced when the caller kept the bundle and dropped the history."""
+    __slots__ = ("hist", "bundle", "recipe")
+
+    def __init__(self, hist, bundle):
+        import weakref
+        self.hist, self.bundle = weakref.ref(hist), weakref.ref(bundle)
+        self.recipe = (hist._src, hist._els, hist._opts, hist._want, hist._scene_key)
+
+    def __call__(self):
+        h = self.hist()
+        if h is None:
+            b = self.bundle()
+            if b is None:
+                return
+            src, els, (ign, mode, pc_), want, key = self.recipe
+            h = LazyHistory(src, els, ign, mode, None, pc_, want, first=b)
+            h._scene_key = key          # the scene the bundle was traced through, not today's
+        h._materialise()
+
+
 class LazyHistory:
     """`output_rays` with the per-element history materialised ON DEMAND (`history="lazy"`).
 
@@ -259,7 +283,7 @@ class LazyHistory:
                                           detector if self._want == m - 1 else None, path_centre)[-1]
         self._bundles[self._want] = first
         if not self._full:
-            first._parent_resolver = self._materialise
+            first._parent_resolver = _ParentResolver(self, first)
 
     def _materialise(self):
         if self._full:
