@@ -58,9 +58,18 @@ class RayBundle:
         self._parent_resolver = None
 
     def _share_parent(self, other):
-        """`other` (a view / copy of this bundle) has this bundle's parent -- also when that is still to be materialised."""
+        """`other` (a view / copy of this bundle) has this bundle's parent -- also when that is still to be materialised.
+        (`other` is referred to weakly: a closure over it, stored on it, would be a reference cycle that keeps its device
+        arrays alive until the cyclic collector runs.)"""
         if self._parent_resolver is not None:
-            other._parent_resolver = lambda o=other, s=self: setattr(o, "_parent", s.parent)
+            import weakref
+            wo = weakref.ref(other)
+
+            def resolve(s=self, wo=wo):
+                o = wo()
+                if o is not None:
+                    o._parent = s.parent
+            other._parent_resolver = resolve
 
     # ------------------------------------------------------------------ backend / persistence
     @property
