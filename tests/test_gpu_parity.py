@@ -689,6 +689,65 @@ def test_gpu_list_analysis(hip):
     scene_cases.run_list_analysis(rays=200_003)
 
 
+def test_gpu_analysis_rows_match_numpy(hip):
+    """Every slot of art_analyse_bundles' output rows (sums, placed detector, 32 moments, kink shifts, largest angle,
+    bounding box) against a NumPy reduction of the same bundle (tests/twin_backend.py: the per-ray read-out of the twin's
+    art_device.h code, reduced on the host), for an auto-placed, a manual and a sums-only job, odd ray count."""
+    import ctypes as C
+    import torch
+    import bench
+    import ART.ModuleProcessing as mp
+    import ART.ModuleDetector as mdet
+    from attosecondraytracing_amd import _abi, analysis
+    from twin_backend import TwinBackend
+    lists, kind, dist = bench.scene_c3()
+    n = 100_003
+    src = bench.device_source(n, 0, n, hip, kind)
+    src.intensity = torch.rand(n, dtype=torch.float64, device=hip.device) + 0.5
+    B = mp.RayTracingCalculation(src, lists[3])[-1]
+    det = mdet.Detector(np.asarray(lists[3][-1].position, dtype=float))
+    det.autoplace(B, dist)
+    man = det.copy_detector()
+    man.shiftByDistance(3.0)
+    reqs = [(B, _abi.ART_JOB_AUTOPLACE, dist), (B, _abi.ART_JOB_MANUAL, man), (src, _abi.ART_JOB_SUMS, None)]
+    rows = hip.analyse_bundles([analysis._job(b, m_, a_) for b, m_, a_ in reqs], n).cpu().numpy()
+    # the same jobs over host copies of the arrays
+    keep = []
+
+    def host_job(b, mode, arg):
+        data, alive, w = b.data.cpu().contiguous().numpy().copy(), b.alive.cpu().numpy().copy(), b.intensity.cpu().numpy().copy()
+        keep.append((data, alive, w))
+        j = analysis._job(b, mode, arg)
+        v = _abi.ArtBundleView()
+        for k, f in enumerate(("ox", "oy", "oz", "dx", "dy", "dz", "path", "incidence")):
+            setattr(v, f, data[k].ctypes.data)
+        v.alive = alive.ctypes.data
+        j.b, j.w = v, w.ctypes.data
+        return j
+    ref = TwinBackend().analyse_bundles([host_job(*r) for r in reqs], n).numpy()
+    for j in range(3):
+        g, r = rows[j], ref[j]
+        assert g[0] == r[0] and g[0] > 0
+        assert np.abs(g[1:9] - r[1:9]).max() <= 1e-12 * g[0] * 2000.0          # sums of mm-scale coordinates
+        if j == 2:
+            assert not g[10:53].any() and g[53] == -np.inf and g[54] == np.inf
+            continue
+        assert np.abs(g[10:20] - r[10:20]).max() <= 1e-11 * 2000.0             # detector, reference point, path centre
+        span = max(abs(g[56:60]).max(), 1e-3)                                   # |X|, |Y| on the detector
+        osp = max(g[61] - g[60], 1e-6)                                          # spread of the optical path
+        m_g, m_r = g[20:53], r[20:53]
+        assert m_g[0] == m_r[0] and abs(m_g[16] - m_r[16]) <= 1e-12 * m_r[16]
+        for base in (0, 16):
+            wsum = m_r[base]
+            for k, scale in enumerate((span, span, osp + abs(g[19] - (g[60] + g[61]) / 2))):
+                o = base + 1 + 5 * k
+                tol = 1e-10 * wsum * np.array([scale, 1.0, scale * scale, scale, 1.0]) + 1e-13
+                assert (np.abs(m_g[o:o + 5] - m_r[o:o + 5]) <= tol).all(), (j, base, k, m_g[o:o + 5], m_r[o:o + 5])
+        assert abs(g[55] - r[55]) <= 1e-12 and np.abs(g[56:62] - r[56:62]).max() <= 1e-11 * 2000.0
+        for k in (53, 54):
+            assert g[k] == r[k] or abs(g[k] - r[k]) <= 1e-9 * abs(r[k])       # kink shifts (~ the detector distance)
+
+
 def test_gpu_list_analysis_edges(hip):
     import scene_cases
     scene_cases.run_list_analysis_edges()
