@@ -143,7 +143,7 @@ def analyse_chain_list(OpticalChainList, SourceProperties, DetectorOptions, Anal
                 requests.append((B, "manual", setup_detector(ch, DetectorOptions)))
             else:
                 requests.append((B, "autoplace", DetectorOptions["DistanceDetector"]))
-    else:
+    elif chains:
         setup_detector(chains[0], DetectorOptions, analysed[0])      # raises the reference's RuntimeError
     for ch in chains:
         key = ch.source_rays.content_key()
