@@ -24,8 +24,9 @@ def trace_chain_list(chains, **kwargs):
     lazy = kwargs.get("history") == "lazy"
     if len(stale) > 1 and not (lazy and kwargs.get("want", -1) not in (-1, len(stale[0].optical_elements) - 1)):
         kw = {k: v for k, v in kwargs.items() if k not in ("history", "want")}
+        # (lazy: what follows is the analysis of every chain's last bundle -- the launch forms its first pass)
         outs = mp.RayTracingCalculationMany([ch.source_rays for ch in stale], [ch.optical_elements for ch in stale],
-                                            history=not lazy, **kw)
+                                            history=not lazy, sums=lazy, **kw)
         for ch, o in zip(stale, outs):
             # lazy: only the last bundle of every chain was written; the rest appears on first access (mp.LazyHistory)
             ch._output_rays = mp.LazyHistory(ch.source_rays, ch.optical_elements, first=o[-1], **kw) if lazy else o

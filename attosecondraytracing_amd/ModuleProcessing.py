@@ -138,8 +138,15 @@ def _attach_readout(bundle, detector, path_centre, res):
     bundle._fused_readout = (detector._readout_key(path_centre), bundle.version, res)
 
 
+def _attach_sums(bundle, res):
+    """Remember the SUMS the tracing launch formed for `bundle` (pass (1) of the analysis: ArtChainReadout.sums): the
+    analysis of this bundle skips its own pass over it as long as the bundle and its weights are unchanged."""
+    w = bundle.intensity
+    bundle._fused_sums = (bundle.version, None if w is None else (w.data_ptr(), w._version), res)
+
+
 def RayTracingCalculation(source_rays, optical_elements, IgnoreDefects=True, mode=None, history=True, detector=None,
-                          path_centre=0.0, readout_lite=False):
+                          path_centre=0.0, readout_lite=False, sums=False):
     """Propagate `source_rays` through `optical_elements` (ART/ModuleProcessing.py:250-313).
 
     Returns a list with one RayBundle per element: the rays *after* that element, in the lab frame.  Each
@@ -152,7 +159,10 @@ def RayTracingCalculation(source_rays, optical_elements, IgnoreDefects=True, mod
     registers (art_trace_chain_readout): `detector.readout(outs[-1])` and the `get_*` methods find it ready instead of
     re-reading the bundle.  Same values as the separate read-out (statistics to rounding: another summation order).
     readout_lite=True: the fused read-out reduces only what `Detector.get_Delays` / `get_PointList2D[Centre]` /
-    `get_OpticalPaths` consume (count, sum of paths, bounding box, path range: 8 of the 22 statistics, no weights)."""
+    `get_OpticalPaths` consume (count, sum of paths, bounding box, path range: 8 of the 22 statistics, no weights).
+    sums=True (no detector known yet): the launch forms pass (1) of the analysis of the last bundle instead -- count, sum
+    point, sum vector, sum intensity, sum path, what `Detector.autoplace` and the transmission need
+    (ART/ModuleDetector.py:109-137) -- so that the analysis that follows reads the bundle once, not twice."""
     if isinstance(history, str):
         if history != "lazy":
             raise ValueError("history must be True, False or 'lazy'")
@@ -208,8 +218,12 @@ def RayTracingCalculation(source_rays, optical_elements, IgnoreDefects=True, mod
         if detector is not None and 0 < n <= be.MAX_FUSED_READOUT_RAYS:
             detector._iscomplete()
             ro = be.new_chain_readout(detector._desc(), src.intensity, n, (0.0, 0.0, path_centre), lite=readout_lite)
+        elif sums and detector is None and 0 < n <= be.MAX_FUSED_READOUT_RAYS and hasattr(be, "new_chain_sums"):
+            ro = be.new_chain_sums(src.intensity, n)
         be.trace_chain(descs, src.view(), views, n, readout=ro)
-        if ro is not None:
+        if ro is not None and ro.get("sums"):
+            _attach_sums(outs[-1], ro)
+        elif ro is not None:
             _attach_readout(outs[-1], detector, path_centre, ro)
     elif mode == "element":
         if not history and m > 1:
@@ -279,8 +293,10 @@ class LazyHistory:
             return
         self._want = want % m
         if first is None:
+            # (no detector known: the launch forms the sums the analysis of this bundle starts from)
             first = RayTracingCalculation(self._src, self._els[:self._want + 1], IgnoreDefects, mode, False,
-                                          detector if self._want == m - 1 else None, path_centre)[-1]
+                                          detector if self._want == m - 1 else None, path_centre,
+                                          sums=detector is None or self._want != m - 1)[-1]
         self._bundles[self._want] = first
         if not self._full:
             first._parent_resolver = _ParentResolver(self, first)
@@ -341,7 +357,7 @@ class LazyHistory:
 
 
 def RayTracingCalculationMany(source_rays_list, optical_elements_list, IgnoreDefects=True, history=True,
-                              detectors=None):
+                              detectors=None, sums=False):
     """`RayTracingCalculation` for a LIST of chains in ONE launch (art_trace_scene): what `OEPlacement` returns when one
     of its arguments is a list -- 10-11 chains that differ only in poses (ART/ModuleProcessing.py:203-239), which the
     reference's `ARTmain.main` traces one after the other (ARTmain.py:304-342).  The element descriptors of all chains
@@ -349,7 +365,8 @@ def RayTracingCalculationMany(source_rays_list, optical_elements_list, IgnoreDef
     identical to separate calls.  Chains that cannot share a launch (different ray or element counts) or whose
     histories together exceed 4 GB are traced one by one -- still on the device; chains with equal sources share the
     trace of their common prefix (below).  `detectors`: one placed Detector per chain whose read-out is fused behind the
-    trace (see RayTracingCalculation)."""
+    trace (see RayTracingCalculation); `sums=True` (without detectors): every chain's launch forms pass (1) of the
+    analysis of its last bundle instead."""
     sources = [_as_bundle(s) for s in source_rays_list]
     c = len(sources)
     if c != len(optical_elements_list):
@@ -379,11 +396,12 @@ def RayTracingCalculationMany(source_rays_list, optical_elements_list, IgnoreDef
         while L < m and all(bytes(descs[ci * m + L]) == bytes(descs[L]) for ci in range(1, c)):
             L += 1
         if L > 0:
-            head = RayTracingCalculation(sources[0], optical_elements_list[0][:L], IgnoreDefects, None, history)
+            head = RayTracingCalculation(sources[0], optical_elements_list[0][:L], IgnoreDefects, None, history,
+                                         sums=sums and L == m)
             if L == m:
                 return [list(head) for _ in range(c)]
             tails = RayTracingCalculationMany([head[-1]] * c, [els[L:] for els in optical_elements_list], IgnoreDefects,
-                                              history)
+                                              history, sums=sums)
             return [list(head) + t for t in tails]
     # One launch pays off where single launches are latency-bound (<= ~1e6 rays per chain).  With 1e7-ray chains the
     # kernels fill the GPU either way and ONE allocation for all histories (20 GB for C3) is slower to obtain than ten
@@ -391,7 +409,8 @@ def RayTracingCalculationMany(source_rays_list, optical_elements_list, IgnoreDef
     # 3.9-4.0 ms both ways, host-bound by descriptor building): above 4 GB of history the chains are launched one by one.
     too_big = history and c * m * n * 65 > 4e9
     if c == 1 or not uniform or too_big:
-        return [RayTracingCalculation(s, els, IgnoreDefects, None, history, None if detectors is None else detectors[k])
+        return [RayTracingCalculation(s, els, IgnoreDefects, None, history, None if detectors is None else detectors[k],
+                                      sums=sums and detectors is None)
                 for k, (s, els) in enumerate(zip(sources, optical_elements_list))]
     if history:
         grid = RayBundle.allocate_grid(n, c, m, sources, be)
@@ -418,13 +437,17 @@ def RayTracingCalculationMany(source_rays_list, optical_elements_list, IgnoreDef
         for d, s_, area in zip(detectors, sources, areas):
             d._iscomplete()
             ros.append(be.new_chain_readout(d._desc(), s_.intensity, n, scratch=area))
+    elif sums and detectors is None and n <= be.MAX_FUSED_READOUT_RAYS and hasattr(be, "new_chain_sums"):
+        ros = [be.new_chain_sums(s_.intensity, n, scratch=area) for s_, area in zip(sources, be.chain_readout_scratch(n, c))]
     host, dev = be.scene_alloc(c, m, transient=True)
     be.scene_pack(descs, [s.view() for s in sources], views, c, m, host, ros)
     be.scene_upload(host, dev)
     be.trace_scene(dev, host, n, segments=-(-m // 8))
     for ci, outs in enumerate(grid):
         outs[-1]._keepalive = (keep, scratch)
-        if ros is not None:
+        if ros is not None and ros[ci].get("sums"):
+            _attach_sums(outs[-1], ros[ci])
+        elif ros is not None:
             _attach_readout(outs[-1], detectors[ci], 0.0, ros[ci])
     return grid
 

@@ -1,7 +1,7 @@
 """ctypes mirror of include/art_hip.h (structs, enums, prototypes).  Keep in sync with ART_ABI_VERSION."""
 import ctypes as C
 
-ART_ABI_VERSION = 10
+ART_ABI_VERSION = 11
 
 ART_OK = 0
 ART_ERR_BAD_ARG = -1
@@ -78,7 +78,7 @@ class ArtChainReadout(C.Structure):
         ("scratch", C.c_void_p),
         ("out24", C.c_void_p),
         ("lite", C.c_int32),
-        ("reserved", C.c_int32),
+        ("sums", C.c_int32),
     ]
 
 
@@ -97,6 +97,7 @@ class ArtAnalysisJob(C.Structure):
         ("centre", C.c_double * 3),
         ("normal", C.c_double * 3),
         ("refpoint", C.c_double * 3),
+        ("sums", C.c_void_p),
     ]
 
 
@@ -148,8 +149,9 @@ PROTOTYPES = {
     "art_survivor_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
     "art_pack_survivors": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 4 + [C.c_int64, C.c_int64, C.c_void_p,
                                                                                     C.c_void_p, C.c_int64, C.c_void_p]),
+    "art_survivor_finish": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "art_trace_guides": (C.c_int, [C.POINTER(ArtElementDesc), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "art_analysis_scratch_doubles": (C.c_int64, [C.c_int32]),
+    "art_analysis_scratch_doubles": (C.c_int64, [C.c_int32, C.c_int64]),
     "art_analyse_bundles": (C.c_int, [C.c_void_p, C.POINTER(ArtAnalysisJob), C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
                                       C.c_void_p]),
     "art_make_extended_source": (C.c_int, [C.c_double, C.c_double, C.c_int64, C.c_int64, c_double_p, c_double_p,

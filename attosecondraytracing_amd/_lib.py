@@ -12,7 +12,9 @@ import torch
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("ART_HIP_LIB", os.path.join(_HERE, "libart_hip.so"))  # override: diagnostic builds
+# The product library, in-tree.  No environment variable redirects the loader: a diagnostic BUILD is loaded by handing its
+# path to HipBackend(path=...) explicitly (tools/ab_kernel.py does), never by the process-wide get_backend().
+LIB_PATH = os.path.join(_HERE, "libart_hip.so")
 
 _BACKEND = None
 
@@ -23,7 +25,9 @@ class ArtError(RuntimeError):
 
 class HipBackend:
     """Thin typed wrapper: torch tensors in, C-ABI calls out.  All calls are asynchronous on torch's
-    current HIP stream of the bundle's device."""
+    current HIP stream of the bundle's device.  Stream-safe like the C ABI underneath: every piece of scratch memory and
+    every staging pair the wrapper reuses between calls is kept PER STREAM (keyed by the current stream's handle), so two
+    torch streams may issue read-outs, compactions, scene launches and analyses concurrently."""
 
     name = "hip"
 
@@ -80,7 +84,13 @@ class HipBackend:
             t = t.to(dtype)
         return t.to(self.device)
 
+    def stream_key(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
     def scratch(self, key, n, dtype):
+        """Reused scratch memory `key` of the CURRENT stream (work of one stream is ordered, so one area per stream and
+        purpose is enough; two streams never share one)."""
+        key = (key, self.stream_key())
         t = self._scratch.get(key)
         if t is None or t.numel() < n or t.dtype != dtype:
             t = torch.empty(int(max(n, 1)), dtype=dtype, device=self.device)
@@ -124,12 +134,17 @@ class HipBackend:
 
     MAX_FUSED_READOUT_RAYS = 1 << 28     # one launch (art_trace_chain_readout)
 
-    def new_chain_readout(self, ddesc, w, n, centres=(0.0, 0.0, 0.0), store=True, scratch=None, lite=False):
+    def new_chain_readout(self, ddesc, w, n, centres=(0.0, 0.0, 0.0), store=True, scratch=None, lite=False, targets=None):
         """Outputs + descriptor of a read-out fused behind a chain launch (ArtChainReadout): returns a dict with the
         result tensors 'X', 'Y', 'opl' (None with store=False), 'stats_dev' and the ctypes 'struct'.  lite=True: only
-        count, sum of paths, bounding box and path range are reduced (ArtChainReadout.lite)."""
+        count, sum of paths, bounding box and path range are reduced (ArtChainReadout.lite).  targets=(X, Y, opl): the
+        read-out writes into these caller-owned tensors (e.g. the sections of a survivor send buffer: zero-copy gather)."""
         X = Y = opl = None
-        if store:
+        if targets is not None:
+            X, Y, opl = targets
+            assert all(t.numel() >= n and t.dtype == torch.float64 and t.is_contiguous() for t in (X, Y, opl))
+            store = True
+        elif store:
             X, Y, opl = self.empty(n), self.empty(n), self.empty(n)
         out = self.empty(24)
         if scratch is None:
@@ -141,7 +156,22 @@ class HipBackend:
         ro.X, ro.Y, ro.opl = (None, None, None) if not store else (X.data_ptr(), Y.data_ptr(), opl.data_ptr())
         ro.scratch, ro.out24 = scratch.data_ptr(), out.data_ptr()
         ro.lite = 1 if lite else 0
+        ro.sums = 0
         return {"struct": ro, "X": X, "Y": Y, "opl": opl, "P3": None, "stats_dev": out, "_keep": (w, scratch), "lite": bool(lite)}
+
+    def new_chain_sums(self, w, n, scratch=None):
+        """Descriptor of the SUMS tail (ArtChainReadout.sums): the tracing launch forms pass (1) of the analysis for the
+        chain's last bundle -- count, sum point, sum vector, sum w, sum path in 'sums_dev'[0..8] -- while the ray is still
+        in registers.  Hand 'sums_dev' to the analysis of that bundle (analysis.analyse does, through the bundle)."""
+        out = self.empty(24)
+        if scratch is None:
+            scratch = self.scratch("chain_ro", self.fn["art_chain_readout_scratch_doubles"](n), torch.float64)
+        ro = _abi.ArtChainReadout()
+        ro.w = None if w is None else w.data_ptr()
+        ro.X = ro.Y = ro.opl = None
+        ro.scratch, ro.out24 = scratch.data_ptr(), out.data_ptr()
+        ro.lite, ro.sums = 0, 1
+        return {"struct": ro, "sums_dev": out, "_keep": (w, scratch), "sums": True}
 
     def chain_readout_scratch(self, n, count):
         """`count` scratch areas for fused read-outs of `count` chains in one scene launch."""
@@ -160,10 +190,11 @@ class HipBackend:
         if nb <= 0:
             raise ArtError("art_scene_bytes: bad chain or element count")
         if transient:
-            pair = self._scene_pool.get(nb)
+            pkey = (nb, self.stream_key())          # per stream: another stream's launch may still read its device image
+            pair = self._scene_pool.get(pkey)
             if pair is None:
-                pair = self._scene_pool[nb] = (torch.empty(nb, dtype=torch.uint8, pin_memory=True),
-                                               torch.empty(nb, dtype=torch.uint8, device=self.device))
+                pair = self._scene_pool[pkey] = (torch.empty(nb, dtype=torch.uint8, pin_memory=True),
+                                                 torch.empty(nb, dtype=torch.uint8, device=self.device))
             ev = self._scene_uploads.pop(pair[0].data_ptr(), None)
             if ev is not None:
                 ev.synchronize()
@@ -342,6 +373,12 @@ class HipBackend:
                                                  int(step), sc.data_ptr(), send.data_ptr(), int(send.numel()),
                                                  self.stream_ptr()), "art_pack_survivors")
 
+    def survivor_finish(self, stats_dev, n, send):
+        """Header of a ZERO-COPY send buffer whose sections the read-out wrote directly (art_survivor_finish): (n, dense) if
+        every slot is alive, else (count, unpacked)."""
+        self.check(self.fn["art_survivor_finish"](stats_dev.data_ptr(), int(n), send.data_ptr(), self.stream_ptr()),
+                   "art_survivor_finish")
+
     def trace_guides(self, descs, rays, alive):
         """Advance guide ray j (row j of the DEVICE tensor rays[count, 8], in place) through descs[j]; alive[count] uint8
         (art_trace_guides, 8 rays per launch)."""
@@ -362,10 +399,11 @@ class HipBackend:
         # pinned staging + device table from a per-size pool (pinning host memory costs milliseconds): the pinned image is
         # rewritten only after its previous upload has completed, the device table is read by launches enqueued before
         # the next upload on the same stream
-        pair = self._job_pool.get(nb)
+        pkey = (nb, self.stream_key())
+        pair = self._job_pool.get(pkey)
         if pair is None:
-            pair = self._job_pool[nb] = [torch.empty(nb, dtype=torch.uint8, pin_memory=True),
-                                         torch.empty(nb, dtype=torch.uint8, device=self.device), None]
+            pair = self._job_pool[pkey] = [torch.empty(nb, dtype=torch.uint8, pin_memory=True),
+                                           torch.empty(nb, dtype=torch.uint8, device=self.device), None]
         host, dev, ev = pair
         if ev is not None:
             ev.synchronize()
@@ -374,7 +412,8 @@ class HipBackend:
         pair[2] = torch.cuda.Event()
         pair[2].record()
         out = torch.empty((c, _abi.ART_ANALYSIS_DOUBLES), dtype=torch.float64, device=self.device)
-        scratch = self.scratch("analysis", self.fn["art_analysis_scratch_doubles"](c), torch.float64)
+        # (jobs that bring their sums along need no per-tile partials, but the area is sized for the general case)
+        scratch = self.scratch("analysis", self.fn["art_analysis_scratch_doubles"](c, int(n)), torch.float64)
         self.check(self.fn["art_analyse_bundles"](dev.data_ptr(), arr, c, int(n), scratch.data_ptr(), out.data_ptr(),
                                                   self.stream_ptr()), "art_analyse_bundles")
         return out

@@ -72,6 +72,8 @@ def _job(bundle, mode, arg):
     j = _abi.ArtAnalysisJob()
     j.b = bundle.view()
     j.w = None if bundle.intensity is None else bundle.intensity.data_ptr()
+    fs = bundle.fused_sums()          # pass (1) formed by the tracing launch: the analysis reads the bundle once
+    j.sums = None if fs is None else fs.data_ptr()
     j.mode = mode
     if mode == _abi.ART_JOB_AUTOPLACE:
         j.distance = float(arg)

@@ -40,6 +40,7 @@ class RayBundle:
         # from Ray objects whose `path` tuples had k > 1 entries (the device keeps only their sum)
         self.path_head = None
         self._fused_readout = None    # (detector key, version, result) of a read-out computed in the tracing launch
+        self._fused_sums = None       # (version, weights identity, result) of the analysis sums formed by the tracing launch
         self._content = None          # (key, version it was valid for): see content_key()
 
     # ------------------------------------------------------------------ parent link
@@ -56,6 +57,17 @@ class RayBundle:
     def parent(self, value):
         self._parent = value
         self._parent_resolver = None
+
+    def fused_sums(self):
+        """DEVICE tensor [>= 9] of this bundle's analysis sums if the tracing launch formed them and neither the bundle nor
+        its weights changed since (ArtChainReadout.sums -> ArtAnalysisJob.sums), else None."""
+        fs = getattr(self, "_fused_sums", None)
+        if fs is None or fs[0] != self.version:
+            return None
+        w = self.intensity
+        if (None if w is None else (w.data_ptr(), w._version)) != fs[1]:
+            return None
+        return fs[2]["sums_dev"]
 
     def _share_parent(self, other):
         """`other` (a view / copy of this bundle) has this bundle's parent -- also when that is still to be materialised.
@@ -104,6 +116,7 @@ class RayBundle:
         self._index = None
         self._count = None
         self._fused_readout = None
+        self._fused_sums = None
         self._content = None
         self._serial = next(_SERIAL)
 

@@ -220,6 +220,24 @@ __device__ __forceinline__ void store_ray(const ArtBundleView& v, int64_t i, con
   v.incidence[i] = r.inc;
 }
 
+// ---- masked streaming reads of the reduction kernels -------------------------------------------------------------------
+// A reduction over the alive rays used to read `alive[i]`, branch, and only then load the slot's data: two dependent memory
+// latencies per iteration and ONE iteration's loads in flight per lane (0.42-0.63 of the rate the trace kernels reach,
+// profiles/r04_relay4.md).  Now every stream of kU grid-stride iterations is requested UNCONDITIONALLY and up front
+// (non-temporal: each byte is used once), and `alive` is applied by SELECTS when the values are folded: 4 x 9 loads in
+// flight per lane, no divergent skip.  A lane beyond the end re-reads slot n - 1 (a valid address, a cache hit) and folds
+// nothing.  The values of a dead slot are unspecified by contract (possibly NaN): they are dropped by the select, never
+// multiplied by 0.  The fold ORDER is unchanged: lane t of workgroup b still folds slots b*256 + t + k*stride for
+// k = 0, 1, ... one after the other, so the results are the bits they were.
+// (the pointer is stated to be GLOBAL memory: one that was itself fetched from a table in memory -- a job's bundle view --
+// would otherwise be a generic pointer and compile to flat_load, which also occupies the LDS counter)
+template <typename T>
+__device__ __forceinline__ T ld_nt(const T* p) {
+  typedef const T __attribute__((address_space(1)))* gptr_t;
+  return __builtin_nontemporal_load((gptr_t)p);
+}
+constexpr int kRedUnroll = 4;
+
 // ------------------------------------------------------------------------------------------- reductions
 // Deterministic: fixed grid, each lane accumulates its grid-stride slice, wave shuffle tree, LDS across the
 // 4 waves, one partial per workgroup into `scratch`, then fold_slot(): one workgroup per statistic folds the
@@ -352,6 +370,96 @@ __device__ __forceinline__ void wave_reduce_lite(const double (&acc)[kReadoutSlo
     v = min_raw(v, dpp_xchg<0x4E>(v));
     v = min_raw(v, dpp_xchg<0x141>(v));
     out[2] = (stat >= 3) ? -v : v;
+  }
+}
+
+// ---- the nine sums of the analysis' pass (1): count, sum point (3), sum vector (3), sum w, sum path ---------------------
+// ONE canonical fold order, whoever forms them -- the tail of a tracing launch (the ray is still in registers: ArtChainReadout.sums),
+// either kernel body, or k_analysis_sums re-reading a bundle: per TILE of 256 consecutive slots, four runs of 64 slots
+// are folded by the LDS transpose below (lane l parks its 8 values, folds 8 of the 64 values of sum l/8, then a 3-step
+// DPP butterfly), the four run totals are added in slot order, and the per-tile partials (row-major: scratch[row * ntiles
+// + tile]) are folded by fold_range.  The count is a popcount of ballots (exact in any order).  So a bundle's sums -- and
+// everything the analysis derives from them -- are the same bits whether they rode on the trace or were taken afterwards.
+constexpr int kSumRows = 9;
+// every lane has parked its values in `tile` rows 0..7 (row j = sum j + 1, column = slot of the run); returns, in all 8 lanes
+// of group l >> 3, the run's total of sum (l >> 3) + 1
+__device__ __forceinline__ double run_fold8(const double* tile, const int l) {
+  const double* row = tile + (l >> 3) * kTileStride + (l & 7);
+  double v = row[0];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) v += row[8 * k];
+  v += dpp_xchg<0xB1>(v);
+  v += dpp_xchg<0x4E>(v);
+  v += dpp_xchg<0x141>(v);
+  return v;
+}
+// one ray per lane, a wave = one run: -> the run's total of sum (l >> 3) + 1
+__device__ __forceinline__ double run_sums8(const double (&v)[8], double* tile, const int l) {
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) tile[j * kTileStride + l] = v[j];
+  __builtin_amdgcn_wave_barrier();
+  return run_fold8(tile, l);
+}
+// the masked values of one ray
+__device__ __forceinline__ void sums_values(double (&v)[8], const bool live, const art::Ray& r, const double w) {
+  v[0] = live ? r.ox : 0.0; v[1] = live ? r.oy : 0.0; v[2] = live ? r.oz : 0.0;
+  v[3] = live ? r.dx : 0.0; v[4] = live ? r.dy : 0.0; v[5] = live ? r.dz : 0.0;
+  v[6] = live ? w : 0.0; v[7] = live ? r.path : 0.0;
+}
+// a workgroup of 4 waves = one tile (one ray per lane): run totals -> the tile's partial, row-major in `rows`.
+// s_run: 4 x kSumRows doubles of LDS.  Bare s_barrier: __syncthreads() would also wait for the stores in flight.
+// Tiles beyond `ntiles` (a grid rounded up by the tile mapping) store nothing.
+__device__ __forceinline__ void tile_sums_store(const double tot, const unsigned long long live_mask, double* s_run,
+                                                const unsigned t, double* rows, const int64_t ntiles, const int64_t tile) {
+  const int l = t & 63, w = t >> 6;
+  if ((l & 7) == 0) s_run[w * kSumRows + 1 + (l >> 3)] = tot;
+  if (l == 0) s_run[w * kSumRows] = (double)__popcll(live_mask);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (t < kSumRows && tile < ntiles)
+    rows[(int64_t)t * ntiles + tile] = ((s_run[t] + s_run[kSumRows + t]) + s_run[2 * kSumRows + t]) + s_run[3 * kSumRows + t];
+}
+// Two NEIGHBOURING slots per lane (chain_body2): a wave's 128 slots are two runs -- lanes 0..31 hold run A, lanes 32..63
+// run B -- and a workgroup's 512 slots two tiles (waves 0, 1 and waves 2, 3).  Same order as above: the values are parked
+// in slot order, one run at a time.
+__device__ __forceinline__ void run_sums8_pairs(const double (&v0)[8], const double (&v1)[8], double* tile, const int l,
+                                                double& totA, double& totB) {
+  const int col = 2 * (l & 31);
+  __builtin_amdgcn_wave_barrier();
+  if (l < 32) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { tile[j * kTileStride + col] = v0[j]; tile[j * kTileStride + col + 1] = v1[j]; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  totA = run_fold8(tile, l);
+  __builtin_amdgcn_wave_barrier();
+  if (l >= 32) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { tile[j * kTileStride + col] = v0[j]; tile[j * kTileStride + col + 1] = v1[j]; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  totB = run_fold8(tile, l);
+}
+// s_run: 8 x kSumRows doubles (the workgroup's eight runs); tiles 2 * pair_tile and 2 * pair_tile + 1
+__device__ __forceinline__ void tile_sums_store_pairs(const double totA, const double totB, const unsigned long long m0,
+                                                      const unsigned long long m1, double* s_run, const unsigned t,
+                                                      double* rows, const int64_t ntiles, const int64_t pair_tile) {
+  const int l = t & 63, w = t >> 6;
+  if ((l & 7) == 0) {
+    s_run[(2 * w) * kSumRows + 1 + (l >> 3)] = totA;
+    s_run[(2 * w + 1) * kSumRows + 1 + (l >> 3)] = totB;
+  }
+  if (l == 0) {
+    s_run[(2 * w) * kSumRows] = (double)(__popcll(m0 & 0xffffffffull) + __popcll(m1 & 0xffffffffull));
+    s_run[(2 * w + 1) * kSumRows] = (double)(__popcll(m0 >> 32) + __popcll(m1 >> 32));
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  const int h = (int)(t >> 6);            // wave 0 stores the first tile, wave 1 the second
+  const int row = (int)(t & 63);
+  const int64_t tile = 2 * pair_tile + h;
+  if (h < 2 && row < kSumRows && tile < ntiles) {
+    const double* q = s_run + 4 * h * kSumRows + row;
+    rows[(int64_t)row * ntiles + tile] = ((q[0] + q[kSumRows]) + q[2 * kSumRows]) + q[3 * kSumRows];
   }
 }
 
@@ -668,6 +776,12 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
       // written row by row (row_of_slot) into ro.scratch -- no __syncthreads() and no load down here: either would make
       // every wave wait for the acknowledgement of its 36 outstanding stores (vmcnt counts loads and stores in one queue)
       // instead of retiring as soon as they are issued, which cost 35 %.
+      if (a.ro.sums) {     // (wave-uniform) pass (1) of the analysis instead of a read-out: see run_sums8
+        double v[8];
+        sums_values(v, ok, r, a.ro.w ? s_w[lane ^ ((unsigned)a.flags >> 30)] : 1.0);
+        const double tot = run_sums8(v, s_red + (lane >> 6) * (8 * kTileStride), lane & 63);
+        tile_sums_store(tot, __ballot(ok), &s_part[0][0], lane, a.ro.scratch, (n + kBlock - 1) / kBlock, tile);
+      } else {
       double acc[kReadoutSlots];
       double Ix, Iy, Iz, x = 0.0, y = 0.0, o = 0.0;
       if (ok) art::detector_ray(a.ro.det, r, Ix, Iy, Iz, x, y, o);
@@ -718,6 +832,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
           v = (lane < 16) ? v + q : (lane < 19 ? fmin(v, q) : fmax(v, q));    // rows 16-18: minima, 19-21: maxima
         }
         a.ro.scratch[(int64_t)lane * nbx + bx] = v;
+      }
       }
     }
     i0 += stride;
@@ -789,7 +904,16 @@ __device__ __forceinline__ void chain_body2(const ChainArgs& a, const int64_t fi
     if (n & 1)      // odd n: the 16-bit store of the pair that holds the last slot was dropped by the range check
       __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(ok[0] ? 1 : 0), ra, (o2 + 1u == (unsigned)n) ? (int)o2 : (int)kDropOffset, 0, ART_ST_AUX);
   } while (++k < a.n_elems);
-  if (a.flags & art::kFlagReadout) {
+  if ((a.flags & art::kFlagReadout) && a.ro.sums) {     // pass (1) of the analysis instead of a read-out: see run_sums8
+    const unsigned li = lane ^ ((unsigned)a.flags >> 30);
+    double v0[8], v1[8], totA, totB;
+    sums_values(v0, ok[0], r[0], a.ro.w ? s_w[0][li] : 1.0);
+    sums_values(v1, ok[1], r[1], a.ro.w ? s_w[1][li] : 1.0);
+    run_sums8_pairs(v0, v1, s_red + (lane >> 6) * (8 * kTileStride), lane & 63, totA, totB);
+    static_assert(sizeof(s_part) >= sizeof(double) * 8 * kSumRows, "eight runs fit the partial area");
+    tile_sums_store_pairs(totA, totB, __ballot(ok[0]), __ballot(ok[1]), &s_part[0][0], lane, a.ro.scratch,
+                          (n + kBlock - 1) / kBlock, tile);
+  } else if (a.flags & art::kFlagReadout) {
     double acc[kReadoutSlots];
     double Ix, Iy, Iz, x[2] = {0.0, 0.0}, y[2] = {0.0, 0.0}, o[2] = {0.0, 0.0};
 #pragma unroll
@@ -932,6 +1056,50 @@ inline void launch_fold_scene(const ChainArgs* seg, int n_chains, int64_t nparts
                      seg, nparts, direct);
 }
 
+// Fold of the per-tile partial SUMS (kSumRows rows of `ntiles`, see run_sums8) into out[0 .. 8]: the same launch shape and
+// fold_range for the tail of a tracing launch and for art_analyse_bundles' own pass (1) -- same bits either way.  Beyond
+// kFoldDirect tiles two stages, with the chunk totals behind the rows (rows + kSumRows * ntiles, kSumRows x kFoldChunks).
+__device__ __forceinline__ void sums_fold1(double* rows, const int64_t ntiles) {
+  const int64_t per = (ntiles + kFoldChunks - 1) / kFoldChunks;
+  const int64_t lo = (int64_t)blockIdx.y * per, hi = (lo + per < ntiles) ? lo + per : ntiles;
+  fold_range(rows + (int64_t)blockIdx.x * ntiles, lo < hi ? lo : hi, hi, RSUM,
+             rows + (int64_t)kSumRows * ntiles + blockIdx.x * kFoldChunks + blockIdx.y);
+}
+__device__ __forceinline__ void sums_fold2(double* rows, const int64_t ntiles, double* out, const int direct) {
+  if (direct) fold_range(rows + (int64_t)blockIdx.x * ntiles, 0, ntiles, RSUM, out + blockIdx.x);
+  else fold_range(rows + (int64_t)kSumRows * ntiles + blockIdx.x * kFoldChunks, 0, kFoldChunks, RSUM, out + blockIdx.x);
+}
+__global__ __launch_bounds__(kFoldBlock) void k_chain_sums_fold1(const ChainArgs* __restrict__ tab, const int64_t ntiles) {
+  sums_fold1(tab[blockIdx.z].ro.scratch, ntiles);
+}
+__global__ __launch_bounds__(kFoldBlock) void k_chain_sums_fold2(const ChainArgs* __restrict__ tab, const int64_t ntiles,
+                                                                 const int direct) {
+  sums_fold2(tab[blockIdx.z].ro.scratch, ntiles, tab[blockIdx.z].ro.out24, direct);
+  if (blockIdx.x == 0 && threadIdx.x < kReadoutSlots - kSumRows) tab[blockIdx.z].ro.out24[kSumRows + threadIdx.x] = 0.0;
+}
+__global__ __launch_bounds__(kFoldBlock) void k_chain_sums_fold1_one(double* scratch, const int64_t ntiles) {
+  sums_fold1(scratch, ntiles);
+}
+__global__ __launch_bounds__(kFoldBlock) void k_chain_sums_fold2_one(double* scratch, double* out24, const int64_t ntiles,
+                                                                     const int direct) {
+  sums_fold2(scratch, ntiles, out24, direct);
+  if (blockIdx.x == 0 && threadIdx.x < kReadoutSlots - kSumRows) out24[kSumRows + threadIdx.x] = 0.0;
+}
+inline void launch_sums_fold_one(double* scratch, double* out24, int64_t ntiles, hipStream_t s) {
+  const int direct = ntiles <= kFoldDirect;
+  if (!direct)
+    hipLaunchKernelGGL(k_chain_sums_fold1_one, dim3(kSumRows, kFoldChunks), dim3(kFoldBlock), 0, s, scratch, ntiles);
+  hipLaunchKernelGGL(k_chain_sums_fold2_one, dim3(kSumRows), dim3(direct ? fold_threads(ntiles) : kBlock), 0, s, scratch, out24,
+                     ntiles, direct);
+}
+inline void launch_sums_fold_scene(const ChainArgs* seg, int n_chains, int64_t ntiles, hipStream_t s) {
+  const int direct = ntiles <= kFoldDirect;
+  if (!direct)
+    hipLaunchKernelGGL(k_chain_sums_fold1, dim3(kSumRows, kFoldChunks, n_chains), dim3(kFoldBlock), 0, s, seg, ntiles);
+  hipLaunchKernelGGL(k_chain_sums_fold2, dim3(kSumRows, 1, n_chains), dim3(direct ? fold_threads(ntiles) : kBlock), 0, s, seg,
+                     ntiles, direct);
+}
+
 template <bool DEFECT, int WAVES>
 __global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain(const ChainArgs, const int64_t n, const int xmap) {
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];   // used by the -DART_ZERN_LDS build only
@@ -1026,6 +1194,7 @@ __global__ __launch_bounds__(kBlock) void k_detector(const ArtDetectorDesc d, co
   }
 }
 
+template <bool HAS_W>
 __global__ __launch_bounds__(kBlock) void k_stats_partial(const uint8_t* alive, const double* X, const double* Y,
                                                           const double* opl, const double* w, const int64_t n,
                                                           double* scratch) {
@@ -1034,16 +1203,30 @@ __global__ __launch_bounds__(kBlock) void k_stats_partial(const uint8_t* alive, 
   double acc[kRedSlots];
 #pragma unroll
   for (int k = 0; k < kRedSlots; ++k) acc[k] = (ops[k] == RSUM) ? 0.0 : (ops[k] == RMIN ? INFINITY : -INFINITY);
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    if (alive[i] == 0) continue;
-    const double x = X ? X[i] : 0.0, y = Y ? Y[i] : 0.0, o = opl ? opl[i] : 0.0, ww = w ? w[i] : 1.0;
-    acc[0] += 1.0; acc[1] += o;
-    acc[2] = fmin(acc[2], x); acc[3] = fmax(acc[3], x);
-    acc[4] = fmin(acc[4], y); acc[5] = fmax(acc[5], y);
-    acc[6] += x; acc[7] += y;
-    acc[8] += ww; acc[9] = fma(ww, x, acc[9]); acc[10] = fma(ww, y, acc[10]); acc[11] = fma(ww, o, acc[11]);
-    acc[12] = fmin(acc[12], o); acc[13] = fmax(acc[13], o);
+  const int64_t stride = (int64_t)gridDim.x * kBlock, last = n - 1;
+  for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < n; i0 += kRedUnroll * stride) {
+    double xv[kRedUnroll], yv[kRedUnroll], ov[kRedUnroll], wv[kRedUnroll];
+    bool live[kRedUnroll];
+#pragma unroll
+    for (int u = 0; u < kRedUnroll; ++u) {
+      const int64_t i = i0 + u * stride, c = i < n ? i : last;
+      live[u] = (ld_nt(alive + c) != 0) & (i < n);
+      xv[u] = X ? ld_nt(X + c) : 0.0;      // (wave-uniform: absent streams read 0)
+      yv[u] = Y ? ld_nt(Y + c) : 0.0;
+      ov[u] = opl ? ld_nt(opl + c) : 0.0;
+      wv[u] = HAS_W ? ld_nt(w + c) : 1.0;
+    }
+#pragma unroll
+    for (int u = 0; u < kRedUnroll; ++u) {
+      const bool l = live[u];
+      const double x = l ? xv[u] : 0.0, y = l ? yv[u] : 0.0, o = l ? ov[u] : 0.0, ww = l ? wv[u] : 0.0;
+      acc[0] += l ? 1.0 : 0.0; acc[1] += o;
+      acc[2] = fmin(acc[2], l ? xv[u] : INFINITY); acc[3] = fmax(acc[3], l ? xv[u] : -INFINITY);
+      acc[4] = fmin(acc[4], l ? yv[u] : INFINITY); acc[5] = fmax(acc[5], l ? yv[u] : -INFINITY);
+      acc[6] += x; acc[7] += y;
+      acc[8] += ww; acc[9] = fma(ww, x, acc[9]); acc[10] = fma(ww, y, acc[10]); acc[11] = fma(ww, o, acc[11]);
+      acc[12] = fmin(acc[12], l ? ov[u] : INFINITY); acc[13] = fmax(acc[13], l ? ov[u] : -INFINITY);
+    }
   }
   block_reduce_store<kRedSlots>(acc, ops, scratch + (int64_t)blockIdx.x * kRedSlots);
 }
@@ -1144,6 +1327,29 @@ __global__ __launch_bounds__(kBlock) void k_detector_readout(const ArtDetectorDe
 
 constexpr int kScanSlots = 33;
 
+// the slot's seven streams + weight of kU grid-stride iterations, requested up front (see ld_nt)
+template <int kU>
+struct SlotBatch {
+  art::Ray r[kU];
+  double w[kU];
+  bool live[kU];
+};
+template <int kU, bool HAS_W>
+__device__ __forceinline__ void load_batch(const ArtBundleView& b, const double* w, const int64_t i0, const int64_t stride,
+                                           const int64_t n, SlotBatch<kU>& q) {
+  const int64_t last = n - 1;
+#pragma unroll
+  for (int u = 0; u < kU; ++u) {
+    const int64_t i = i0 + u * stride, c = i < n ? i : last;
+    q.live[u] = (ld_nt(b.alive + c) != 0) & (i < n);
+    q.r[u].ox = ld_nt(b.ox + c); q.r[u].oy = ld_nt(b.oy + c); q.r[u].oz = ld_nt(b.oz + c);
+    q.r[u].dx = ld_nt(b.dx + c); q.r[u].dy = ld_nt(b.dy + c); q.r[u].dz = ld_nt(b.dz + c);
+    q.r[u].path = ld_nt(b.path + c);
+    q.w[u] = HAS_W ? ld_nt(w + c) : 1.0;
+  }
+}
+
+template <bool HAS_W>
 __global__ __launch_bounds__(kBlock) void k_scan_moments_partial(const ArtDetectorDesc d, const ArtBundleView b,
                                                                  const double* w, const int64_t n, const double co,
                                                                  const double span, double* scratch) {
@@ -1151,29 +1357,34 @@ __global__ __launch_bounds__(kBlock) void k_scan_moments_partial(const ArtDetect
 #pragma unroll
   for (int k = 0; k < kScanSlots; ++k) acc[k] = 0.0;
   const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    if (b.alive[i] == 0) continue;
-    art::Ray r;
-    load_ray(b, i, r);
-    double q0[3], sq[3];
-    bool crosses;
-    art::detector_ray_scan(d, r, span, q0[0], q0[1], q0[2], sq[0], sq[1], sq[2], crosses);
-    acc[32] += crosses ? 1.0 : 0.0;
-    q0[2] -= co;
-    sq[2] -= 1.0;
-    const double ww = w ? w[i] : 1.0;
-    acc[0] += 1.0;
-    acc[16] += ww;
+  constexpr int kU = 2;
+  for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < n; i0 += kU * stride) {
+    SlotBatch<kU> q;
+    load_batch<kU, HAS_W>(b, w, i0, stride, n, q);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int o = 1 + 5 * k;
-      acc[o] += q0[k]; acc[o + 1] += sq[k];
-      acc[o + 2] = fma(q0[k], q0[k], acc[o + 2]); acc[o + 3] = fma(q0[k], sq[k], acc[o + 3]);
-      acc[o + 4] = fma(sq[k], sq[k], acc[o + 4]);
-      const double wq = ww * q0[k], ws = ww * sq[k];
-      acc[16 + o] += wq; acc[16 + o + 1] += ws;
-      acc[16 + o + 2] = fma(wq, q0[k], acc[16 + o + 2]); acc[16 + o + 3] = fma(wq, sq[k], acc[16 + o + 3]);
-      acc[16 + o + 4] = fma(ws, sq[k], acc[16 + o + 4]);
+    for (int u = 0; u < kU; ++u) {
+      const bool l = q.live[u];
+      double q0[3], sq[3];
+      bool crosses;
+      art::detector_ray_scan(d, q.r[u], span, q0[0], q0[1], q0[2], sq[0], sq[1], sq[2], crosses);
+      acc[32] += (l && crosses) ? 1.0 : 0.0;
+      q0[2] -= co;
+      sq[2] -= 1.0;
+      const double ww = l ? q.w[u] : 0.0;
+      acc[0] += l ? 1.0 : 0.0;
+      acc[16] += ww;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int o = 1 + 5 * k;
+        const double a0 = l ? q0[k] : 0.0, s0 = l ? sq[k] : 0.0;       // (a dead slot's values are unspecified: selected away)
+        acc[o] += a0; acc[o + 1] += s0;
+        acc[o + 2] = fma(a0, a0, acc[o + 2]); acc[o + 3] = fma(a0, s0, acc[o + 3]);
+        acc[o + 4] = fma(s0, s0, acc[o + 4]);
+        const double wq = ww * a0, ws = ww * s0;
+        acc[16 + o] += wq; acc[16 + o + 1] += ws;
+        acc[16 + o + 2] = fma(wq, a0, acc[16 + o + 2]); acc[16 + o + 3] = fma(wq, s0, acc[16 + o + 3]);
+        acc[16 + o + 4] = fma(ws, s0, acc[16 + o + 4]);
+      }
     }
   }
   block_reduce_store_f<kScanSlots>(acc, [](int) { return (int)RSUM; }, scratch + (int64_t)blockIdx.x * kScanSlots);
@@ -1189,37 +1400,64 @@ __global__ __launch_bounds__(kBlock) void k_readout_final(const double* scratch,
   fold_slot(scratch, nblocks, kReadoutSlots, ops[blockIdx.x], out);
 }
 
+template <bool HAS_W>
 __global__ __launch_bounds__(kBlock) void k_moments_partial(const uint8_t* alive, const double* X, const double* Y,
                                                             const double* opl, const double* w, const int64_t n,
                                                             const double cx, const double cy, const double co,
                                                             double* scratch) {
   const int ops[kSumSlots] = {RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM};
   double acc[kSumSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    if (alive[i] == 0) continue;
-    const double ww = w ? w[i] : 1.0;
-    const double ex = X ? X[i] - cx : 0.0, ey = Y ? Y[i] - cy : 0.0, eo = opl ? opl[i] - co : 0.0;
-    acc[0] += ww;
-    acc[1] = fma(ww * ex, ex, acc[1]);
-    acc[2] = fma(ww * ey, ey, acc[2]);
-    acc[3] = fma(ww * eo, eo, acc[3]);
-    acc[4] += 1.0;
+  const int64_t stride = (int64_t)gridDim.x * kBlock, last = n - 1;
+  for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < n; i0 += kRedUnroll * stride) {
+    double xv[kRedUnroll], yv[kRedUnroll], ov[kRedUnroll], wv[kRedUnroll];
+    bool live[kRedUnroll];
+#pragma unroll
+    for (int u = 0; u < kRedUnroll; ++u) {
+      const int64_t i = i0 + u * stride, c = i < n ? i : last;
+      live[u] = (ld_nt(alive + c) != 0) & (i < n);
+      xv[u] = X ? ld_nt(X + c) : cx;       // (wave-uniform: an absent stream sits on its centre)
+      yv[u] = Y ? ld_nt(Y + c) : cy;
+      ov[u] = opl ? ld_nt(opl + c) : co;
+      wv[u] = HAS_W ? ld_nt(w + c) : 1.0;
+    }
+#pragma unroll
+    for (int u = 0; u < kRedUnroll; ++u) {
+      const bool l = live[u];
+      const double ww = l ? wv[u] : 0.0;
+      const double ex = (l && X) ? xv[u] - cx : 0.0, ey = (l && Y) ? yv[u] - cy : 0.0, eo = (l && opl) ? ov[u] - co : 0.0;
+      acc[0] += ww;
+      acc[1] = fma(ww * ex, ex, acc[1]);
+      acc[2] = fma(ww * ey, ey, acc[2]);
+      acc[3] = fma(ww * eo, eo, acc[3]);
+      acc[4] += l ? 1.0 : 0.0;
+    }
   }
   block_reduce_store<kSumSlots>(acc, ops, scratch + (int64_t)blockIdx.x * kSumSlots);
 }
 
+template <bool HAS_W>
 __global__ __launch_bounds__(kBlock) void k_bundle_sums_partial(const ArtBundleView b, const double* w,
                                                                 const int64_t n, double* scratch) {
   const int ops[kSumSlots] = {RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM};
   double acc[kSumSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    if (b.alive[i] == 0) continue;
-    acc[0] += 1.0;
-    acc[1] += b.ox[i]; acc[2] += b.oy[i]; acc[3] += b.oz[i];
-    acc[4] += b.dx[i]; acc[5] += b.dy[i]; acc[6] += b.dz[i];
-    acc[7] += w ? w[i] : 0.0;
+  const int64_t stride = (int64_t)gridDim.x * kBlock, last = n - 1;
+  for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < n; i0 += kRedUnroll * stride) {
+    double v[kRedUnroll][7];
+    bool live[kRedUnroll];
+#pragma unroll
+    for (int u = 0; u < kRedUnroll; ++u) {
+      const int64_t i = i0 + u * stride, c = i < n ? i : last;
+      live[u] = (ld_nt(b.alive + c) != 0) & (i < n);
+      v[u][0] = ld_nt(b.ox + c); v[u][1] = ld_nt(b.oy + c); v[u][2] = ld_nt(b.oz + c);
+      v[u][3] = ld_nt(b.dx + c); v[u][4] = ld_nt(b.dy + c); v[u][5] = ld_nt(b.dz + c);
+      v[u][6] = HAS_W ? ld_nt(w + c) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < kRedUnroll; ++u) {
+      acc[0] += live[u] ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) acc[1 + k] += live[u] ? v[u][k] : 0.0;
+    }
   }
   block_reduce_store<kSumSlots>(acc, ops, scratch + (int64_t)blockIdx.x * kSumSlots);
 }
@@ -1254,11 +1492,27 @@ __global__ __launch_bounds__(kBlock) void k_gauss_max_partial(const ArtBundleVie
                                                               double* scratch) {
   const int ops[kSumSlots] = {RMAX, RMAX, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM};
   double acc[kSumSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    if (b.alive[i] == 0) continue;
-    acc[0] = fmax(acc[0], angle_to_axis(ax, b.dx[i], b.dy[i], b.dz[i]));
-    acc[1] = fmax(acc[1], sqrt(art::dot3(b.ox[i], b.oy[i], b.oz[i], b.ox[i], b.oy[i], b.oz[i])));
+  const int64_t stride = (int64_t)gridDim.x * kBlock, last = n - 1;
+  constexpr int kU = 2;     // (an atan2 and three square roots per ray: the arithmetic hides the rest of the latency)
+  for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < n; i0 += kU * stride) {
+    double v[kU][6];
+    bool live[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int64_t i = i0 + u * stride, c = i < n ? i : last;
+      live[u] = (ld_nt(b.alive + c) != 0) & (i < n);
+      v[u][0] = ld_nt(b.ox + c); v[u][1] = ld_nt(b.oy + c); v[u][2] = ld_nt(b.oz + c);
+      v[u][3] = ld_nt(b.dx + c); v[u][4] = ld_nt(b.dy + c); v[u][5] = ld_nt(b.dz + c);
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      // a dead slot holds unspecified values: it takes part as the axis itself at the origin (angle 0, distance 0)
+      const double dx = live[u] ? v[u][3] : ax.x, dy = live[u] ? v[u][4] : ax.y, dz = live[u] ? v[u][5] : ax.z;
+      const double px = live[u] ? v[u][0] : 0.0, py = live[u] ? v[u][1] : 0.0, pz = live[u] ? v[u][2] : 0.0;
+      const double ang = angle_to_axis(ax, dx, dy, dz);
+      acc[0] = fmax(acc[0], live[u] ? ang : 0.0);
+      acc[1] = fmax(acc[1], sqrt(art::dot3(px, py, pz, px, py, pz)));
+    }
   }
   block_reduce_store<kSumSlots>(acc, ops, scratch + (int64_t)blockIdx.x * kSumSlots);
 }
@@ -1315,16 +1569,17 @@ __global__ __launch_bounds__(64) void k_trace_guides(const GuideArgs ga, double*
 
 // ------------------------------------------------------------------------------------------- batched analysis
 // art_analyse_bundles: blockIdx.y = job.  Partials per job and workgroup, folded in a fixed order.
-constexpr int kAnaSums = 9;      // count, sum point (3), sum vector (3), sum w, sum path
 constexpr int kAnaMom = 42;      // 32 moment sums, kink shifts (2), max angle, bounding box + path range (6), pad
 constexpr int kAnaPlace = 24;    // per job: ArtDetectorDesc (15 doubles), axis (3), co, pad
-constexpr int kAnaBlocks = 1024; // workgroups per job at most
-// Workgroups per job: a function of the ray count ALONE, so that a bundle's sums are folded in the same order whether it
-// is analysed alone or as one of a list (same bits either way).
+constexpr int kAnaBlocks = 1024; // workgroups per job of the moments pass at most
+constexpr int kAnaSumsPad = 16;  // doubles per job of the folded sums (9 used)
+// Workgroups per job of the moments pass: a function of the ray count ALONE, so that a bundle's moments are folded in the
+// same order whether it is analysed alone or as one of a list (same bits either way).
 inline int analysis_blocks(int64_t n) {
   const int64_t b = (n + kBlock - 1) / kBlock;
   return (int)(b < 1 ? 1 : (b > kAnaBlocks ? kAnaBlocks : b));
 }
+inline int64_t analysis_tiles(int64_t n) { return n < 1 ? 1 : (n + kBlock - 1) / kBlock; }
 __device__ __forceinline__ int ana_mom_op(const int q) {   // operator of moment-pass partial q
   return (q < 32) ? RSUM : ((q == 33 || q == 35 || q == 37 || q == 39) ? RMIN : ((q == 41) ? RSUM : RMAX));
 }
@@ -1332,45 +1587,58 @@ __device__ __forceinline__ int ana_mom_slot(const int q) { // where partial q la
   return (q < 32) ? 20 + q : ((q < 35) ? 53 + (q - 32) : 56 + (q - 35));
 }
 
+// Pass (1) for the jobs that do not bring their sums along (ArtAnalysisJob.sums): one workgroup per tile of 256 slots, one
+// ray per lane, the canonical order of run_sums8.  rows: [job][kSumRows][ntiles] (+ the chunk totals of a two-stage fold).
 __global__ __launch_bounds__(kBlock) void k_analysis_sums(const ArtAnalysisJob* __restrict__ jobs, const int64_t n,
-                                                          double* scratch) {
+                                                          double* rows, const int64_t job_stride) {
   const ArtAnalysisJob& jb = jobs[blockIdx.y];
-  const ArtBundleView b = jb.b;
-  const double* w = jb.w;
-  const int ops[kAnaSums] = {RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM};
-  double acc[kAnaSums] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    if (b.alive[i] == 0) continue;
-    acc[0] += 1.0;
-    acc[1] += b.ox[i]; acc[2] += b.oy[i]; acc[3] += b.oz[i];
-    acc[4] += b.dx[i]; acc[5] += b.dy[i]; acc[6] += b.dz[i];
-    acc[7] += w ? w[i] : 1.0;
-    acc[8] += b.path[i];
+  if (jb.sums != nullptr) return;      // (workgroup-uniform) formed by the tracing launch already
+  __shared__ __attribute__((aligned(16))) double s_tile[(kBlock / 64) * 8 * kTileStride];
+  __shared__ double s_run[(kBlock / 64) * kSumRows];
+  const unsigned t = threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + t, c = i < n ? i : n - 1;
+  const ArtBundleView& b = jb.b;
+  const bool live = (ld_nt(b.alive + c) != 0) & (i < n);
+  art::Ray r;
+  r.ox = ld_nt(b.ox + c); r.oy = ld_nt(b.oy + c); r.oz = ld_nt(b.oz + c);
+  r.dx = ld_nt(b.dx + c); r.dy = ld_nt(b.dy + c); r.dz = ld_nt(b.dz + c);
+  r.path = ld_nt(b.path + c);
+  const double w = jb.w ? ld_nt(jb.w + c) : 1.0;
+  double v[8];
+  sums_values(v, live, r, w);
+  const double tot = run_sums8(v, s_tile + (t >> 6) * (8 * kTileStride), t & 63);
+  tile_sums_store(tot, __ballot(live), s_run, t, rows + (int64_t)blockIdx.y * job_stride, gridDim.x, blockIdx.x);
+}
+// grids (kSumRows, kFoldChunks, jobs) and (kSumRows, 1, jobs): the folds of launch_sums_fold_*, or a copy of the sums a job
+// brought along
+__global__ __launch_bounds__(kFoldBlock) void k_analysis_sums_fold1(const ArtAnalysisJob* __restrict__ jobs, double* rows,
+                                                                    const int64_t job_stride, const int64_t ntiles) {
+  if (jobs[blockIdx.z].sums != nullptr) return;
+  sums_fold1(rows + (int64_t)blockIdx.z * job_stride, ntiles);
+}
+__global__ __launch_bounds__(kFoldBlock) void k_analysis_sums_fold2(const ArtAnalysisJob* __restrict__ jobs, double* rows,
+                                                                    const int64_t job_stride, const int64_t ntiles,
+                                                                    const int direct, double* sums) {
+  double* out = sums + (int64_t)blockIdx.z * kAnaSumsPad;
+  const double* given = jobs[blockIdx.z].sums;
+  if (given != nullptr) {
+    if (threadIdx.x == 0) out[blockIdx.x] = given[blockIdx.x];
+    return;
   }
-  block_reduce_store<kAnaSums>(acc, ops, scratch + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * kAnaSums);
+  sums_fold2(rows + (int64_t)blockIdx.z * job_stride, ntiles, out, direct);
 }
 
-// one workgroup per job: fold the sums (thread t takes partials t, t + 256, ...; fixed tree), place the detector
-__global__ __launch_bounds__(kBlock) void k_analysis_place(const ArtAnalysisJob* __restrict__ jobs, const int nblocks,
-                                                           const double* partials, double* place, double* out) {
-  const int j = blockIdx.x;
-  __shared__ double s_sum[kAnaSums];
-  const int ops[kAnaSums] = {RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM};
-  double acc[kAnaSums] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const double* mine = partials + (int64_t)j * nblocks * kAnaSums;
-  for (int blk = threadIdx.x; blk < nblocks; blk += kBlock) {
-#pragma unroll
-    for (int k = 0; k < kAnaSums; ++k) acc[k] += mine[(int64_t)blk * kAnaSums + k];
-  }
-  block_reduce_store<kAnaSums>(acc, ops, s_sum);
-  __syncthreads();
-  if (threadIdx.x != 0) return;
+// one thread per job: the sums are folded; place the detector
+__global__ __launch_bounds__(64) void k_analysis_place(const ArtAnalysisJob* __restrict__ jobs, const int n_jobs,
+                                                       const double* sums, double* place, double* out) {
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  if (j >= n_jobs) return;
+  const double* s_sum = sums + (int64_t)j * kAnaSumsPad;
   const ArtAnalysisJob& jb = jobs[j];
   double* o = out + (int64_t)j * ART_ANALYSIS_DOUBLES;
   double* pl = place + (int64_t)j * kAnaPlace;
   for (int k = 0; k < ART_ANALYSIS_DOUBLES; ++k) o[k] = 0.0;
-  for (int k = 0; k < kAnaSums; ++k) o[k] = s_sum[k];
+  for (int k = 0; k < kSumRows; ++k) o[k] = s_sum[k];
   o[53] = -INFINITY; o[54] = INFINITY;
   o[56] = INFINITY; o[57] = -INFINITY; o[58] = INFINITY; o[59] = -INFINITY; o[60] = INFINITY; o[61] = -INFINITY;
   if (jb.mode == ART_JOB_SUMS) return;
@@ -1390,6 +1658,71 @@ __global__ __launch_bounds__(kBlock) void k_analysis_place(const ArtAnalysisJob*
   pl[18] = co;
 }
 
+// The moments pass keeps 42 accumulators (84 VGPRs) beside the ray: 128 VGPRs = 4 waves per SIMD, which is also all the
+// fixed grid of 1024 workgroups offers.  What it gained in round 5: the next slot's nine streams are requested
+// UNCONDITIONALLY (ld_nt, selects instead of the alive-guarded skip) while the current slot is worked on.
+template <bool HAS_W>
+__device__ __forceinline__ void moments_body(const ArtAnalysisJob& jb, const int64_t n, const double* pl, double (&acc)[kAnaMom]) {
+  ArtDetectorDesc d;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { d.centre[k] = pl[k]; d.normal[k] = pl[3 + k]; }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) d.rot[k] = pl[6 + k];
+  const Axis3 ax = {pl[15], pl[16], pl[17]};
+  const double au = sqrt(art::dot3(ax.x, ax.y, ax.z, ax.x, ax.y, ax.z));      // |axis|: once, not per ray
+  const double inv_nn = 1.0 / art::dot3(d.normal[0], d.normal[1], d.normal[2], d.normal[0], d.normal[1], d.normal[2]);
+  const double co = pl[18];
+  const ArtBundleView b = jb.b;
+  const double* w = jb.w;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  // Every stream of the slot is requested UNCONDITIONALLY at the top of its iteration (alive is applied by selects: no
+  // load waits for another load); buffer descriptors: one 32-bit offset register serves all nine streams (nine 64-bit
+  // addresses would not fit beside the accumulators), slots beyond the end read 0 = dead.  A software pipeline (the next
+  // slot's loads in flight behind this slot's arithmetic) does NOT fit: 41 fp64 accumulators + two slots' state exceed
+  // the 128 registers of 4 waves per SIMD and the compiler parks the prefetched values in scratch (tried, round 5).
+  // n <= 2^28 (checked by the host).
+  const BundleRsrc rb = make_rsrc(b, n);
+  const __amdgpu_buffer_rsrc_t rw = rsrc_of(const_cast<double*>(w), HAS_W ? (unsigned)(n * 8) : 0u);
+  const unsigned ustride = (unsigned)stride, un_ = (unsigned)n;
+  int cnt = 0;
+  for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < un_; i += ustride) {
+    const double cox = ld_f64(rb.ox, i * 8u), coy = ld_f64(rb.oy, i * 8u), coz = ld_f64(rb.oz, i * 8u);
+    const double cdx = ld_f64(rb.dx, i * 8u), cdy = ld_f64(rb.dy, i * 8u), cdz = ld_f64(rb.dz, i * 8u);
+    const bool l = __builtin_amdgcn_raw_buffer_load_b8(rb.alive, (int)i, 0, ART_LD_AUX) != 0;
+    const double pth = ld_f64(rb.path, i * 8u);
+    const double wv = HAS_W ? ld_f64(rw, i * 8u) : 1.0;
+    art::Ray r;
+    r.ox = cox; r.oy = coy; r.oz = coz; r.dx = cdx; r.dy = cdy; r.dz = cdz; r.path = pth; r.inc = 0.0;
+    double q0[3], sq[3], sk, un;
+    art::detector_ray_scan_kink(d, r, inv_nn, q0[0], q0[1], q0[2], sq[0], sq[1], sq[2], sk, un);
+    acc[35] = fmin(acc[35], l ? q0[0] : INFINITY); acc[36] = fmax(acc[36], l ? q0[0] : -INFINITY);
+    acc[37] = fmin(acc[37], l ? q0[1] : INFINITY); acc[38] = fmax(acc[38], l ? q0[1] : -INFINITY);
+    acc[39] = fmin(acc[39], l ? q0[2] : INFINITY); acc[40] = fmax(acc[40], l ? q0[2] : -INFINITY);
+    acc[32] = fmax(acc[32], (l && sk <= 0.0) ? sk : -INFINITY);
+    acc[33] = fmin(acc[33], (l && sk > 0.0) ? sk : INFINITY);
+    const double t2 = tan2_half_angle_to_axis(ax, au, r.dx, r.dy, r.dz, un);
+    acc[34] = fmax(acc[34], l ? t2 : 0.0);
+    q0[2] -= co;
+    sq[2] -= 1.0;
+    const double ww = l ? wv : 0.0;
+    cnt += l ? 1 : 0;
+    acc[16] += ww;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int o = 1 + 5 * k;
+      const double a0 = l ? q0[k] : 0.0, s0 = l ? sq[k] : 0.0;       // (a dead slot's values are unspecified: selected away)
+      acc[o] += a0; acc[o + 1] += s0;
+      acc[o + 2] = fma(a0, a0, acc[o + 2]); acc[o + 3] = fma(a0, s0, acc[o + 3]);
+      acc[o + 4] = fma(s0, s0, acc[o + 4]);
+      const double wq = ww * a0, ws = ww * s0;
+      acc[16 + o] += wq; acc[16 + o + 1] += ws;
+      acc[16 + o + 2] = fma(wq, a0, acc[16 + o + 2]); acc[16 + o + 3] = fma(wq, s0, acc[16 + o + 3]);
+      acc[16 + o + 4] = fma(ws, s0, acc[16 + o + 4]);
+    }
+  }
+  acc[0] = (double)cnt;      // (a lane folds < 2^31 slots: the integer count is exact, as the sum of 1.0s was)
+}
+
 __global__ __launch_bounds__(kBlock, 4) void k_analysis_moments(const ArtAnalysisJob* __restrict__ jobs, const int64_t n,
                                                              const double* place, const double* out, double* scratch) {
   const int j = blockIdx.y;
@@ -1400,48 +1733,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_analysis_moments(const ArtAnalysi
   acc[34] = 0.0;    // the largest angle of an empty set is 0 (ReturnNumericalAperture's max over nothing never happens)
   const bool active = jb.mode != ART_JOB_SUMS && out[(int64_t)j * ART_ANALYSIS_DOUBLES] > 0.0;
   if (active) {
-    const double* pl = place + (int64_t)j * kAnaPlace;
-    ArtDetectorDesc d;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { d.centre[k] = pl[k]; d.normal[k] = pl[3 + k]; }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) d.rot[k] = pl[6 + k];
-    const Axis3 ax = {pl[15], pl[16], pl[17]};
-    const double au = sqrt(art::dot3(ax.x, ax.y, ax.z, ax.x, ax.y, ax.z));      // |axis|: once, not per ray
-    const double inv_nn = 1.0 / art::dot3(d.normal[0], d.normal[1], d.normal[2], d.normal[0], d.normal[1], d.normal[2]);
-    const double co = pl[18];
-    const ArtBundleView b = jb.b;
-    const double* w = jb.w;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-      if (b.alive[i] == 0) continue;
-      art::Ray r;
-      load_ray(b, i, r);
-      double q0[3], sq[3], sk, un;
-      art::detector_ray_scan_kink(d, r, inv_nn, q0[0], q0[1], q0[2], sq[0], sq[1], sq[2], sk, un);
-      acc[35] = fmin(acc[35], q0[0]); acc[36] = fmax(acc[36], q0[0]);
-      acc[37] = fmin(acc[37], q0[1]); acc[38] = fmax(acc[38], q0[1]);
-      acc[39] = fmin(acc[39], q0[2]); acc[40] = fmax(acc[40], q0[2]);
-      acc[32] = fmax(acc[32], (sk <= 0.0) ? sk : -INFINITY);
-      acc[33] = fmin(acc[33], (sk > 0.0) ? sk : INFINITY);
-      acc[34] = fmax(acc[34], tan2_half_angle_to_axis(ax, au, r.dx, r.dy, r.dz, un));
-      q0[2] -= co;
-      sq[2] -= 1.0;
-      const double ww = w ? w[i] : 1.0;
-      acc[0] += 1.0;
-      acc[16] += ww;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int o = 1 + 5 * k;
-        acc[o] += q0[k]; acc[o + 1] += sq[k];
-        acc[o + 2] = fma(q0[k], q0[k], acc[o + 2]); acc[o + 3] = fma(q0[k], sq[k], acc[o + 3]);
-        acc[o + 4] = fma(sq[k], sq[k], acc[o + 4]);
-        const double wq = ww * q0[k], ws = ww * sq[k];
-        acc[16 + o] += wq; acc[16 + o + 1] += ws;
-        acc[16 + o + 2] = fma(wq, q0[k], acc[16 + o + 2]); acc[16 + o + 3] = fma(wq, sq[k], acc[16 + o + 3]);
-        acc[16 + o + 4] = fma(ws, sq[k], acc[16 + o + 4]);
-      }
-    }
+    if (jb.w) moments_body<true>(jb, n, place + (int64_t)j * kAnaPlace, acc);
+    else moments_body<false>(jb, n, place + (int64_t)j * kAnaPlace, acc);
   }
   block_reduce_store_f<kAnaMom>(acc, [](int k) { return ana_mom_op(k); }, scratch + ((int64_t)j * gridDim.x + blockIdx.x) * kAnaMom);
 }
@@ -1456,9 +1749,13 @@ __global__ __launch_bounds__(kBlock) void k_analysis_fold(const ArtAnalysisJob* 
   const double ident = (op == RSUM) ? 0.0 : (op == RMIN ? INFINITY : -INFINITY);
   double acc[1] = {ident};
   const double* mine = scratch + (int64_t)j * nblocks * kAnaMom;
-  for (int blk = threadIdx.x; blk < nblocks; blk += kBlock) {
-    const double v = mine[(int64_t)blk * kAnaMom + q];
-    acc[0] = (op == RSUM) ? acc[0] + v : (op == RMIN ? fmin(acc[0], v) : fmax(acc[0], v));
+  constexpr int kU = 4;    // partials in flight per thread (the fold order stays blk, blk + 256, ...)
+  for (int blk = threadIdx.x; blk < nblocks; blk += kBlock * kU) {
+    double v[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) v[u] = (blk + u * kBlock < nblocks) ? mine[(int64_t)(blk + u * kBlock) * kAnaMom + q] : ident;
+#pragma unroll
+    for (int u = 0; u < kU; ++u) acc[0] = (op == RSUM) ? acc[0] + v[u] : (op == RMIN ? fmin(acc[0], v[u]) : fmax(acc[0], v[u]));
   }
   __shared__ double s_res[1];
   block_reduce_store<1>(acc, op1, s_res);
@@ -1472,13 +1769,29 @@ __global__ __launch_bounds__(kBlock) void k_analysis_fold(const ArtAnalysisJob* 
 // counts by one workgroup, scatter with an intra-wave ballot/popcount rank.
 constexpr int kTile = 2048;  // slots per workgroup: 8 per lane
 
+// number of non-zero bytes of a 64-bit word
+__device__ __forceinline__ int nonzero_bytes(const unsigned long long x) {
+  const unsigned long long lo7 = 0x7f7f7f7f7f7f7f7full;
+  return __popcll(((x & lo7) + lo7 | x) & ~lo7);
+}
+// A tile's 2048 alive bytes as ONE 8-byte load per lane (the count needs no order); the last, partial tile and a mask that
+// does not start on an 8-byte boundary take the byte path.  10 MB per 1e7 rays: the kernel is a few microseconds of launch
+// and latency, not bandwidth (it was 14.6 us with eight dependent byte loads per lane).
 __global__ __launch_bounds__(kBlock) void k_compact_count(const uint8_t* alive, const int64_t n, int32_t* counts) {
   __shared__ int s[kBlock / 64];
   const int64_t base = (int64_t)blockIdx.x * kTile;
   int c = 0;
-  for (int j = 0; j < kTile / kBlock; ++j) {
-    const int64_t i = base + j * kBlock + threadIdx.x;
-    c += (i < n && alive[i] != 0) ? 1 : 0;
+  if (base + kTile <= n && (reinterpret_cast<uintptr_t>(alive) & 7u) == 0) {     // (workgroup-uniform)
+    c = nonzero_bytes(ld_nt(reinterpret_cast<const unsigned long long*>(alive + base) + threadIdx.x));
+  } else {
+    uint8_t a[kTile / kBlock];
+#pragma unroll
+    for (int j = 0; j < kTile / kBlock; ++j) {
+      const int64_t i = base + j * kBlock + threadIdx.x;
+      a[j] = (i < n) ? alive[i] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < kTile / kBlock; ++j) c += a[j] != 0 ? 1 : 0;
   }
   for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
   if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
@@ -1511,28 +1824,58 @@ __global__ __launch_bounds__(1024) void k_compact_scan(int32_t* counts, const in
   if (threadIdx.x == 1023) *total = s[1023];
 }
 
+// Ranks of a tile's alive slots, all eight passes at once: the eight alive bytes of a lane (slots base + j*256 + t) are
+// requested together, every wave ballots its eight passes and parks the popcounts, ONE barrier, and each lane adds up what
+// lies in front of it (passes before its own in full, earlier waves of its own pass, its rank inside the ballot).  Round 4
+// did this pass by pass: eight dependent byte loads and sixteen barriers per tile.
+struct TileRanks {
+  bool a[kTile / kBlock];
+  int pos[kTile / kBlock];     // position of slot j among the tile's alive slots (valid where a[j])
+};
+__device__ __forceinline__ void tile_ranks(const uint8_t* alive, const int64_t n, const int64_t base, int (*s_cnt)[kBlock / 64],
+                                           TileRanks& q) {
+  constexpr int P = kTile / kBlock;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint8_t raw[P];
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    const int64_t i = base + j * kBlock + threadIdx.x;
+    raw[j] = (i < n) ? ld_nt(alive + i) : 0;
+  }
+  int rank[P];
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    q.a[j] = raw[j] != 0;
+    const unsigned long long m = __ballot(q.a[j]);
+    rank[j] = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_cnt[j][wv] = __popcll(m);
+  }
+  __syncthreads();
+  int run = 0;
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    int before = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < kBlock / 64; ++k) {
+      const int c = s_cnt[j][k];
+      before += (k < wv) ? c : 0;
+      tot += c;
+    }
+    q.pos[j] = run + before + rank[j];
+    run += tot;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_compact_scatter(const uint8_t* alive, const int64_t n,
                                                             const int64_t* tile_offsets, int64_t* idx_out) {
-  __shared__ int s_wave[kBlock / 64];
+  __shared__ int s_cnt[kTile / kBlock][kBlock / 64];
   const int64_t base = (int64_t)blockIdx.x * kTile;
-  int64_t run = tile_offsets[blockIdx.x];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int j = 0; j < kTile / kBlock; ++j) {
-    const int64_t i = base + j * kBlock + threadIdx.x;
-    const bool a = (i < n) && alive[i] != 0;
-    const unsigned long long m = __ballot(a);
-    const int rank = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) s_wave[wv] = __popcll(m);
-    __syncthreads();
-    int before = 0, tot = 0;
-    for (int k = 0; k < kBlock / 64; ++k) {
-      if (k < wv) before += s_wave[k];
-      tot += s_wave[k];
-    }
-    if (a) idx_out[run + before + rank] = i;
-    run += tot;
-    __syncthreads();
-  }
+  const int64_t run = tile_offsets[blockIdx.x];
+  TileRanks q;
+  tile_ranks(alive, n, base, s_cnt, q);
+#pragma unroll
+  for (int j = 0; j < kTile / kBlock; ++j)
+    if (q.a[j]) idx_out[run + q.pos[j]] = base + j * kBlock + threadIdx.x;
 }
 
 // ------------------------------------------------------------------------------------------- survivor records
@@ -1555,7 +1898,7 @@ __global__ __launch_bounds__(kBlock) void k_survivor_scatter(const uint8_t* aliv
                                                              const double* Y, const double* opl, const int64_t* number,
                                                              const int64_t first, const int64_t step,
                                                              unsigned char* send) {
-  __shared__ int s_wave[kBlock / 64];
+  __shared__ int s_cnt[kTile / kBlock][kBlock / 64];
   const int64_t* header = reinterpret_cast<const int64_t*>(send);
   const int64_t count = header[0];
   const bool dense = (header[1] & kSurvDense) != 0;
@@ -1564,27 +1907,40 @@ __global__ __launch_bounds__(kBlock) void k_survivor_scatter(const uint8_t* aliv
   double* so = sy + count;
   int32_t* sn = reinterpret_cast<int32_t*>(so + count);
   const int64_t base = (int64_t)blockIdx.x * kTile;
-  int64_t run = tile_offsets[blockIdx.x];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int j = 0; j < kTile / kBlock; ++j) {
+  const int64_t run = tile_offsets[blockIdx.x];
+  TileRanks q;
+  tile_ranks(alive, n, base, s_cnt, q);
+  // the records of all eight passes are requested before the first is stored
+  constexpr int P = kTile / kBlock;
+  double xv[P], yv[P], ov[P];
+  int64_t nv[P];
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
     const int64_t i = base + j * kBlock + threadIdx.x;
-    const bool a = (i < n) && alive[i] != 0;
-    const unsigned long long m = __ballot(a);
-    const int rank = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) s_wave[wv] = __popcll(m);
-    __syncthreads();
-    int before = 0, tot = 0;
-    for (int k = 0; k < kBlock / 64; ++k) {
-      if (k < wv) before += s_wave[k];
-      tot += s_wave[k];
+    if (q.a[j]) {
+      xv[j] = ld_nt(X + i); yv[j] = ld_nt(Y + i); ov[j] = ld_nt(opl + i);
+      nv[j] = (number && !dense) ? ld_nt(number + i) : first + i * step;
     }
-    if (a) {
-      const int64_t p = run + before + rank;
-      sx[p] = X[i]; sy[p] = Y[i]; so[p] = opl[i];
-      if (!dense) sn[p] = (int32_t)(number ? number[i] : first + i * step);
+  }
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    if (q.a[j]) {
+      const int64_t p = run + q.pos[j];
+      sx[p] = xv[j]; sy[p] = yv[j]; so[p] = ov[j];
+      if (!dense) sn[p] = (int32_t)nv[j];
     }
-    run += tot;
-    __syncthreads();
+  }
+}
+
+// Zero-copy form of the send buffer (art_survivor_finish): the read-out wrote X, Y, path of ALL n slots straight into the
+// dense layout's sections; if every slot is alive the buffer is complete once its header says so.  Otherwise the header
+// says "unpacked" (flags bit 1): the sections hold slot-indexed values with holes, and the caller packs them elsewhere.
+constexpr int64_t kSurvUnpacked = 2;
+__global__ void k_survivor_finish(const double* stats24, const int64_t n, int64_t* header) {
+  if (threadIdx.x == 0) {
+    const int64_t count = (int64_t)stats24[0];
+    header[0] = count;
+    header[1] = (count == n) ? kSurvDense : kSurvUnpacked;
   }
 }
 
@@ -1839,7 +2195,7 @@ static int trace_chain_impl(const ArtElementDesc* elems, int32_t n_elems, const 
   }
   hipStream_t s = (hipStream_t)stream;
   if (ro) {
-    if (!art::readout_ok(*ro)) return fail(ART_ERR_BAD_ARG, "read-out: scratch/out24 missing or X/Y/opl partially NULL");
+    if (!art::readout_ok(*ro)) return fail(ART_ERR_BAD_ARG, "read-out: scratch/out24 missing, X/Y/opl partially NULL, or outputs / lite with sums");
     if (n > max_rays_per_launch()) return fail(ART_ERR_UNSUPPORTED, "fused read-out: more rays than one launch covers");
 #ifdef ART_ZERN_LDS
     return fail(ART_ERR_UNSUPPORTED, "ART_ZERN_LDS comparison build: no fused read-out");
@@ -1847,7 +2203,8 @@ static int trace_chain_impl(const ArtElementDesc* elems, int32_t n_elems, const 
   }
   if (n == 0) {
     if (ro) {   // nothing to trace: the statistics are the reduction identities
-      launch_fold_one(ro->scratch, ro->out24, 0, s);
+      if (ro->sums) launch_sums_fold_one(ro->scratch, ro->out24, 0, s);
+      else launch_fold_one(ro->scratch, ro->out24, 0, s);
       hipError_t e0 = hipGetLastError();
       if (e0 != hipSuccess) return fail_hip(e0, "art_trace_chain_readout launch");
     }
@@ -1908,7 +2265,9 @@ static int trace_chain_impl(const ArtElementDesc* elems, int32_t n_elems, const 
         hipLaunchKernelGGL((k_trace_chain<false, 6>), g, b, chain_dyn_lds(), s, a, cnt, xm);
       else
         hipLaunchKernelGGL((k_trace_chain<false, 5>), g, b, chain_dyn_lds(), s, a, cnt, xm);
-      if (tail)
+      if (tail && ro->sums)
+        launch_sums_fold_one(ro->scratch, ro->out24, analysis_tiles(cnt), s);
+      else if (tail)
         launch_fold_one(ro->scratch, ro->out24, (int64_t)g.x, s);
       cur = a.out[m - 1];
     }
@@ -1960,7 +2319,7 @@ int art_trace_scene(const void* image_dev, const void* image_host, int64_t n, vo
   if (h.magic != art::kSceneMagic) return fail(ART_ERR_BAD_ARG, "host image was not written by art_scene_pack");
   const int32_t n_chains = h.n_chains, n_elems = h.n_elems, flags = h.flags;
   if (n_chains <= 0 || n_chains > 65535 || n_elems <= 0 || h.n_segments != art::scene_segments(n_elems) ||
-      (flags & ~(art::kFlagDefects | art::kFlagReadout | art::kFlagMask | art::kFlagSharedIn)))
+      (flags & ~(art::kFlagDefects | art::kFlagReadout | art::kFlagMask | art::kFlagSharedIn | art::kFlagSums)))
     return fail(ART_ERR_BAD_ARG, "scene header is corrupt");
   if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
 #ifdef ART_ZERN_LDS
@@ -1972,7 +2331,9 @@ int art_trace_scene(const void* image_dev, const void* image_host, int64_t n, vo
   const ChainArgs* tab = art::scene_table(image_dev);
   const int S = art::scene_segments(n_elems);
   if (n == 0) {
-    if (flags & art::kFlagReadout)
+    if (flags & art::kFlagSums)
+      launch_sums_fold_scene(tab + (int64_t)(S - 1) * n_chains, n_chains, 0, s);
+    else if (flags & art::kFlagReadout)
       launch_fold_scene(tab + (int64_t)(S - 1) * n_chains, n_chains, 0, s);
     return ART_OK;
   }
@@ -1999,7 +2360,9 @@ int art_trace_scene(const void* image_dev, const void* image_host, int64_t n, vo
         hipLaunchKernelGGL((k_trace_scene<false, 6>), g, b, 0, s, seg, off, cnt, xm, tr);
       else
         hipLaunchKernelGGL((k_trace_scene<false, 5>), g, b, 0, s, seg, off, cnt, xm, tr);
-      if ((flags & art::kFlagReadout) && sg == S - 1)
+      if ((flags & art::kFlagSums) && sg == S - 1)
+        launch_sums_fold_scene(seg, n_chains, analysis_tiles(cnt), s);
+      else if ((flags & art::kFlagReadout) && sg == S - 1)
         launch_fold_scene(seg, n_chains, (int64_t)tiles, s);
     }
   }
@@ -2107,7 +2470,8 @@ int art_detector_scan_moments(const ArtDetectorDesc* d, const ArtBundleView* b, 
   if (!view_ok(b)) return fail(ART_ERR_BAD_ARG, "bundle view has a NULL array");
   int64_t nbk = (n + kBlock - 1) / kBlock;
   const int nb = (int)(nbk > kRedBlocks ? kRedBlocks : nbk);
-  hipLaunchKernelGGL(k_scan_moments_partial, dim3(nb), dim3(kBlock), 0, s, *d, *b, w, n, co, span, scratch);
+  if (w) hipLaunchKernelGGL(k_scan_moments_partial<true>, dim3(nb), dim3(kBlock), 0, s, *d, *b, w, n, co, span, scratch);
+  else hipLaunchKernelGGL(k_scan_moments_partial<false>, dim3(nb), dim3(kBlock), 0, s, *d, *b, w, n, co, span, scratch);
   hipLaunchKernelGGL(k_scan_moments_final, dim3(kScanSlots), dim3(kBlock), 0, s, scratch, nb, out32);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_detector_scan_moments launch");
@@ -2123,7 +2487,8 @@ int art_detector_stats(const uint8_t* alive, const double* X, const double* Y, c
   hipStream_t s = (hipStream_t)stream;
   int64_t b = (n + kBlock - 1) / kBlock;
   const int nb = (int)(b < 1 ? 1 : (b > kRedBlocks ? kRedBlocks : b));
-  hipLaunchKernelGGL(k_stats_partial, dim3(nb), dim3(kBlock), 0, s, alive, X, Y, opl, w, n, scratch);
+  if (w) hipLaunchKernelGGL(k_stats_partial<true>, dim3(nb), dim3(kBlock), 0, s, alive, X, Y, opl, w, n, scratch);
+  else hipLaunchKernelGGL(k_stats_partial<false>, dim3(nb), dim3(kBlock), 0, s, alive, X, Y, opl, w, n, scratch);
   hipLaunchKernelGGL(k_stats_final, dim3(kRedSlots), dim3(kBlock), 0, s, scratch, nb, out16);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_detector_stats launch");
@@ -2137,7 +2502,8 @@ int art_detector_moments(const uint8_t* alive, const double* X, const double* Y,
   hipStream_t s = (hipStream_t)stream;
   int64_t b = (n + kBlock - 1) / kBlock;
   const int nb = (int)(b < 1 ? 1 : (b > kRedBlocks ? kRedBlocks : b));
-  hipLaunchKernelGGL(k_moments_partial, dim3(nb), dim3(kBlock), 0, s, alive, X, Y, opl, w, n, cx, cy, co, scratch);
+  if (w) hipLaunchKernelGGL(k_moments_partial<true>, dim3(nb), dim3(kBlock), 0, s, alive, X, Y, opl, w, n, cx, cy, co, scratch);
+  else hipLaunchKernelGGL(k_moments_partial<false>, dim3(nb), dim3(kBlock), 0, s, alive, X, Y, opl, w, n, cx, cy, co, scratch);
   hipLaunchKernelGGL(k_sums_final, dim3(kSumSlots), dim3(kBlock), 0, s, scratch, nb, out8);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_detector_moments launch");
@@ -2150,7 +2516,8 @@ int art_bundle_sums(const ArtBundleView* bv, const double* w, int64_t n, double*
   hipStream_t s = (hipStream_t)stream;
   int64_t b = (n + kBlock - 1) / kBlock;
   const int nb = (int)(b < 1 ? 1 : (b > kRedBlocks ? kRedBlocks : b));
-  hipLaunchKernelGGL(k_bundle_sums_partial, dim3(nb), dim3(kBlock), 0, s, *bv, w, n, scratch);
+  if (w) hipLaunchKernelGGL(k_bundle_sums_partial<true>, dim3(nb), dim3(kBlock), 0, s, *bv, w, n, scratch);
+  else hipLaunchKernelGGL(k_bundle_sums_partial<false>, dim3(nb), dim3(kBlock), 0, s, *bv, w, n, scratch);
   hipLaunchKernelGGL(k_sums_final, dim3(kSumSlots), dim3(kBlock), 0, s, scratch, nb, out8);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_bundle_sums launch");
@@ -2352,9 +2719,12 @@ int art_trace_guides(const ArtElementDesc* elems, int32_t count, double* rays, u
   return ART_OK;
 }
 
-int64_t art_analysis_scratch_doubles(int32_t n_jobs) {
+// scratch layout of art_analyse_bundles: [job][kSumRows rows x ntiles + chunk totals] | [job][kAnaSumsPad] | [job][P][kAnaMom] | [job][kAnaPlace]
+static int64_t analysis_rows_stride(int64_t n) { return (int64_t)kSumRows * (analysis_tiles(n) + kFoldChunks); }
+int64_t art_analysis_scratch_doubles(int32_t n_jobs, int64_t n) {
   if (n_jobs < 1) n_jobs = 1;
-  return (int64_t)n_jobs * ((int64_t)kAnaBlocks * (kAnaSums + kAnaMom) + kAnaPlace);
+  if (n < 0) n = 0;
+  return (int64_t)n_jobs * (analysis_rows_stride(n) + kAnaSumsPad + (int64_t)kAnaBlocks * kAnaMom + kAnaPlace);
 }
 
 int art_analyse_bundles(const ArtAnalysisJob* jobs_dev, const ArtAnalysisJob* jobs_host, int32_t n_jobs, int64_t n,
@@ -2362,21 +2732,50 @@ int art_analyse_bundles(const ArtAnalysisJob* jobs_dev, const ArtAnalysisJob* jo
   if (!jobs_dev || !jobs_host || !scratch || !out) return fail(ART_ERR_BAD_ARG, "NULL argument");
   if (n_jobs <= 0 || n_jobs > 65535) return fail(ART_ERR_BAD_ARG, "n_jobs must be in 1..65535");
   if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
+  if (n > kMaxRaysPerLaunchHw) return fail(ART_ERR_UNSUPPORTED, "more than 2^28 rays per bundle in one analysis");
+  bool all_given = true;
   for (int j = 0; j < n_jobs; ++j) {
-    if (jobs_host[j].mode < ART_JOB_AUTOPLACE || jobs_host[j].mode > ART_JOB_SUMS) return fail(ART_ERR_BAD_ARG, "unknown job mode");
-    if (n > 0 && !view_ok(&jobs_host[j].b)) return fail(ART_ERR_BAD_ARG, "a job's bundle view has a NULL array");
+    const ArtAnalysisJob& jb = jobs_host[j];
+    if (jb.mode < ART_JOB_AUTOPLACE || jb.mode > ART_JOB_SUMS) return fail(ART_ERR_BAD_ARG, "unknown job mode");
+    if (n > 0 && !view_ok(&jb.b)) return fail(ART_ERR_BAD_ARG, "a job's bundle view has a NULL array");
+    if (jb.mode == ART_JOB_MANUAL) {
+      // the manual detector's normal is used bit for bit (rotation_to_ez and the Kahan angle assume a unit vector)
+      const double nn = jb.normal[0] * jb.normal[0] + jb.normal[1] * jb.normal[1] + jb.normal[2] * jb.normal[2];
+      if (!(fabs(nn - 1.0) <= 1e-12)) return fail(ART_ERR_BAD_ARG, "a manual job's detector normal is not a unit vector");
+    }
+    all_given = all_given && jb.sums != nullptr;
   }
   hipStream_t s = (hipStream_t)stream;
   const int P = analysis_blocks(n);
-  double* sums = scratch;
-  double* mom = sums + (int64_t)n_jobs * P * kAnaSums;
+  const int64_t ntiles = analysis_tiles(n), rstride = analysis_rows_stride(n);
+  double* rows = scratch;
+  double* sums = rows + (int64_t)n_jobs * rstride;
+  double* mom = sums + (int64_t)n_jobs * kAnaSumsPad;
   double* place = mom + (int64_t)n_jobs * P * kAnaMom;
-  hipLaunchKernelGGL(k_analysis_sums, dim3(P, n_jobs), dim3(kBlock), 0, s, jobs_dev, n, sums);
-  hipLaunchKernelGGL(k_analysis_place, dim3(n_jobs), dim3(kBlock), 0, s, jobs_dev, P, sums, place, out);
+  const int direct = ntiles <= kFoldDirect;
+  if (!all_given && n > 0) {
+    hipLaunchKernelGGL(k_analysis_sums, dim3((unsigned)ntiles, n_jobs), dim3(kBlock), 0, s, jobs_dev, n, rows, rstride);
+    if (!direct)
+      hipLaunchKernelGGL(k_analysis_sums_fold1, dim3(kSumRows, kFoldChunks, n_jobs), dim3(kFoldBlock), 0, s, jobs_dev, rows, rstride, ntiles);
+  }
+  // (n == 0: no tiles were written; a fold over zero tiles leaves the sums' identities -- all zero)
+  hipLaunchKernelGGL(k_analysis_sums_fold2, dim3(kSumRows, 1, n_jobs), dim3(direct ? fold_threads(n > 0 ? ntiles : 0) : kBlock), 0, s,
+                     jobs_dev, rows, rstride, n > 0 ? ntiles : 0, direct, sums);
+  hipLaunchKernelGGL(k_analysis_place, dim3((n_jobs + 63) / 64), dim3(64), 0, s, jobs_dev, (int)n_jobs, sums, place, out);
   hipLaunchKernelGGL(k_analysis_moments, dim3(P, n_jobs), dim3(kBlock), 0, s, jobs_dev, n, place, out, mom);
   hipLaunchKernelGGL(k_analysis_fold, dim3(kAnaMom - 1, n_jobs), dim3(kBlock), 0, s, jobs_dev, P, mom, out);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_analyse_bundles launch");
+  return ART_OK;
+}
+
+int art_survivor_finish(const double* stats24, int64_t n, void* send, void* stream) {
+  if (!stats24 || !send) return fail(ART_ERR_BAD_ARG, "NULL argument");
+  if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
+  if (((uintptr_t)send & 15u) != 0) return fail(ART_ERR_BAD_ARG, "send buffer must be 16-byte aligned");
+  hipLaunchKernelGGL(k_survivor_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, stats24, n, reinterpret_cast<int64_t*>(send));
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail_hip(err, "art_survivor_finish launch");
   return ART_OK;
 }
 

@@ -32,9 +32,11 @@ struct ChainArgs {
 constexpr int kFlagDefects = 1, kFlagReadout = 2;
 constexpr int kFlagMask = 4;     // scene header only: some chain contains a mask (selects the body of the launch)
 constexpr int kFlagSharedIn = 8; // scene header only: every chain reads the SAME input bundle (selects the grid shape)
+constexpr int kFlagSums = 16;    // scene header only: the tails form the analysis' sums (ArtChainReadout.sums), not a read-out
 
 inline bool readout_ok(const ArtChainReadout& r) {
   const int outs = (r.X != nullptr) + (r.Y != nullptr) + (r.opl != nullptr);
+  if (r.sums && (outs != 0 || r.lite)) return false;      // the sums tail has no per-ray outputs and no lite form
   return r.scratch && r.out24 && (outs == 0 || outs == 3);
 }
 
@@ -100,10 +102,12 @@ inline int scene_pack(const ArtElementDesc* elems, int n_chains, int n_elems, co
         a.out[k] = o;
       }
       if (ros && s == S - 1) {   // the read-out rides on the chain's last segment
-        if (!readout_ok(ros[c])) { *err = "read-out: scratch/out24 missing or X/Y/opl partially NULL"; return ART_ERR_BAD_ARG; }
+        if (!readout_ok(ros[c])) { *err = "read-out: scratch/out24 missing, X/Y/opl partially NULL, or outputs / lite with sums"; return ART_ERR_BAD_ARG; }
+        if ((ros[c].sums != 0) != (ros[0].sums != 0)) { *err = "read-outs of one scene must all be read-outs or all sums"; return ART_ERR_BAD_ARG; }
         a.ro = ros[c];
         a.flags |= kFlagReadout;
         h.flags |= kFlagReadout;
+        if (ros[c].sums) h.flags |= kFlagSums;
       }
       // the segment's last bundle is the next segment's input (or the chain's result): it must exist
       if (!scene_view_ok(a.out[m - 1])) {

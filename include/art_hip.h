@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ART_ABI_VERSION 10
+#define ART_ABI_VERSION 11
 
 /* error codes */
 #define ART_OK 0
@@ -184,7 +184,13 @@ typedef struct ArtChainReadout {
                             Detector.get_Delays / get_PointList2DCentre consume (ART/ModuleDetector.py:236-279); the sums
                             [6..11] and the second moments [16..21] read 0 and the weights `w` are not touched.  The tail
                             then costs 8 instead of 22 statistics per ray.  0: all 22 (default)     */
-  int32_t reserved;
+  int32_t sums;          /* 1: NO read-out -- the tail forms pass (1) of art_analyse_bundles for the last bundle instead, while the
+                            ray is still in registers: out24[0..8] = count, sum point (3), sum vector (3), sum w (= count if w is
+                            NULL), sum path; out24[9..23] = 0.  `det`, cx, cy, co are ignored, X / Y / opl must be NULL and lite 0.
+                            For a detector that is NOT known before the trace (Detector.autoplace needs exactly these sums,
+                            ART/ModuleDetector.py:109-137): hand out24 to ArtAnalysisJob.sums and the analysis of the bundle is
+                            placement + ONE pass.  Same bits as the sums art_analyse_bundles forms itself (one canonical fold
+                            order: tiles of 256 slots).  0 (default): a read-out                    */
 } ArtChainReadout;
 int64_t art_chain_readout_scratch_doubles(int64_t n);
 int art_trace_chain_readout(const ArtElementDesc* elems, int32_t n_elems, const ArtBundleView* in,
@@ -348,6 +354,14 @@ int art_exchange_fold(const double* recv, int32_t world, int64_t stride_doubles,
  * art_survivor_bytes(count, dense) bytes; the header tells the receiver how to read them.  scratch_ints: DEVICE,
  * art_compact_scratch_ints(n) int32.  Everything is enqueued on `stream`; nothing returns to the host.                  */
 int64_t art_survivor_bytes(int64_t count, int32_t dense);
+/* ZERO-COPY form for a shard that is expected to lose nothing: let the read-out write its X, Y, opl of all n slots
+ * straight into the dense layout's sections (X = send + 16, Y = X + n, path = Y + n: art_trace_chain_readout / the scene
+ * read-outs / art_detector_readout take any pointers), then call art_survivor_finish with the read-out's statistics
+ * (stats24[0] = number of alive slots, DEVICE): it writes the header -- (n, dense) if every slot is alive, and the buffer is
+ * complete without a pack or a staging copy; otherwise (count, flags bit 1 "unpacked"): the sections hold slot-indexed
+ * values with holes and the caller packs them into ANOTHER buffer with art_pack_survivors (X, Y, opl may point into this
+ * one).  `send`: DEVICE, 16-byte aligned, >= art_survivor_bytes(n, 1) bytes.                                            */
+int art_survivor_finish(const double* stats24, int64_t n, void* send, void* stream);
 int art_pack_survivors(const uint8_t* alive, int64_t n, const double* X, const double* Y, const double* opl,
                        const int64_t* number, int64_t first, int64_t step, int32_t* scratch_ints, void* send,
                        int64_t send_bytes, void* stream);
@@ -389,8 +403,10 @@ int art_trace_guides(const ArtElementDesc* elems, int32_t count, double* rays, u
  *   [55] largest angle to the mean vector (rad)
  *   [56] min X [57] max X [58] min Y [59] max Y [60] min opl [61] max opl   (s = 0; +inf / -inf if nothing is alive)
  *   [62..63] 0
- * A job without alive rays gets count 0, NaN detector fields and zero moments.  scratch: DEVICE,
- * art_analysis_scratch_doubles(n_jobs) doubles.  Deterministic (fixed grids, fixed fold order, no float atomics); the
+ * A job without alive rays gets count 0, NaN detector fields and zero moments.  A manual detector's normal must be a unit
+ * vector (| |normal|^2 - 1 | <= 1e-12, ART_ERR_BAD_ARG otherwise); a manual detector parallel to the mean ray (mean vector .
+ * normal = 0) makes the provisional path centre infinite and every path moment NaN -- as the reference's read-out of such a
+ * detector is.  scratch: DEVICE, art_analysis_scratch_doubles(n_jobs, n) doubles.  Deterministic (fixed grids, fixed fold order, no float atomics); the
  * launches are enqueued on `stream`, nothing returns to the host.                                                        */
 #define ART_ANALYSIS_DOUBLES 64
 enum ArtJobMode { ART_JOB_AUTOPLACE = 0, ART_JOB_MANUAL = 1, ART_JOB_SUMS = 2 };
@@ -403,8 +419,11 @@ typedef struct ArtAnalysisJob {
   double centre[3];       /* ART_JOB_MANUAL: the detector (unit normal, used bit for bit)              */
   double normal[3];
   double refpoint[3];
+  const double* sums;     /* DEVICE, 9 doubles, or NULL: the sums of step 1 if something formed them already (the tail of
+                             the tracing launch, ArtChainReadout.sums -> its out24).  Jobs that bring them skip step 1; if all
+                             do, the bundles are read ONCE (step 3).                                   */
 } ArtAnalysisJob;
-int64_t art_analysis_scratch_doubles(int32_t n_jobs);
+int64_t art_analysis_scratch_doubles(int32_t n_jobs, int64_t n);
 int art_analyse_bundles(const ArtAnalysisJob* jobs_dev, const ArtAnalysisJob* jobs_host, int32_t n_jobs, int64_t n,
                         double* scratch, double* out, void* stream);
 

@@ -113,7 +113,7 @@ int art_cpu_trace_scene(const void* image, const void* image_host, int64_t n) {
           }
         }
       }
-      if (a.flags & art::kFlagReadout) readout_tail(a.ro, a.out[a.n_elems - 1], n);
+      if ((a.flags & art::kFlagReadout) && !a.ro.sums) readout_tail(a.ro, a.out[a.n_elems - 1], n);
     }
   }
   return 0;

@@ -1,0 +1,242 @@
+"""GPU (-m gpu), round 5: the sums tail of the tracing launches (ArtChainReadout.sums) against art_analyse_bundles' own
+pass (1) -- bit for bit, every kernel body --, the zero-copy header of a survivor send buffer, the wide-load compaction on
+awkward masks, and the host wrapper under two concurrent streams."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    import __graft_entry__
+    from attosecondraytracing_amd import _lib
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    __graft_entry__.ensure_built()
+    _lib._BACKEND = None
+    be = _lib.get_backend()
+    assert be.name == "hip"
+    return be
+
+
+def _scenes():
+    import bench
+    yield "relay4 (one ray per lane)", bench.build_scene(4)[0].optical_elements, ("point", 0.02), True
+    els, kind, _ = bench.scene_c3()
+    yield "C3 chain 3 (mask: two rays per lane)", els[3], kind, True
+    els, kind, _ = bench.scene_c5()
+    yield "C5 (defects)", els[0], kind, False
+    els, kind, _ = bench.scene_c4()
+    yield "C4 (8 elements)", els[0], kind, True
+
+
+def _bits(t):
+    import torch
+    return t.contiguous().view(torch.int64)
+
+
+@pytest.mark.parametrize("n", [100, 257, 100003, 1 << 20])
+def test_gpu_sums_tail_is_the_analysis_pass_bit_for_bit(hip, n):
+    """Whoever forms the nine sums -- the tail of the tracing launch (either body, with or without defects) or
+    art_analyse_bundles re-reading the bundle -- they are the same bits, and so is everything derived from them."""
+    import torch
+    import bench
+    import ART.ModuleProcessing as mp
+    from attosecondraytracing_amd import analysis, _abi
+    for label, els, kind, ign in _scenes():
+        src = bench.device_source(n, 0, n, hip, kind, 800e-6 if "C5" in label else 50e-6)
+        src.intensity = torch.rand(n, dtype=torch.float64, device=hip.device) + 0.25
+        last = mp.RayTracingCalculation(src, els, IgnoreDefects=ign, history=False, sums=True)[-1]
+        fs = last.fused_sums()
+        assert fs is not None, label
+        with_tail = analysis.analyse([(last, "autoplace", 100.0)])[0].row.copy()
+        last._fused_sums = None                       # the same bundle, analysed from scratch
+        own = analysis.analyse([(last, "autoplace", 100.0)])[0].row.copy()
+        assert np.array_equal(fs[:9].cpu().numpy().view(np.int64), own[:9].view(np.int64)), (label, n, fs[:9].cpu().numpy() - own[:9])
+        assert np.array_equal(with_tail.view(np.int64), own.view(np.int64)), (label, n)
+        # ... and they are the sums: against NumPy
+        a = last.alive.bool().cpu().numpy()
+        d = last.data.cpu().numpy()
+        ref = np.concatenate([[a.sum()], d[0:6][:, a].sum(axis=1), [src.intensity.cpu().numpy()[a].sum()], [d[6][a].sum()]])
+        assert np.allclose(own[:9], ref, rtol=1e-12, atol=1e-9), (label, own[:9] - ref)
+        # no weights: sum w = count
+        src.intensity = None
+        last = mp.RayTracingCalculation(src, els, IgnoreDefects=ign, history=False, sums=True)[-1]
+        s9 = last.fused_sums()[:9].cpu().numpy()
+        assert s9[7] == s9[0] == a.sum(), label
+
+
+def test_gpu_sums_tail_of_a_scene_launch(hip):
+    """The many-chain launch (loop list, shared prefix) with sums: every chain's tail == the analysis' own pass."""
+    import torch
+    import bench
+    import ART.ModuleProcessing as mp
+    from attosecondraytracing_amd import analysis
+    element_lists, kind, _ = bench.scene_c3()
+    n = 200_001
+    src = bench.device_source(n, 0, n, hip, kind)
+    src.intensity = torch.rand(n, dtype=torch.float64, device=hip.device) + 0.25
+    for srcs in ([src] * len(element_lists), [src.copy() for _ in element_lists]):     # shared prefix / plain scene launch
+        outs = mp.RayTracingCalculationMany(srcs, element_lists, history=False, sums=True)
+        lasts = [o[-1] for o in outs]
+        assert all(b.fused_sums() is not None for b in lasts)
+        tail = [r.row.copy() for r in analysis.analyse([(b, "autoplace", 600.0) for b in lasts])]
+        for b in lasts:
+            b._fused_sums = None
+        own = [r.row.copy() for r in analysis.analyse([(b, "autoplace", 600.0) for b in lasts])]
+        for t, o in zip(tail, own):
+            assert np.array_equal(t.view(np.int64), o.view(np.int64))
+        # one chain alone == the same chain in the list
+        alone = analysis.analyse([(lasts[4], "autoplace", 600.0)])[0].row
+        assert np.array_equal(alone.view(np.int64), own[4].view(np.int64))
+
+
+def test_gpu_sums_go_stale_with_the_bundle(hip):
+    import torch
+    import bench
+    import ART.ModuleProcessing as mp
+    els = bench.build_scene(2)[0].optical_elements
+    n = 5000
+    src = bench.device_source(n, 0, n, hip, ("point", 0.02))
+    last = mp.RayTracingCalculation(src, els, history=False, sums=True)[-1]
+    assert last.fused_sums() is not None
+    src.intensity.mul_(2.0)                    # the weights changed in place: the sum of weights is stale
+    assert last.fused_sums() is None
+    last = mp.RayTracingCalculation(src, els, history=False, sums=True)[-1]
+    last.alive[:10] = 0
+    last.touch()
+    assert last.fused_sums() is None
+
+
+def test_gpu_survivor_finish_zero_copy(hip):
+    """The read-out writes straight into a send buffer's dense sections; art_survivor_finish makes it a complete dense
+    buffer when nothing was lost and says `unpacked` otherwise (then art_pack_survivors packs from those sections)."""
+    import torch
+    import bench
+    import ART.ModuleProcessing as mp
+    import ART.ModuleDetector as mdet
+    from attosecondraytracing_amd import sharding
+    els = bench.build_scene(2)[0].optical_elements
+    n = 30_001
+    src = bench.device_source(n, 0, n, hip, ("point", 0.02))
+    last = mp.RayTracingCalculation(src, els)[-1]
+    det = mdet.Detector(np.asarray(els[-1].position, float))
+    det.autoplace(last, 600.0)
+    ref = det.readout(last, sync=False)
+    send = torch.zeros(hip.survivor_bytes(n, False), dtype=torch.uint8, device=hip.device)
+    sec = send[16:16 + 24 * n].view(torch.float64).view(3, n)
+    ro = hip.new_chain_readout(det._desc(), src.intensity, n, targets=(sec[0], sec[1], sec[2]))
+    descs = [mp.element_descriptor(oe, True, hip)[0] for oe in els]
+    from attosecondraytracing_amd.bundle import RayBundle
+    hist = RayBundle.allocate_many(n, len(els), src, hip)
+    hip.trace_chain(descs, src.view(), [b.view() for b in hist], n, readout=ro)
+    hip.survivor_finish(ro["stats_dev"], n, send)
+    hdr = send[:16].view(torch.int64).tolist()
+    assert hdr == [n, 1]
+    num, X, Y, P = sharding.decode_survivors(send, hdr[0], hdr[1], (7, 3, n))
+    assert torch.equal(_bits(X), _bits(ref["X"])) and torch.equal(_bits(Y), _bits(ref["Y"])) and torch.equal(_bits(P), _bits(ref["opl"]))
+    assert torch.equal(num, 7 + 3 * torch.arange(n, device=hip.device))
+    # a shard that lost rays: header says unpacked; the pack from the sections gives the survivors' records
+    hist[-1].alive[5:50] = 0
+    stats = ro["stats_dev"].clone()
+    stats[0] = n - 45
+    hip.survivor_finish(stats, n, send)
+    assert send[:16].view(torch.int64).tolist() == [n - 45, 2]
+    packed = torch.zeros_like(send)
+    hip.pack_survivors(hist[-1].alive, sec[0], sec[1], sec[2], None, 7, 3, packed)
+    c, f = packed[:16].view(torch.int64).tolist()
+    assert (c, f) == (n - 45, 0)
+    num, X, Y, P = sharding.decode_survivors(packed, c, f, (7, 3, n))
+    keep = hist[-1].alive.bool()
+    assert torch.equal(_bits(X), _bits(ref["X"][keep])) and torch.equal(_bits(P), _bits(ref["opl"][keep]))
+    assert torch.equal(num, (7 + 3 * torch.arange(n, device=hip.device))[keep])
+
+
+@pytest.mark.parametrize("n", [1, 63, 2048, 2049, 50_000, 1_000_003])
+def test_gpu_compaction_on_awkward_masks(hip, n):
+    """Wide-load count, one-barrier scatter: against torch.nonzero for dense, empty, sparse, random masks, odd lengths and a
+    mask that does not start on an 8-byte boundary."""
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(n)
+    base = torch.zeros(n + 16, dtype=torch.uint8, device=hip.device)
+    for off in (0, 3):
+        alive = base[off:off + n]
+        for kind in ("dense", "empty", "random", "sparse", "byte values"):
+            if kind == "dense":
+                alive.fill_(1)
+            elif kind == "empty":
+                alive.zero_()
+            elif kind == "random":
+                alive.copy_((torch.rand(n, generator=g) < 0.5).to(torch.uint8))
+            elif kind == "sparse":
+                alive.copy_((torch.rand(n, generator=g) < 0.001).to(torch.uint8))
+            else:
+                alive.copy_(torch.randint(0, 256, (n,), generator=g).to(torch.uint8) * (torch.rand(n, generator=g) < 0.7).to(torch.uint8))
+            idx, c = hip.compact(alive, n)
+            ref = torch.nonzero(alive, as_tuple=False).reshape(-1)
+            assert c == ref.numel() and torch.equal(idx, ref), (n, off, kind)
+
+
+def test_gpu_two_streams_share_the_wrapper(hip):
+    """Read-outs and compactions issued concurrently on two torch streams give the serial results bit for bit: the
+    wrapper's reused scratch areas are per stream."""
+    import torch
+    import bench
+    import ART.ModuleProcessing as mp
+    import ART.ModuleDetector as mdet
+    n = 2_000_000
+    els = bench.scene_c3()[0]
+    src = bench.device_source(n, 0, n, hip, ("point", 0.025))
+    lasts = [mp.RayTracingCalculation(src, e)[-1] for e in (els[0], els[7])]
+    dets = []
+    for b, e in zip(lasts, (els[0], els[7])):
+        d = mdet.Detector(np.asarray(e[-1].position, float))
+        d.autoplace(b, 600.0)
+        dets.append(d)
+
+    def work(b, d):
+        XY = (hip.empty(n), hip.empty(n))
+        O = hip.empty(n)
+        st = hip.detector_readout(d._desc(), b.view(), src.intensity, n, XY=XY, opl=O, to_host=False)
+        idx, c = hip.compact(b.alive, n)
+        s9 = hip.bundle_sums(b.view(), src.intensity, n)
+        return st, XY[0], O, idx, s9
+
+    serial = [work(b, d) for b, d in zip(lasts, dets)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for rep in range(6):
+        got = [None, None]
+        for s in streams:
+            s.wait_stream(torch.cuda.current_stream())
+        # interleave the issue order: stream 0, stream 1, stream 0, ... -- the launches of the two streams overlap on the device
+        for k in (0, 1):
+            with torch.cuda.stream(streams[k]):
+                got[k] = work(lasts[k], dets[k])
+        for s in streams:
+            s.synchronize()
+        for k in (0, 1):
+            st, X, O, idx, s9 = got[k]
+            rs, rX, rO, ridx, rs9 = serial[k]
+            assert torch.equal(_bits(st), _bits(rs)), (rep, k)
+            live = lasts[k].alive.bool()
+            assert torch.equal(_bits(X[live]), _bits(rX[live])) and torch.equal(_bits(O[live]), _bits(rO[live]))
+            assert torch.equal(idx, ridx)
+            assert np.array_equal(s9.view(np.int64), rs9.view(np.int64))
+
+
+def test_gpu_analysis_refuses_a_non_unit_manual_normal(hip):
+    import bench
+    import ART.ModuleProcessing as mp
+    from attosecondraytracing_amd import _abi, analysis
+    from attosecondraytracing_amd._lib import ArtError
+    els = bench.build_scene(2)[0].optical_elements
+    n = 1000
+    src = bench.device_source(n, 0, n, hip, ("point", 0.02))
+    last = mp.RayTracingCalculation(src, els)[-1]
+    j = analysis._job(last, _abi.ART_JOB_SUMS, None)
+    j.mode = _abi.ART_JOB_MANUAL
+    j.normal[:] = [0.0, 0.0, 2.0]
+    with pytest.raises(ArtError, match="unit vector"):
+        hip.analyse_bundles([j], n)

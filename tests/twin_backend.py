@@ -68,8 +68,11 @@ class TwinBackend:
 
     MAX_FUSED_READOUT_RAYS = 1 << 28
 
-    def new_chain_readout(self, ddesc, w, n, centres=(0.0, 0.0, 0.0), store=True, scratch=None, lite=False):
+    def new_chain_readout(self, ddesc, w, n, centres=(0.0, 0.0, 0.0), store=True, scratch=None, lite=False, targets=None):
         X, Y, opl = (torch.empty(n, dtype=torch.float64) for _ in range(3))     # the twin always computes them
+        if targets is not None:
+            X, Y, opl = targets
+            store = True
         out = torch.empty(24, dtype=torch.float64)
         ro = _abi.ArtChainReadout()
         ro.det = ddesc
@@ -81,11 +84,35 @@ class TwinBackend:
         return {"struct": ro, "X": X if store else None, "Y": Y if store else None, "opl": opl if store else None,
                 "P3": None, "stats_dev": out, "_keep": (w, X, Y, opl), "_w": w, "_centres": centres, "lite": bool(lite)}
 
+    def new_chain_sums(self, w, n, scratch=None):
+        """ArtChainReadout.sums: the twin's trace leaves the sums to _finish_readout (NumPy, like its other reductions)."""
+        out = torch.zeros(24, dtype=torch.float64)
+        ro = _abi.ArtChainReadout()
+        ro.w = None if w is None else w.data_ptr()
+        ro.scratch, ro.out24 = out.data_ptr(), out.data_ptr()
+        ro.lite, ro.sums = 0, 1
+        return {"struct": ro, "sums_dev": out, "_keep": (w,), "_w": w, "sums": True}
+
     def chain_readout_scratch(self, n, count):
         return [None] * count
 
+    def _finish_sums(self, ro, last_view, n):
+        def arr(ptr, ty=C.c_double):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ty)), shape=(max(n, 1),))[:n]
+        a = arr(last_view.alive, C.c_uint8).astype(bool) if n else np.zeros(0, bool)
+        out = np.zeros(24)
+        out[0] = a.sum()
+        for k, f_ in enumerate(("ox", "oy", "oz", "dx", "dy", "dz")):
+            out[1 + k] = arr(getattr(last_view, f_))[a].sum() if n else 0.0
+        w = ro["_w"]
+        out[7] = w.numpy()[a].sum() if w is not None else a.sum()
+        out[8] = arr(last_view.path)[a].sum() if n else 0.0
+        ro["sums_dev"].copy_(torch.from_numpy(out))
+
     def _finish_readout(self, ro, last_view, n):
         """Statistics of a fused read-out (the twin's C side only fills X, Y, opl): same reduction as detector_readout."""
+        if ro.get("sums"):
+            return self._finish_sums(ro, last_view, n)
         X, Y, O = ro["_keep"][1:4]
         alive = torch.from_numpy(np.ctypeslib.as_array(C.cast(last_view.alive, C.POINTER(C.c_uint8)), shape=(max(n, 1),))[:n].copy())
         w, c = ro["_w"], ro["_centres"]
@@ -103,7 +130,9 @@ class TwinBackend:
 
     def trace_chain(self, descs, vin, vouts, n, readout=None):
         self._trace_chain(descs, vin, vouts, n)
-        if readout is not None:
+        if readout is not None and readout.get("sums"):
+            self._finish_sums(readout, vouts[len(descs) - 1], n)
+        elif readout is not None:
             f = self.lib.art_cpu_chain_readout_tail
             f.restype, f.argtypes = C.c_int, [C.POINTER(_abi.ArtChainReadout), C.POINTER(_abi.ArtBundleView), C.c_int64]
             assert f(C.byref(readout["struct"]), C.byref(vouts[len(descs) - 1]), n) == 0
@@ -184,11 +213,14 @@ class TwinBackend:
             v = jb.b
             a = arr(v.alive, C.c_uint8).astype(bool) if n else np.zeros(0, bool)
             w = arr(jb.w)[a] if (jb.w and n) else np.ones(int(a.sum()))
-            o[0] = a.sum()
-            for k, f_ in enumerate(("ox", "oy", "oz", "dx", "dy", "dz")):
-                o[1 + k] = arr(getattr(v, f_))[a].sum() if n else 0.0
-            o[7] = w.sum()
-            o[8] = arr(v.path)[a].sum() if n else 0.0
+            if jb.sums:       # pass (1) came with the job (ArtAnalysisJob.sums): used as given
+                o[:9] = np.ctypeslib.as_array(C.cast(jb.sums, C.POINTER(C.c_double)), shape=(9,))
+            else:
+                o[0] = a.sum()
+                for k, f_ in enumerate(("ox", "oy", "oz", "dx", "dy", "dz")):
+                    o[1 + k] = arr(getattr(v, f_))[a].sum() if n else 0.0
+                o[7] = w.sum()
+                o[8] = arr(v.path)[a].sum() if n else 0.0
             if jb.mode == _abi.ART_JOB_SUMS:
                 continue
             if o[0] == 0:
@@ -389,6 +421,11 @@ class TwinBackend:
         if not dense:
             num = number.numpy()[a] if number is not None else first + np.nonzero(a)[0] * step
             buf[16 + 24 * c:16 + 28 * c].view(np.int32)[:] = num.astype(np.int32)
+
+    def survivor_finish(self, stats_dev, n, send):
+        """art_survivor_finish: the header of a zero-copy send buffer."""
+        c = int(stats_dev[0].item())
+        send.numpy()[:16].view(np.int64)[:] = [c, 1 if c == n else 2]
 
     def make_extended_source(self, radius, divergence, n_points, per, rot, S, first, n, view):
         r = (C.c_double * 9)(*[float(v) for v in np.asarray(rot).reshape(9)])
