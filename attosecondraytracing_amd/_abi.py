@@ -83,6 +83,7 @@ class ArtChainReadout(C.Structure):
 
 
 ART_GUIDES_MAX = 8
+ART_XHDR_DOUBLES = 26
 ART_ANALYSIS_DOUBLES = 64
 ART_JOB_AUTOPLACE, ART_JOB_MANUAL, ART_JOB_SUMS = range(3)
 
@@ -149,7 +150,8 @@ PROTOTYPES = {
     "art_survivor_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
     "art_pack_survivors": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 4 + [C.c_int64, C.c_int64, C.c_void_p,
                                                                                     C.c_void_p, C.c_int64, C.c_void_p]),
-    "art_survivor_finish": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "art_survivor_finish": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "art_survivor_xheader": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "art_trace_guides": (C.c_int, [C.POINTER(ArtElementDesc), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "art_analysis_scratch_doubles": (C.c_int64, [C.c_int32, C.c_int64]),
     "art_analyse_bundles": (C.c_int, [C.c_void_p, C.POINTER(ArtAnalysisJob), C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,

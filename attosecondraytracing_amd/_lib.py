@@ -373,11 +373,17 @@ class HipBackend:
                                                  int(step), sc.data_ptr(), send.data_ptr(), int(send.numel()),
                                                  self.stream_ptr()), "art_pack_survivors")
 
-    def survivor_finish(self, stats_dev, n, send):
+    def survivor_finish(self, stats_dev, n, send, xhdr=None):
         """Header of a ZERO-COPY send buffer whose sections the read-out wrote directly (art_survivor_finish): (n, dense) if
-        every slot is alive, else (count, unpacked)."""
-        self.check(self.fn["art_survivor_finish"](stats_dev.data_ptr(), int(n), send.data_ptr(), self.stream_ptr()),
+        every slot is alive, else (count, unpacked); `xhdr` (26 doubles): the rank's block of the header exchange."""
+        self.check(self.fn["art_survivor_finish"](stats_dev.data_ptr(), int(n), send.data_ptr(),
+                                                  None if xhdr is None else xhdr.data_ptr(), self.stream_ptr()),
                    "art_survivor_finish")
+
+    def survivor_xheader(self, send, stats_dev, xhdr):
+        """The rank's block of the header exchange behind art_pack_survivors (art_survivor_xheader)."""
+        self.check(self.fn["art_survivor_xheader"](send.data_ptr(), None if stats_dev is None else stats_dev.data_ptr(),
+                                                   xhdr.data_ptr(), self.stream_ptr()), "art_survivor_xheader")
 
     def trace_guides(self, descs, rays, alive):
         """Advance guide ray j (row j of the DEVICE tensor rays[count, 8], in place) through descs[j]; alive[count] uint8

@@ -236,6 +236,11 @@ __device__ __forceinline__ T ld_nt(const T* p) {
   typedef const T __attribute__((address_space(1)))* gptr_t;
   return __builtin_nontemporal_load((gptr_t)p);
 }
+template <typename T>
+__device__ __forceinline__ void st_nt(T* p, const T v) {
+  typedef T __attribute__((address_space(1)))* gptr_t;
+  __builtin_nontemporal_store(v, (gptr_t)p);
+}
 constexpr int kRedUnroll = 4;
 
 // ------------------------------------------------------------------------------------------- reductions
@@ -1357,7 +1362,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_moments_partial(const ArtDetect
 #pragma unroll
   for (int k = 0; k < kScanSlots; ++k) acc[k] = 0.0;
   const int64_t stride = (int64_t)gridDim.x * kBlock;
-  constexpr int kU = 2;
+  constexpr int kU = 1;     // (two slots per iteration need 148 VGPRs = 3 waves per SIMD: 0.65 of peak; one: 4 waves)
   for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < n; i0 += kU * stride) {
     SlotBatch<kU> q;
     load_batch<kU, HAS_W>(b, w, i0, stride, n, q);
@@ -1875,7 +1880,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_scatter(const uint8_t* alive
   tile_ranks(alive, n, base, s_cnt, q);
 #pragma unroll
   for (int j = 0; j < kTile / kBlock; ++j)
-    if (q.a[j]) idx_out[run + q.pos[j]] = base + j * kBlock + threadIdx.x;
+    if (q.a[j]) st_nt(idx_out + run + q.pos[j], (int64_t)(base + j * kBlock + threadIdx.x));     // (written once, read by another kernel)
 }
 
 // ------------------------------------------------------------------------------------------- survivor records
@@ -1910,24 +1915,28 @@ __global__ __launch_bounds__(kBlock) void k_survivor_scatter(const uint8_t* aliv
   const int64_t run = tile_offsets[blockIdx.x];
   TileRanks q;
   tile_ranks(alive, n, base, s_cnt, q);
-  // the records of all eight passes are requested before the first is stored
-  constexpr int P = kTile / kBlock;
-  double xv[P], yv[P], ov[P];
-  int64_t nv[P];
+  // four passes at a time: their records are requested together (12-16 loads in flight per lane) and then stored,
+  // non-temporally (each record is written once and read by the transfer, not by this kernel's neighbours)
+  constexpr int P = kTile / kBlock, H = 4;
 #pragma unroll
-  for (int j = 0; j < P; ++j) {
-    const int64_t i = base + j * kBlock + threadIdx.x;
-    if (q.a[j]) {
-      xv[j] = ld_nt(X + i); yv[j] = ld_nt(Y + i); ov[j] = ld_nt(opl + i);
-      nv[j] = (number && !dense) ? ld_nt(number + i) : first + i * step;
+  for (int j0 = 0; j0 < P; j0 += H) {
+    double xv[H], yv[H], ov[H];
+    int64_t nv[H];
+#pragma unroll
+    for (int u = 0; u < H; ++u) {
+      const int64_t i = base + (j0 + u) * kBlock + threadIdx.x;
+      if (q.a[j0 + u]) {
+        xv[u] = ld_nt(X + i); yv[u] = ld_nt(Y + i); ov[u] = ld_nt(opl + i);
+        nv[u] = (number && !dense) ? ld_nt(number + i) : first + i * step;
+      }
     }
-  }
 #pragma unroll
-  for (int j = 0; j < P; ++j) {
-    if (q.a[j]) {
-      const int64_t p = run + q.pos[j];
-      sx[p] = xv[j]; sy[p] = yv[j]; so[p] = ov[j];
-      if (!dense) sn[p] = (int32_t)nv[j];
+    for (int u = 0; u < H; ++u) {
+      if (q.a[j0 + u]) {
+        const int64_t p = run + q.pos[j0 + u];
+        st_nt(sx + p, xv[u]); st_nt(sy + p, yv[u]); st_nt(so + p, ov[u]);
+        if (!dense) st_nt(sn + p, (int32_t)nv[u]);
+      }
     }
   }
 }
@@ -1936,12 +1945,22 @@ __global__ __launch_bounds__(kBlock) void k_survivor_scatter(const uint8_t* aliv
 // dense layout's sections; if every slot is alive the buffer is complete once its header says so.  Otherwise the header
 // says "unpacked" (flags bit 1): the sections hold slot-indexed values with holes, and the caller packs them elsewhere.
 constexpr int64_t kSurvUnpacked = 2;
-__global__ void k_survivor_finish(const double* stats24, const int64_t n, int64_t* header) {
-  if (threadIdx.x == 0) {
-    const int64_t count = (int64_t)stats24[0];
-    header[0] = count;
-    header[1] = (count == n) ? kSurvDense : kSurvUnpacked;
-  }
+// xhdr (optional): the rank's contribution to the per-step header exchange of a sharded run -- [0], [1] = count, flags as
+// int64 bit patterns, [2 .. 25] = the shard's 24 read-out statistics (zeros if none are given)
+constexpr int kXhdrDoubles = 26;
+__device__ __forceinline__ void xheader_store(const int64_t count, const int64_t flags, const double* stats24, double* xhdr) {
+  const int t = threadIdx.x;
+  if (t == 0) { reinterpret_cast<int64_t*>(xhdr)[0] = count; reinterpret_cast<int64_t*>(xhdr)[1] = flags; }
+  if (t < kReadoutSlots) xhdr[2 + t] = stats24 ? stats24[t] : 0.0;
+}
+__global__ void k_survivor_finish(const double* stats24, const int64_t n, int64_t* header, double* xhdr) {
+  const int64_t count = (int64_t)stats24[0];
+  const int64_t flags = (count == n) ? kSurvDense : kSurvUnpacked;
+  if (threadIdx.x == 0) { header[0] = count; header[1] = flags; }
+  if (xhdr) xheader_store(count, flags, stats24, xhdr);
+}
+__global__ void k_survivor_xheader(const int64_t* header, const double* stats24, double* xhdr) {
+  xheader_store(header[0], header[1], stats24, xhdr);
 }
 
 // ------------------------------------------------------------------------------------------- sources
@@ -2769,13 +2788,22 @@ int art_analyse_bundles(const ArtAnalysisJob* jobs_dev, const ArtAnalysisJob* jo
   return ART_OK;
 }
 
-int art_survivor_finish(const double* stats24, int64_t n, void* send, void* stream) {
+int art_survivor_finish(const double* stats24, int64_t n, void* send, double* xhdr, void* stream) {
   if (!stats24 || !send) return fail(ART_ERR_BAD_ARG, "NULL argument");
   if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
   if (((uintptr_t)send & 15u) != 0) return fail(ART_ERR_BAD_ARG, "send buffer must be 16-byte aligned");
-  hipLaunchKernelGGL(k_survivor_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, stats24, n, reinterpret_cast<int64_t*>(send));
+  hipLaunchKernelGGL(k_survivor_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, stats24, n, reinterpret_cast<int64_t*>(send), xhdr);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_survivor_finish launch");
+  return ART_OK;
+}
+
+int art_survivor_xheader(const void* send, const double* stats24, double* xhdr, void* stream) {
+  if (!send || !xhdr) return fail(ART_ERR_BAD_ARG, "NULL argument");
+  if (((uintptr_t)send & 7u) != 0) return fail(ART_ERR_BAD_ARG, "send buffer must be 8-byte aligned");
+  hipLaunchKernelGGL(k_survivor_xheader, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<const int64_t*>(send), stats24, xhdr);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail_hip(err, "art_survivor_xheader launch");
   return ART_OK;
 }
 

@@ -265,31 +265,43 @@ def decode_survivors(buf, count, flags, spec):
     return num, f64[0], f64[1], f64[2]
 
 
+XHDR = 26   # doubles a rank contributes to the per-step header exchange: count, flags (int64 bit patterns), 24 statistics
+
+
 class SurvivorGather:
     """The gather of SURVEY.md 8(e) as written: `(number:int32, X, Y, path)` = 28 B per SURVIVING ray from every shard to
-    rank `dst` in ONE payload collective (the consumer, ART/ModuleDetector.py:254-279, sees survivors only; ReadoutGather
-    above ships all slots, dead or alive).  Per step and rank:
-      1. `art_pack_survivors` compacts the read-out of the alive slots into the rank's send buffer (header: count, flags;
-         a shard whose every slot is alive and whose numbers are the implicit first + slot * step drops the number section:
-         24 B/ray);
-      2. the 16-byte headers are all-gathered on the device and copied to pinned host memory behind an event -- NOBODY
-         WAITS for them in this step;
-      3. ONE `gather` of `nbytes` bytes per rank, asynchronous on the communicator's stream.  A collective's size must be
-         known on the host when it is issued: it is PREDICTED from the newest headers the host already holds (those of
-         step i - 2 with two buffer sets: settled when their buffer set is taken again), with a margin (the larger of
-         `margin` = 1/16 of the count and `slack` = 1024 records, explicit numbers assumed; a shard that was dense is predicted dense).  The
-         count travels inside the payload's own header, so the root decodes exactly what was packed.  When the headers of
-         a step land and show that some shard packed MORE than was shipped (overflow), that one step's gather is issued
-         again with the exact size -- before its send buffer is packed again, on every rank alike (all ranks read the
-         same all-gathered headers at the same point of the program).  Only the first step of a gather (nothing to
-         predict from) reads its own headers synchronously.
-    So a steady-state step costs two collectives -- a 16-byte all-gather nobody waits for and the payload gather -- and no
-    host synchronisation; `host_syncs` counts the exceptions (first step, overflows).
-    `buffers` independent sets let the gather of step i overlap the tracing of step i + 1 (start / drain / result as in
-    ReadoutGather).  `result(b)` -> per-rank list of (number int64, X, Y, path) views on dst; `assemble(b)` -> the four
-    arrays of the whole job in global ray order."""
+    rank `dst` (the consumer, ART/ModuleDetector.py:254-279, sees survivors only; ReadoutGather above ships all slots, dead
+    or alive).  Per step and rank, on set b of `buffers` independent buffer sets:
 
-    def __init__(self, backend, n, world, rank, dst=0, buffers=2, specs=None, margin=1.0 / 16, slack=1024, predict=True):
+      1. the send buffer.  ZERO-COPY (a shard that loses nothing -- `zero_copy=True`, the caller's knowledge of its scene):
+         `acquire(b)` hands out X, Y, path views of the buffer's dense sections, the step's read-out writes straight into
+         them (Detector read-out targets: art_trace_chain_readout / scene read-outs take any pointers) and
+         `art_survivor_finish` adds the 16-byte header -- no pack, no staging copy, 24 B/ray.  Otherwise `art_pack_survivors`
+         compacts the read-out of the alive slots into it (28 B per survivor; 24 where every slot is alive and the numbers
+         are the implicit first + slot * step);
+      2. ONE small all-gather: every rank's header (count, flags) + its 24 read-out statistics (208 B) -- the global
+         statistics of the step (`stats(b)`: the delays are relative to the GLOBAL mean path, ART/ModuleDetector.py:277)
+         ride along, and a copy of the headers goes to pinned host memory behind an event NOBODY WAITS FOR in this step;
+      3. the payload: every peer SENDS its records to `dst`, which posts one receive per peer -- grouped point-to-point
+         operations (on the xGMI mesh every peer has its own link into the root; the root's own shard is read where it
+         lies, it is not copied).  A transfer's size must be known on the host when it is issued: it is PREDICTED, per
+         rank, from the newest headers the host already holds (those of step i - 2 with two sets), with a margin (the
+         larger of `margin` = 1/16 of the count and `slack` = 1024 records; a shard that was dense is predicted dense: it
+         cannot grow).  The count travels in the payload's own header, so the root decodes exactly what was packed.
+
+    When the headers of a step land and show that some shard packed MORE than was shipped, or that a zero-copy shard did
+    lose rays (header flag `unpacked`), that step is SHORT.  Whoever wants its records calls `settle(b)` (every rank: it
+    re-issues that one step's transfers with the exact sizes, packing an unpacked shard first) before set b is acquired
+    again; a short step that nobody settled is dropped when its set is reused (`dropped`), its headers still teach the
+    next prediction.  Only the first step (nothing to predict from) reads its own headers synchronously.  So a
+    steady-state step costs the 208-byte all-gather and the payload transfers, and no host synchronisation;
+    `host_syncs` counts the exceptions (first step, settled short steps).
+
+    `start(b, ...)` enqueues a step, `settle(b)` / `drain()` complete it (them), `result(b)` -> per-rank list of (number
+    int64, X, Y, path) views on dst, `assemble(b)` -> the four arrays of the whole job in global ray order."""
+
+    def __init__(self, backend, n, world, rank, dst=0, buffers=2, specs=None, margin=1.0 / 16, slack=1024, predict=True,
+                 zero_copy=False):
         self.be, self.n, self.world, self.rank, self.dst = backend, int(n), int(world), int(rank), int(dst)
         # (first, step, n) of every rank's shard: for the implicit numbers of dense shards on the root
         self.specs = specs if specs is not None else [(0, 1, self.n)] * self.world
@@ -297,134 +309,203 @@ class SurvivorGather:
         if top > 2 ** 31 - 1:
             raise ValueError("ray numbers up to %d do not fit the int32 of a survivor record" % top)
         dev = backend.device
-        self.margin, self.slack, self.predict = float(margin), int(slack), bool(predict)
+        self.margin, self.slack, self.predict, self.zero_copy = float(margin), int(slack), bool(predict), bool(zero_copy)
         # capacity of every buffer: the longest shard with every slot alive and explicit numbers (28 B per ray)
         self.cap = backend.survivor_bytes(max([self.n] + [s[2] for s in self.specs]), False)
         self.send = [torch.empty(self.cap, dtype=torch.uint8, device=dev) for _ in range(buffers)]
-        self.recv = [[torch.empty(self.cap, dtype=torch.uint8, device=dev) for _ in range(self.world)]
+        self.alt = [None] * buffers           # where an unpacked zero-copy shard is packed when its step is settled
+        self._src = list(self.send)           # the buffer this rank's records of set b lie in
+        self.recv = [[None if r == self.rank else torch.empty(self.cap, dtype=torch.uint8, device=dev) for r in range(self.world)]
                      if self.rank == self.dst else None for _ in range(buffers)]
-        self.hdr = [torch.zeros((self.world, 2), dtype=torch.int64, device=dev) for _ in range(buffers)]
+        self.xh_mine = [torch.zeros(XHDR, dtype=torch.float64, device=dev) for _ in range(buffers)]
+        self.xh = [torch.zeros((self.world, XHDR), dtype=torch.float64, device=dev) for _ in range(buffers)]
         pin = torch.device(dev).type == "cuda"
-        self._hdr_host = [torch.zeros((self.world, 2), dtype=torch.int64, pin_memory=pin) for _ in range(buffers)]
+        self._xh_host = [torch.zeros((self.world, XHDR), dtype=torch.float64, pin_memory=pin) for _ in range(buffers)]
         self._side = torch.cuda.Stream(device=dev) if pin else None
         self._hdr_event = [None] * buffers    # the headers of set b are on the host once this event has completed
-        self._settled = [True] * buffers      # headers read and the shipped size checked against them
-        self.headers = [None] * buffers       # host copies: [[count, flags]] per rank (valid once set b is settled)
-        self.nbytes = [0] * buffers           # size of the collective issued on set b
-        self.work = [None] * buffers
-        self._known = None                    # newest settled headers: what the next size is predicted from
-        self.host_syncs = 0                   # steps that read their own headers synchronously + overflow repairs
-        self.overflows = 0
+        self._state = ["idle"] * buffers      # idle | inflight (started, headers unread) | ok | short
+        self._acquired = [False] * buffers
+        self._args = [None] * buffers         # (X, Y, opl, alive, number) of the step on set b: what a repair packs from
+        self._stats_out = [torch.zeros(24, dtype=torch.float64, device=dev) for _ in range(buffers)]
+        self.headers = [None] * buffers       # host copies: [[count, flags]] per rank (valid once set b has been checked)
+        self.sizes = [[0] * self.world for _ in range(buffers)]     # bytes shipped per rank on set b
+        self.nbytes = [0] * buffers           # ... by this rank
+        self.work = [[] for _ in range(buffers)]
+        self._known = None                    # newest checked headers: what the next sizes are predicted from
+        self.host_syncs = 0                   # steps that read their own headers synchronously + settled short steps
+        self.overflows = 0                    # steps whose shipped sizes did not cover what was packed
+        self.dropped = 0                      # ... of which nobody asked for the records before the set was reused
+
+    @staticmethod
+    def _dist():
+        return dist.is_available() and dist.is_initialized()
+
+    # ---- the zero-copy sections ----------------------------------------------------------------------------------------
+    def targets(self, b):
+        """X, Y, path views (n doubles each) of send buffer b's dense sections."""
+        sec = self.send[b][16:16 + 24 * self.n].view(torch.float64).view(3, self.n)
+        return sec[0], sec[1], sec[2]
 
     # ---- sizes ---------------------------------------------------------------------------------------------------------
-    def _exact_bytes(self, headers):
-        return max(self.be.survivor_bytes(c, bool(f & 1)) for c, f in headers)
+    def _exact(self, headers):
+        return [self.be.survivor_bytes(c, bool(f & 1)) if c > 0 else 0 for c, f in headers]
 
-    def _predicted_bytes(self, headers):
-        need = 0
+    def _predicted(self, headers):
+        out = []
         for (c, f), (_, _, slots) in zip(headers, self.specs):
             if f & 1:                                   # dense last time: predicted dense (a shard cannot grow)
-                b = self.be.survivor_bytes(c, True)
+                out.append(self.be.survivor_bytes(c, True))
             else:
-                b = self.be.survivor_bytes(min(int(slots), int(c + max(self.slack, self.margin * c))), False)
-            need = max(need, b)
-        return min(need, self.cap)
+                out.append(min(self.cap, self.be.survivor_bytes(min(int(slots), int(c + max(self.slack, self.margin * c))), False)))
+        return out
 
-    # ---- collectives ---------------------------------------------------------------------------------------------------
-    def _issue(self, b, nb):
-        self.nbytes[b] = nb
-        if dist.is_available() and dist.is_initialized():
-            recv = None if self.recv[b] is None else [t[:nb] for t in self.recv[b]]
-            self.work[b] = dist.gather(self.send[b][:nb], recv, dst=self.dst, async_op=True)     # ONE payload collective
-        elif self.recv[b] is not None:
-            self.recv[b][0][:nb].copy_(self.send[b][:nb])
+    # ---- transfers -----------------------------------------------------------------------------------------------------
+    def _issue(self, b, sizes):
+        """The payload of set b: every peer sends sizes[rank] bytes to dst, dst posts one receive per peer (one group)."""
+        self.sizes[b], self.nbytes[b] = list(sizes), int(sizes[self.rank])
+        self.work[b] = []
+        if not self._dist() or self.world == 1:
+            return                                       # the root's own shard is read where it lies
+        ops = []
+        if self.rank == self.dst:
+            ops = [dist.P2POp(dist.irecv, self.recv[b][r][:sizes[r]], r) for r in range(self.world) if r != self.dst and sizes[r] > 0]
+        elif sizes[self.rank] > 0:
+            ops = [dist.P2POp(dist.isend, self._src[b][:sizes[self.rank]], self.dst)]
+        if ops:
+            self.work[b] = dist.batch_isend_irecv(ops)
+
+    def _wait(self, b):
+        for w in self.work[b]:
+            w.wait()          # NCCL / RCCL: the caller's STREAM waits; gloo: the host does
+        self.work[b] = []
 
     def _read_headers(self, b):
         ev = self._hdr_event[b]
         if ev is not None:
             ev.synchronize()
-        self.headers[b] = self._hdr_host[b].tolist()
+        raw = self._xh_host[b][:, :2].contiguous().view(torch.int64)
+        self.headers[b] = raw.tolist()
 
-    def _settle(self, b):
-        """Headers of set b on the host, the shipped size checked: a step that packed more than was shipped is gathered
-        again with the exact size (its send buffer is still intact)."""
-        if self._settled[b]:
-            return
+    def _check(self, b):
+        """Headers of set b on the host, the shipped sizes compared with what was packed (no communication)."""
+        if self._state[b] != "inflight":
+            return self._state[b] in ("ok", "idle")
         self._read_headers(b)
-        need = self._exact_bytes(self.headers[b])
-        if need > self.nbytes[b]:
+        need = self._exact([(c, f) for c, f in self.headers[b]])
+        short = any((f & 2) or nd > sz for (c, f), nd, sz in zip(self.headers[b], need, self.sizes[b]))
+        # what the next prediction starts from: an unpacked shard is a sparse shard of that count
+        self._known = [[c, f & 1] for c, f in self.headers[b]]
+        if short:
             self.overflows += 1
-            self.host_syncs += 1
-            if self.work[b] is not None:
-                self.work[b].wait()
-                self.work[b] = None
-            self._issue(b, need)
-            if self.work[b] is not None:
-                self.work[b].wait()
-                self.work[b] = None
-        self._settled[b] = True
-        self._known = self.headers[b]
+        self._state[b] = "short" if short else "ok"
+        return not short
 
-    def start(self, b, X, Y, opl, alive, number=None):
-        """Pack this rank's survivors into buffer set b and enqueue the gather; returns the bytes shipped per rank."""
-        if self.work[b] is not None:
-            self.work[b].wait()
-            self.work[b] = None
-        self._settle(b)                       # the previous use of this set (two steps ago with two sets)
+    # ---- per step ------------------------------------------------------------------------------------------------------
+    def acquire(self, b):
+        """Before the step's trace: the caller's stream waits for the previous transfers of set b (its send buffer is about
+        to be rewritten), the step before that is checked (a short one nobody settled is dropped).  -> the zero-copy
+        targets (X, Y, path views) if this gather was built with zero_copy, else None."""
+        self._wait(b)
+        if not self._check(b):
+            self.dropped += 1
+        self._state[b] = "idle"
+        self._src[b] = self.send[b]
+        self._acquired[b] = True
+        return self.targets(b) if self.zero_copy else None
+
+    def start(self, b, X, Y, opl, alive, stats_dev=None, number=None):
+        """Enqueue the step on set b: header (zero-copy: X is the view acquire(b) handed out, stats_dev the read-out's 24
+        statistics) or pack, header exchange, payload transfers.  -> the bytes this rank ships."""
+        if not self._acquired[b]:
+            self.acquire(b)
+        self._acquired[b] = False
         first, step, _ = self.specs[self.rank]
-        self.be.pack_survivors(alive, X, Y, opl, number, first, step, self.send[b])
-        mine = self.send[b][:16].view(torch.int64)
+        zero = X.data_ptr() == self.targets(b)[0].data_ptr()
+        if zero:
+            if stats_dev is None or number is not None:
+                raise ValueError("zero-copy survivor records need the read-out's statistics and implicit ray numbers")
+            self.be.survivor_finish(stats_dev, self.n, self.send[b], self.xh_mine[b])
+        else:
+            self.be.pack_survivors(alive, X, Y, opl, number, first, step, self.send[b])
+            self.be.survivor_xheader(self.send[b], stats_dev, self.xh_mine[b])
+        self._args[b] = (X, Y, opl, alive, number)
         if self._side is not None:
-            # the headers travel on the communicator's stream BEHIND the previous step's payload gather, and their copy to
-            # the host on a side stream behind that: the caller's stream (the next trace) never waits for either
-            if dist.is_available() and dist.is_initialized():
-                w = dist.all_gather_into_tensor(self.hdr[b].view(-1), mine, async_op=True)
+            # the headers travel on the communicator's stream, their copy to the host on a side stream behind that: the
+            # caller's stream (the next trace) never waits for either
+            if self._dist():
+                w = dist.all_gather_into_tensor(self.xh[b].view(-1), self.xh_mine[b], async_op=True)
                 with torch.cuda.stream(self._side):
                     w.wait()                  # the SIDE stream waits for the collective
             else:
-                self.hdr[b][0].copy_(mine)
+                self.xh[b][0].copy_(self.xh_mine[b])
                 self._side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._side):
-                self._hdr_host[b].copy_(self.hdr[b], non_blocking=True)
+                self._xh_host[b].copy_(self.xh[b], non_blocking=True)
                 self._hdr_event[b] = torch.cuda.Event()
                 self._hdr_event[b].record()
         else:                                 # CPU tensors (gloo tests): everything is synchronous
-            if dist.is_available() and dist.is_initialized():
-                dist.all_gather_into_tensor(self.hdr[b].view(-1), mine)
+            if self._dist():
+                dist.all_gather_into_tensor(self.xh[b].view(-1), self.xh_mine[b])
             else:
-                self.hdr[b][0].copy_(mine)
-            self._hdr_host[b].copy_(self.hdr[b])
-        self._settled[b] = False
+                self.xh[b][0].copy_(self.xh_mine[b])
+            self._xh_host[b].copy_(self.xh[b])
+        self._state[b] = "inflight"
         if self._known is None or not self.predict:
             self.host_syncs += 1              # nothing to predict from: this step's own headers, synchronously
             self._read_headers(b)
-            nb = self._exact_bytes(self.headers[b])
-            self._settled[b], self._known = True, self.headers[b]       # exact by construction
-        else:
-            nb = self._predicted_bytes(self._known)
-        self._issue(b, nb)
-        return nb
+            self._issue(b, self._exact([(c, f) for c, f in self.headers[b]]))
+            self._check(b)                    # exact by construction -- unless a zero-copy shard came out unpacked (settle repairs)
+            return self.nbytes[b]
+        sizes = self._predicted(self._known)
+        self._issue(b, sizes)
+        return self.nbytes[b]
+
+    def settle(self, b):
+        """Complete the step on set b -- EVERY rank calls it (a short step's transfers are issued again with the exact sizes,
+        which is communication); afterwards result(b) holds on dst.  Waits for set b only: the step on the other set may
+        still be tracing."""
+        if self._state[b] == "idle":
+            return
+        self._wait(b)
+        if self._check(b):
+            return
+        self.host_syncs += 1
+        mine = self.headers[b][self.rank]
+        if mine[1] & 2:                       # a zero-copy shard that lost rays: pack its records (the sections are intact)
+            X, Y, opl, alive, number = self._args[b]
+            if self.alt[b] is None:
+                self.alt[b] = torch.empty(self.cap, dtype=torch.uint8, device=self.be.device)
+            first, step, _ = self.specs[self.rank]
+            self.be.pack_survivors(alive, X, Y, opl, number, first, step, self.alt[b])
+            self._src[b] = self.alt[b]
+        self.headers[b] = [[c, (f & 1) if not (f & 2) else 0] for c, f in self.headers[b]]     # packed now: sparse records
+        self._issue(b, self._exact([(c, f) for c, f in self.headers[b]]))
+        self._wait(b)
+        self._state[b] = "ok"
 
     def drain(self):
-        for b, w in enumerate(self.work):
-            if w is not None:
-                w.wait()
-                self.work[b] = None
-            self._settle(b)
+        for b in range(len(self.send)):
+            self.settle(b)
+
+    def stats(self, b):
+        """Global read-out statistics of the step on set b (DEVICE tensor [24]): the shards' statistics rode on the header
+        exchange; folded on the device (sums added, minima / maxima folded)."""
+        if self._hdr_event[b] is not None:
+            torch.cuda.current_stream().wait_event(self._hdr_event[b])      # (recorded behind the all-gather)
+        self.be.exchange_fold(self.xh[b].view(-1)[2:], self.world, XHDR, self._stats_out[b])
+        return self._stats_out[b]
 
     def result(self, b):
-        """On dst: [(number int64 [c], X [c], Y [c], path [c])] per rank (views of receive set b; the numbers of a dense
-        shard are generated).  None elsewhere.  With more than one rank, call drain() on EVERY rank first: settling a set
-        may re-issue its gather (overflow), which is a collective."""
-        if not self._settled[b] and self.world > 1 and dist.is_available() and dist.is_initialized():
-            raise RuntimeError("SurvivorGather.result: set %d is not settled yet -- call drain() on every rank first" % b)
-        if self.work[b] is not None:
-            self.work[b].wait()
-            self.work[b] = None
-        self._settle(b)
+        """On dst: [(number int64 [c], X [c], Y [c], path [c])] per rank (views of the receive buffers -- the root's own
+        shard: of its send buffer; the numbers of a dense shard are generated).  None elsewhere.  With more than one rank
+        the step must have been settled (settle(b) / drain() on EVERY rank)."""
+        if self._state[b] not in ("ok", "idle") and self.world > 1 and self._dist():
+            raise RuntimeError("SurvivorGather.result: set %d is not settled yet -- call settle(%d) or drain() on every rank first" % (b, b))
+        self.settle(b)
         if self.recv[b] is None:
             return None
-        return [decode_survivors(buf, *self.headers[b][r], self.specs[r]) for r, buf in enumerate(self.recv[b])]
+        bufs = [self._src[b] if r == self.rank else buf for r, buf in enumerate(self.recv[b])]
+        return [decode_survivors(buf, *self.headers[b][r], self.specs[r]) for r, buf in enumerate(bufs)]
 
     def assemble(self, b):
         """On dst: (number, X, Y, path) of all survivors of the job in global ray order (rank order for contiguous

@@ -111,7 +111,7 @@ int main(void) {
   double *ana_scratch, *ana_out;
   CHECK_HIP(hipMalloc((void**)&job_dev, sizeof(job)));
   CHECK_HIP(hipMemcpy(job_dev, &job, sizeof(job), hipMemcpyHostToDevice));
-  CHECK_HIP(hipMalloc((void**)&ana_scratch, (size_t)art_analysis_scratch_doubles(1) * sizeof(double)));
+  CHECK_HIP(hipMalloc((void**)&ana_scratch, (size_t)art_analysis_scratch_doubles(1, n) * sizeof(double)));
   CHECK_HIP(hipMalloc((void**)&ana_out, ART_ANALYSIS_DOUBLES * sizeof(double)));
   CHECK_ART(art_analyse_bundles(job_dev, &job, 1, n, ana_scratch, ana_out, NULL));
   double row[ART_ANALYSIS_DOUBLES];

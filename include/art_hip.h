@@ -360,8 +360,15 @@ int64_t art_survivor_bytes(int64_t count, int32_t dense);
  * (stats24[0] = number of alive slots, DEVICE): it writes the header -- (n, dense) if every slot is alive, and the buffer is
  * complete without a pack or a staging copy; otherwise (count, flags bit 1 "unpacked"): the sections hold slot-indexed
  * values with holes and the caller packs them into ANOTHER buffer with art_pack_survivors (X, Y, opl may point into this
- * one).  `send`: DEVICE, 16-byte aligned, >= art_survivor_bytes(n, 1) bytes.                                            */
-int art_survivor_finish(const double* stats24, int64_t n, void* send, void* stream);
+ * one).  `send`: DEVICE, 16-byte aligned, >= art_survivor_bytes(n, 1) bytes.
+ * `xhdr` (DEVICE, ART_XHDR_DOUBLES doubles, or NULL): the rank's contribution to the per-step HEADER EXCHANGE of a sharded
+ * run, filled in the same launch -- [0], [1] = count, flags as int64 bit patterns, [2 .. 25] = stats24.  All ranks all-gather
+ * these 208 bytes: every rank learns every shard's count (the size of the next transfer is predicted from it) and the
+ * global statistics follow by art_exchange_fold(recv + 2, world, ART_XHDR_DOUBLES, out).  art_survivor_xheader builds the
+ * same block behind art_pack_survivors (header read from `send`; stats24 may be NULL: zeros).                          */
+#define ART_XHDR_DOUBLES 26
+int art_survivor_finish(const double* stats24, int64_t n, void* send, double* xhdr, void* stream);
+int art_survivor_xheader(const void* send, const double* stats24, double* xhdr, void* stream);
 int art_pack_survivors(const uint8_t* alive, int64_t n, const double* X, const double* Y, const double* opl,
                        const int64_t* number, int64_t first, int64_t step, int32_t* scratch_ints, void* send,
                        int64_t send_bytes, void* stream);

@@ -663,6 +663,105 @@ def weighted_standard_deviation(v, w):
     return float(np.sqrt(np.sum(variance)))
 
 
+# =============================================================================== analysis behind the trace
+def e_transmission(B_in: Bundle, B_out: Bundle) -> float:
+    """ART/ModuleAnalysisAndPlots.py:62-77 (percent)."""
+    return float(100 * np.sum(B_out.intensity) / np.sum(B_in.intensity))
+
+
+def numerical_aperture(B: Bundle, refractive_index: float = 1) -> float:
+    """ART/ModuleProcessing.py:536-566: sin of the largest angle between any ray and the central ray's vector."""
+    _, cv = find_central_ray(B)
+    return float(np.sin(np.amax(angle_between(np.broadcast_to(cv, B.vector.shape), B.vector))) * refractive_index)
+
+
+def result_summary(D: Detector, B: Bundle):
+    """ART/ModuleAnalysisAndPlots.py:81-129: (spot-size SD in mm, duration SD in fs) at the detector as it stands."""
+    return standard_deviation(detector_points2dcentre(D, B)), standard_deviation(detector_delays(D, B))
+
+
+def detector_shifted(D: Detector, shift: float) -> Detector:
+    """ART/ModuleDetector.py:163-177 (shiftByDistance: centre - shift * normal; refpoint and normal stay)."""
+    return Detector(D.centre - shift * D.normal, D.normal, D.refpoint)
+
+
+def _find_optimal_distance_bis(D: Detector, amplitude, step, B: Bundle, opt_for, weighted):
+    """ART/ModuleProcessing.py:317-366: one scan level, POSITION BY POSITION as the reference loops (no linear model):
+    n = int(2 A / Step) positions from -A in steps of Step; returns the detector at the best position."""
+    sizes, durations, fitness = [], [], []
+    w = B.intensity if weighted else None
+    D = detector_shifted(D, -amplitude)
+    n = int(2 * amplitude / step)
+    for _ in range(n):
+        if opt_for in ("intensity", "spotsize"):
+            P = detector_points2dcentre(D, B)
+            size = weighted_standard_deviation(P, w) if weighted else standard_deviation(P)
+            sizes.append(size)
+        if opt_for in ("intensity", "duration"):
+            dl = detector_delays(D, B)
+            dur = weighted_standard_deviation(dl, w) if weighted else standard_deviation(dl)
+            durations.append(dur)
+        fitness.append(size ** 2 * dur if opt_for == "intensity" else (dur if opt_for == "duration" else size))
+        D = detector_shifted(D, step)
+    ind = fitness.index(min(fitness))
+    D = detector_shifted(D, -(n - ind) * step)
+    return (D, sizes[ind] if opt_for in ("intensity", "spotsize") else np.nan,
+            durations[ind] if opt_for in ("intensity", "duration") else np.nan)
+
+
+def find_optimal_distance(D: Detector, B: Bundle, opt_for="intensity", amplitude=None, precision=3, weighted=False):
+    """ART/ModuleProcessing.py:369-460.  (Like the reference: "size" passes the name check but the scan only knows
+    "spotsize" -- only "intensity" and "duration" work.)  -> (moved Detector, spot SD, duration SD)."""
+    if opt_for not in ("intensity", "size", "duration"):
+        raise NameError("OptFor must be either 'intensity', 'size' or 'duration'.")
+    first = detector_distance(D)
+    size = 2 * standard_deviation(detector_points2dcentre(D, B))
+    na = numerical_aperture(B, 1)
+    if amplitude is None:
+        amplitude = min(4 * np.ceil(size / np.tan(np.arcsin(na))), first)
+    step = amplitude / 10
+    spot = dur = np.nan
+    for k in range(precision + 1):
+        D, spot, dur = _find_optimal_distance_bis(D, amplitude * 0.1 ** k, step * 0.1 ** k, B, opt_for, weighted)
+    return D, spot, dur
+
+
+def analysis_row(B: Bundle, D: Detector, co: float, axis=None):
+    """What art_analyse_bundles (include/art_hip.h) reports for bundle B on detector D, restated from the REFERENCE's
+    definitions only (no kernel code): the sums of FindCentralRay / getETransmission (ART/ModuleProcessing.py:464-482,
+    ART/ModuleAnalysisAndPlots.py:62-77), the read-out of ART/ModuleDetector.py:191-279 at the detector and at the detector
+    shifted by 1 mm (shiftByDistance, :163-177: every ray's read-out is linear in the shift, so the difference IS the
+    slope), the largest Kahan angle to `axis` (default: the mean vector; ART/ModuleProcessing.py:536-566), and the shifts
+    at which a hit point passes through its ray's origin (t(s) = n.(C - s n - A) / (u.n) = 0).  `co`: the provisional
+    centre of the path moments -- a free parameter of the sums, taken from the caller.  -> dict of row slots."""
+    w = B.intensity if B.intensity is not None else np.ones(len(B))
+    P0 = detector_points2d(D, B)
+    O0 = optical_paths(D, B)
+    D1 = detector_shifted(D, 1.0)
+    P1 = detector_points2d(D1, B)
+    O1 = optical_paths(D1, B)
+    q = [P0[:, 0], P0[:, 1], O0 - co]
+    sq = [P1[:, 0] - P0[:, 0], P1[:, 1] - P0[:, 1], (O1 - O0) - 1.0]
+    mom = np.zeros(32)
+    for base, wt in ((0, np.ones(len(B))), (16, w)):
+        mom[base] = wt.sum()
+        for k in range(3):
+            o = base + 1 + 5 * k
+            mom[o:o + 5] = [(wt * q[k]).sum(), (wt * sq[k]).sum(), (wt * q[k] * q[k]).sum(), (wt * q[k] * sq[k]).sum(),
+                            (wt * sq[k] * sq[k]).sum()]
+    n = D.normal
+    sk = ((D.centre - B.point) @ n) / (n @ n)
+    if axis is None:
+        axis = find_central_ray(B)[1]
+    return {"count": float(len(B)), "sum_point": B.point.sum(axis=0), "sum_vector": B.vector.sum(axis=0), "sum_w": float(w.sum()),
+            "sum_path": float(np.sum(B.path)), "moments": mom,
+            "kink_below": sk[sk <= 0].max() if (sk <= 0).any() else -np.inf,
+            "kink_above": sk[sk > 0].min() if (sk > 0).any() else np.inf,
+            "max_angle": float(np.amax(angle_between(np.broadcast_to(axis, B.vector.shape), B.vector))),
+            "bbox": np.array([P0[:, 0].min(), P0[:, 0].max(), P0[:, 1].min(), P0[:, 1].max(), O0.min(), O0.max()]),
+            "mean_opl": float(O0.mean())}
+
+
 # =============================================================================== ModuleSource
 def spiral_vogel(n, radius):
     """ART/ModuleGeometry.py:61-76."""

@@ -45,7 +45,7 @@ def chain_golden_names():
     names = []
     for p in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))):
         n = os.path.basename(p)[:-4]
-        if n in ("zernike_tierA", "geometry_units", "render_grids"):
+        if n in ("zernike_tierA", "geometry_units", "render_grids") or n.startswith("analysis_"):
             continue
         names.append(n)
     return names

@@ -514,3 +514,75 @@ def run_list_analysis_edges():
         raise AssertionError("an empty bundle was analysed")
     except TypeError as e:
         assert "Detector Normal" in str(e)
+
+
+def run_analysis_goldens(name):
+    """ARTmain.analyse_chain_list -- the device analysis of a whole loop list -- against what THE REFERENCE computed for every
+    chain of the shipped loop lists (tests/golden/analysis_c2 / analysis_c3.npz, generate_analysis_goldens.py: ARTmain.run_ART's
+    getETransmission, Detector.autoplace, GetResultSummary and FindOptimalDistance on the full ray set).  Bars: transmission
+    1e-10 of its value, detector pose 1e-10 of the scene, spot size 1e-9, duration 1e-7 (the reference's two-pass variances
+    against the moment form), the optimum's distance on the reference's finest grid (1e-3 of the search amplitude) or within
+    1e-9 of it."""
+    import ARTmain
+    import ART.ModuleOpticalChain as moc
+    import ART.ModuleProcessing as mp
+    scene, a = load_golden(name)
+    src = pc.source_bundle(a, scene)
+    chains = []
+    for i, c in enumerate(scene["chains"]):
+        els = pc.build_elements(c, a)
+        ch = moc.OpticalChain(src, els, "golden", "loop", c["loop_variable_value"])
+        chains.append(ch)
+    worst = {"ET": 0.0, "pose": 0.0, "spot": 0.0, "dur": 0.0, "opt_dist": 0.0, "opt_spot": 0.0, "opt_dur": 0.0}
+    base = dict(ReflectionNumber=-1, ManualDetector=False, DistanceDetector=scene["detector_distance"], OptFor="intensity")
+    # (1) the summary at the auto-placed detector
+    SP, DO, AO = ARTmain.complete_defaults({"Wavelength": scene["wavelength"]}, dict(base, AutoDetectorDistance=False),
+                                           dict(verbose=False, save_results=False))
+    got = ARTmain.analyse_chain_list(chains, SP, DO, AO)
+    scale = pc.scene_scale(a, {"elements": scene["chains"][0]["elements"]})
+    for (ch, det, tr, spot, dur), c in zip(got, scene["chains"]):
+        last = ch.get_output_rays()[-1]
+        assert np.array_equal(last.numbers(), a[f"c{scene['chains'].index(c)}_last_number"])
+        d = c["detector"]
+        worst["ET"] = max(worst["ET"], abs(tr - c["ETransmission"]) / c["ETransmission"])
+        worst["pose"] = max(worst["pose"], np.abs(det.centre - d["centre"]).max() / scale, np.abs(det.normal - d["normal"]).max(),
+                            np.abs(det.refpoint - d["refpoint"]).max() / scale)
+        worst["spot"] = max(worst["spot"], abs(spot - c["SpotSizeSD"]) / c["SpotSizeSD"])
+        worst["dur"] = max(worst["dur"], abs(dur - c["DurationSD"]) / c["DurationSD"])
+    assert worst["ET"] <= 1e-10 and worst["pose"] <= 1e-10 and worst["spot"] <= 1e-9 and worst["dur"] <= 1e-7, worst
+    # (2) the autofocus as run_ART does it (intensity, weighted), all chains in one call ...
+    DO2 = dict(DO, AutoDetectorDistance=True)
+    got = ARTmain.analyse_chain_list(chains, SP, DO2, AO)
+
+    def compare(D, s, t, ref, amplitude):
+        dist, spot, dur = ref
+        # positions of the finest level lie 1e-4 of the amplitude apart; the two implementations may settle on neighbours
+        # where the fitness is flat to rounding -- never farther apart
+        worst["opt_dist"] = max(worst["opt_dist"], abs(D.get_distance() - dist) / amplitude)
+        assert abs(D.get_distance() - dist) <= 1.5e-4 * amplitude + 1e-9 * dist, (D.get_distance(), dist, amplitude)
+        on_grid_point = abs(D.get_distance() - dist) <= 1e-9 * dist
+        if not np.isnan(spot):
+            worst["opt_spot"] = max(worst["opt_spot"], abs(s - spot) / spot)
+            assert abs(s - spot) <= (1e-9 if on_grid_point else 1e-4) * spot, (s, spot)
+        worst["opt_dur"] = max(worst["opt_dur"], abs(t - dur) / dur)
+        assert abs(t - dur) <= (1e-7 if on_grid_point else 1e-4) * dur, (t, dur)
+        return on_grid_point
+
+    same = 0
+    for (ch, det, tr, spot, dur), c in zip(got, scene["chains"]):
+        amp = min(4 * np.ceil(2 * c["SpotSizeSD"] / np.tan(np.arcsin(c["NA"]))), scene["detector_distance"])
+        same += compare(det, spot, dur, c["autofocus"]["intensity_1"], amp)
+    # ... and the other variants chain by chain (FindOptimalDistance on the placed detector)
+    import ART.ModuleDetector as mdet
+    for ch, c in zip(chains, scene["chains"]):
+        last = ch.get_output_rays()[-1]
+        d = c["detector"]
+        det = mdet.Detector(np.array(d["refpoint"]), np.array(d["centre"]), np.array(d["normal"]))
+        amp = min(4 * np.ceil(2 * c["SpotSizeSD"] / np.tan(np.arcsin(c["NA"]))), scene["detector_distance"])
+        assert abs(mp.ReturnNumericalAperture(last, 1) - c["NA"]) <= 1e-10
+        for key in ("intensity_0", "duration_1"):
+            optfor, weighted = key.rsplit("_", 1)
+            D, s, t = mp.FindOptimalDistance(det, last, optfor, None, 3, bool(int(weighted)), False)
+            same += compare(D, s, t, c["autofocus"][key], amp)
+    assert same >= 2 * len(chains), (same, len(chains))       # most optima are the reference's grid point itself
+    return worst

@@ -43,6 +43,7 @@ int main(void) {
          offsetof(ArtElementDesc, sp), offsetof(ArtElementDesc, zern), sizeof(ArtBundleView),
          sizeof(ArtDetectorDesc), (size_t)ART_ZERN_STRIDE, sizeof(ArtChainReadout), offsetof(ArtChainReadout, w),
          offsetof(ArtChainReadout, X), offsetof(ArtChainReadout, out24));
+  printf("%zu %zu\n", offsetof(ArtChainReadout, sums), offsetof(ArtAnalysisJob, sums));
   printf("%zu %zu %zu %zu %zu %zu %zu %zu %d %d %d\n", offsetof(ArtChainReadout, lite), sizeof(ArtAnalysisJob),
          offsetof(ArtAnalysisJob, w), offsetof(ArtAnalysisJob, distance), offsetof(ArtAnalysisJob, mode),
          offsetof(ArtAnalysisJob, centre), offsetof(ArtAnalysisJob, normal), offsetof(ArtAnalysisJob, refpoint),
@@ -60,7 +61,7 @@ int main(void) {
     J = _abi.ArtAnalysisJob
     assert vals == [C.sizeof(E), E.fwd.offset, E.sp.offset, E.zern.offset, C.sizeof(_abi.ArtBundleView),
                     C.sizeof(_abi.ArtDetectorDesc), _abi.ART_ZERN_STRIDE, C.sizeof(R), R.w.offset, R.X.offset,
-                    R.out24.offset,
+                    R.out24.offset, R.sums.offset, J.sums.offset,
                     R.lite.offset, C.sizeof(J), J.w.offset, J.distance.offset, J.mode.offset, J.centre.offset,
                     J.normal.offset, J.refpoint.offset, _abi.ART_ANALYSIS_DOUBLES, _abi.ART_GUIDES_MAX, _abi.ART_MAX_DEFECTS]
 
@@ -81,6 +82,22 @@ def test_no_cpu_fallback():
         import ART.ModuleProcessing as mp
         with pytest.raises(RuntimeError):
             mp.RayTracingCalculation([mray.Ray(np.zeros(3), np.array([1.0, 0, 0]))], [])
+    finally:
+        _lib._BACKEND = old
+
+
+def test_loader_takes_no_library_from_the_environment(monkeypatch):
+    """The process-wide backend loads the in-tree product library and nothing else: no environment variable can put
+    another .so (a CPU stand-in, say) in its place.  Diagnostic builds are loaded explicitly: HipBackend(path=...)."""
+    import importlib
+    from attosecondraytracing_amd import _lib
+    monkeypatch.setenv("ART_HIP_LIB", "/tmp/some_other_library.so")
+    old = _lib._BACKEND
+    try:
+        lib2 = importlib.reload(_lib)
+        assert lib2.LIB_PATH == os.path.join(ROOT, "attosecondraytracing_amd", "libart_hip.so")
+        src = open(os.path.join(ROOT, "attosecondraytracing_amd", "_lib.py")).read()
+        assert "os.environ" not in src and "getenv" not in src
     finally:
         _lib._BACKEND = old
 

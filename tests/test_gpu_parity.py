@@ -689,17 +689,26 @@ def test_gpu_list_analysis(hip):
     scene_cases.run_list_analysis(rays=200_003)
 
 
+@pytest.mark.parametrize("name", ["analysis_c2", "analysis_c3"])
+def test_gpu_list_analysis_matches_the_reference_for_every_chain(hip, name):
+    """art_analyse_bundles + the moment-form autofocus against the reference's FindOptimalDistance / GetResultSummary /
+    getETransmission for all 11 C2 and all 10 C3 chains (fixtures from the reference itself, not from the twin)."""
+    import scene_cases
+    w = scene_cases.run_analysis_goldens(name)
+    report(f"[analysis goldens {name}] vs the reference, worst over all chains: " + "  ".join(f"{k} {float(v):.1e}" for k, v in w.items()))
+
+
 def test_gpu_analysis_rows_match_numpy(hip):
     """Every slot of art_analyse_bundles' output rows (sums, placed detector, 32 moments, kink shifts, largest angle,
-    bounding box) against a NumPy reduction of the same bundle (tests/twin_backend.py: the per-ray read-out of the twin's
-    art_device.h code, reduced on the host), for an auto-placed, a manual and a sums-only job, odd ray count."""
-    import ctypes as C
+    bounding box) against a PURE-NumPy restatement of the reference's definitions (oracle/art_oracle.py: detector_autoplace,
+    analysis_row -- ART/ModuleDetector.py:109-137, :191-279, ART/ModuleProcessing.py:464-482, :536-566; no kernel code on
+    that side), for an auto-placed, a manual and a sums-only job, odd ray count."""
     import torch
     import bench
     import ART.ModuleProcessing as mp
     import ART.ModuleDetector as mdet
     from attosecondraytracing_amd import _abi, analysis
-    from twin_backend import TwinBackend
+    from oracle import art_oracle as orc
     lists, kind, dist = bench.scene_c3()
     n = 100_003
     src = bench.device_source(n, 0, n, hip, kind)
@@ -711,41 +720,46 @@ def test_gpu_analysis_rows_match_numpy(hip):
     man.shiftByDistance(3.0)
     reqs = [(B, _abi.ART_JOB_AUTOPLACE, dist), (B, _abi.ART_JOB_MANUAL, man), (src, _abi.ART_JOB_SUMS, None)]
     rows = hip.analyse_bundles([analysis._job(b, m_, a_) for b, m_, a_ in reqs], n).cpu().numpy()
-    # the same jobs over host copies of the arrays
-    keep = []
 
-    def host_job(b, mode, arg):
-        data, alive, w = b.data.cpu().contiguous().numpy().copy(), b.alive.cpu().numpy().copy(), b.intensity.cpu().numpy().copy()
-        keep.append((data, alive, w))
-        j = analysis._job(b, mode, arg)
-        v = _abi.ArtBundleView()
-        for k, f in enumerate(("ox", "oy", "oz", "dx", "dy", "dz", "path", "incidence")):
-            setattr(v, f, data[k].ctypes.data)
-        v.alive = alive.ctypes.data
-        j.b, j.w = v, w.ctypes.data
-        return j
-    ref = TwinBackend().analyse_bundles([host_job(*r) for r in reqs], n).numpy()
-    for j in range(3):
-        g, r = rows[j], ref[j]
-        assert g[0] == r[0] and g[0] > 0
-        assert np.abs(g[1:9] - r[1:9]).max() <= 1e-12 * g[0] * 2000.0          # sums of mm-scale coordinates
+    def oracle_bundle(b):
+        a = b.alive.bool().cpu().numpy()
+        d = b.data.cpu().numpy()
+        return orc.make_bundle(d[0:3].T[a], d[3:6].T[a], np.nonzero(a)[0], b.intensity.cpu().numpy()[a], 50e-6), d[6][a]
+    for j, (b, mode, arg) in enumerate(reqs):
+        g = rows[j]
+        Bo, path = oracle_bundle(b)
+        Bo.path = path[:, None]
+        assert g[0] == len(Bo) > 0
         if j == 2:
+            r = orc.analysis_row(Bo, orc.Detector(np.zeros(3), np.array([0.0, 0.0, 1.0]), np.zeros(3)), 0.0)
+            assert np.abs(g[1:4] - r["sum_point"]).max() <= 1e-12 * g[0] * 2000.0 and np.abs(g[4:7] - r["sum_vector"]).max() <= 1e-12 * g[0]
+            assert abs(g[7] - r["sum_w"]) <= 1e-12 * r["sum_w"]
             assert not g[10:53].any() and g[53] == -np.inf and g[54] == np.inf
             continue
-        assert np.abs(g[10:20] - r[10:20]).max() <= 1e-11 * 2000.0             # detector, reference point, path centre
+        # the detector: placed like Detector.autoplace (oracle: detector_autoplace), or the manual one, bit for bit
+        Do = orc.detector_autoplace(Bo, dist) if mode == _abi.ART_JOB_AUTOPLACE else orc.Detector(man.centre, man.normal, man.refpoint)
+        assert np.abs(g[10:13] - Do.centre).max() <= 1e-11 * 2000.0 and np.abs(g[13:16] - Do.normal).max() <= 1e-12
+        assert np.abs(g[16:19] - Do.refpoint).max() <= 1e-11 * 2000.0
+        # everything else on the DEVICE's detector and path centre (a provisional centre is a free parameter of the sums)
+        Dg = orc.Detector(g[10:13].copy(), g[13:16].copy(), g[16:19].copy())
+        r = orc.analysis_row(Bo, Dg, g[19])
+        assert abs(g[19] - r["mean_opl"]) <= 0.5                                  # the path centre is near the mean path
+        assert np.abs(g[1:4] - r["sum_point"]).max() <= 1e-12 * g[0] * 2000.0 and np.abs(g[4:7] - r["sum_vector"]).max() <= 1e-12 * g[0]
+        assert abs(g[7] - r["sum_w"]) <= 1e-12 * r["sum_w"] and abs(g[8] - r["sum_path"]) <= 1e-12 * r["sum_path"]
         span = max(abs(g[56:60]).max(), 1e-3)                                   # |X|, |Y| on the detector
         osp = max(g[61] - g[60], 1e-6)                                          # spread of the optical path
-        m_g, m_r = g[20:53], r[20:53]
+        m_g, m_r = g[20:52], r["moments"]
         assert m_g[0] == m_r[0] and abs(m_g[16] - m_r[16]) <= 1e-12 * m_r[16]
         for base in (0, 16):
             wsum = m_r[base]
             for k, scale in enumerate((span, span, osp + abs(g[19] - (g[60] + g[61]) / 2))):
                 o = base + 1 + 5 * k
+                # (the NumPy side's slopes are differences of two read-outs 1 mm apart: 1e-13 of the coordinate each)
                 tol = 1e-10 * wsum * np.array([scale, 1.0, scale * scale, scale, 1.0]) + 1e-13
                 assert (np.abs(m_g[o:o + 5] - m_r[o:o + 5]) <= tol).all(), (j, base, k, m_g[o:o + 5], m_r[o:o + 5])
-        assert abs(g[55] - r[55]) <= 1e-12 and np.abs(g[56:62] - r[56:62]).max() <= 1e-11 * 2000.0
-        for k in (53, 54):
-            assert g[k] == r[k] or abs(g[k] - r[k]) <= 1e-9 * abs(r[k])       # kink shifts (~ the detector distance)
+        assert abs(g[55] - r["max_angle"]) <= 1e-12 and np.abs(g[56:62] - r["bbox"]).max() <= 1e-11 * 2000.0
+        for k, key in ((53, "kink_below"), (54, "kink_above")):
+            assert g[k] == r[key] or abs(g[k] - r[key]) <= 1e-9 * abs(r[key])       # kink shifts (~ the detector distance)
 
 
 def test_gpu_list_analysis_edges(hip):

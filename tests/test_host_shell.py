@@ -331,6 +331,14 @@ def test_list_analysis_on_the_twin(twin):
     scene_cases.run_list_analysis()
 
 
+@pytest.mark.parametrize("name", ["analysis_c2", "analysis_c3"])
+def test_list_analysis_matches_the_reference_for_every_chain(twin, name):
+    """analyse_chain_list against the reference's FindOptimalDistance / GetResultSummary / getETransmission for all 11 C2
+    and all 10 C3 chains (fixtures generated by running the reference: tests/golden/generate_analysis_goldens.py)."""
+    import scene_cases
+    scene_cases.run_analysis_goldens(name)
+
+
 def test_list_analysis_edges_on_the_twin(twin):
     import scene_cases
     scene_cases.run_list_analysis_edges()

@@ -74,6 +74,36 @@ def test_oracle_detector_matches_reference(name):
     assert abs(et - scene["ETransmission"]) <= 1e-10
 
 
+@pytest.mark.parametrize("name", ["analysis_c2", "analysis_c3"])
+def test_oracle_analysis_matches_reference(name):
+    """The oracle's restatement of the analysis behind the trace (e_transmission, detector_autoplace, result_summary,
+    numerical_aperture, find_optimal_distance: position by position, like ART/ModuleProcessing.py:317-460) against what
+    the reference computed for EVERY chain of the shipped loop lists (generate_analysis_goldens.py)."""
+    scene, a = load_golden(name)
+    src = source_from_arrays(a, scene)
+    for i, c in enumerate(scene["chains"]):
+        els = orc.elements_from_scene(c, a)
+        last = orc.ray_tracing_calculation(src, els)[-1]
+        assert np.array_equal(last.number, a[f"c{i}_last_number"])
+        assert abs(orc.e_transmission(src, last) - c["ETransmission"]) <= 1e-10
+        D = orc.detector_autoplace(last, scene["detector_distance"])
+        d = c["detector"]
+        assert np.abs(D.centre - d["centre"]).max() <= 1e-9 and np.abs(D.normal - d["normal"]).max() <= 1e-11
+        D = orc.Detector(np.array(d["centre"]), np.array(d["normal"]), np.array(d["refpoint"]))
+        spot, dur = orc.result_summary(D, last)
+        assert abs(spot - c["SpotSizeSD"]) <= 1e-9 * c["SpotSizeSD"] and abs(dur - c["DurationSD"]) <= 1e-8 * c["DurationSD"]
+        assert abs(orc.numerical_aperture(last) - c["NA"]) <= 1e-11
+        keys = ("intensity_1", "intensity_0", "duration_1") if i % 3 == 0 else ("intensity_1",)      # (bounds the run time)
+        for key in keys:
+            optfor, weighted = key.rsplit("_", 1)
+            Do, s, t = orc.find_optimal_distance(D, last, optfor, None, 3, bool(int(weighted)))
+            dist, rs, rt = c["autofocus"][key]
+            assert abs(orc.detector_distance(Do) - dist) <= 1e-9 * dist, (i, key, orc.detector_distance(Do), dist)
+            if not np.isnan(rs):
+                assert abs(s - rs) <= 1e-8 * rs, (i, key)
+            assert abs(t - rt) <= 1e-7 * rt, (i, key)
+
+
 def test_zernike_tierA():
     """Fixture generated from reference modules that import with no stand-in at all."""
     _, a = load_golden("zernike_tierA")

@@ -129,35 +129,78 @@ def _worker(rank, world, port, n_total, q):
                 off += sizes[kk]
         else:
             assert got is None and galive is None
-        # the gather of SURVEY 8(e) as written: (number:int32, X, Y, path) of the SURVIVORS only, one collective,
-        # unequal shards, two buffer sets used alternately; then a shard with every slot alive (dense: no number section)
+        # the gather of SURVEY 8(e) as written: (number:int32, X, Y, path) of the SURVIVORS only -- every peer sends its
+        # records to the root (sizes per rank), unequal shards, two buffer sets used alternately; then a shard with every
+        # slot alive (dense: no number section)
+        be = _lib.get_backend()
         specs = [sharding.shard_spec(n_total, k, world) for k in range(world)]
-        sg = sharding.SurvivorGather(_lib.get_backend(), sizes[rank], world, rank, dst=0, buffers=2, specs=specs)
-        nb = [sg.start(b, r["X"], r["Y"], r["opl"], last.alive) for b in (0, 1, 0)]
+        sg = sharding.SurvivorGather(be, sizes[rank], world, rank, dst=0, buffers=2, specs=specs)
+        nb = [sg.start(b, r["X"], r["Y"], r["opl"], last.alive, r["stats_dev"]) for b in (0, 1, 0)]
         sg.drain()
         counts = [c for c, _ in sg.headers[0]]
-        exact = max((16 + (24 if f else 28) * c + 15) // 16 * 16 for c, f in sg.headers[0])
-        # the first step reads its own headers (exact size, the one host synchronisation); the following ones are sized
+        exact = [be.survivor_bytes(c, bool(f)) for c, f in sg.headers[0]]
+        # the first step reads its own headers (exact sizes, the one host synchronisation); the following ones are sized
         # from headers the host already holds, with a margin -- never below what was packed, never above the capacity
-        assert nb[0] == exact and sg.host_syncs == 1 and sg.overflows == 0
-        assert exact <= nb[1] <= sg.cap and exact <= nb[2] <= sg.cap
+        assert nb[0] == exact[rank] and sg.host_syncs == 1 and sg.overflows == 0 and sg.dropped == 0
+        assert exact[rank] <= nb[1] <= sg.cap and exact[rank] <= nb[2] <= sg.cap
+        assert all(e <= z <= sg.cap for e, z in zip(exact, sg.sizes[0]))
         assert [f for _, f in sg.headers[0]] == [int(c == sz) for c, sz in zip(counts, sizes)]    # dense iff nothing was lost
         assert sum(counts) < n_total and counts[rank] == int(last.alive.sum())
+        # the shards' statistics rode on the header exchange: the global ones, same fold as allreduce_stats
+        assert torch.equal(sg.stats(0), stats)
         surv = sg.assemble(0)
         everyone = torch.ones_like(last.alive)
-        nbd = sg.start(1, r["X"], r["Y"], r["opl"], everyone)
+        sg.start(1, r["X"], r["Y"], r["opl"], everyone)
         sg.drain()
-        # (whatever was predicted at start -- nbd -- the settled size covers the dense records)
-        assert [f for _, f in sg.headers[1]] == [1] * world and sg.nbytes[1] >= 16 + 24 * max(sizes) + (-24 * max(sizes)) % 16 >= 0 * nbd
+        # (whatever was predicted at start, the settled size covers the dense records)
+        assert [f for _, f in sg.headers[1]] == [1] * world and sg.nbytes[1] >= be.survivor_bytes(sizes[rank], True)
         dense = sg.assemble(1)
+        # ZERO-COPY: the "read-out" writes X, Y, path straight into the send buffer's dense sections; with every slot alive
+        # art_survivor_finish's header completes the buffer -- same records as the packed dense step, no pack
+        zc = sharding.SurvivorGather(be, sizes[rank], world, rank, dst=0, buffers=2, specs=specs, zero_copy=True)
+        all_stats = r["stats_dev"].clone()
+        all_stats[0] = sizes[rank]
+        packs = [0]
+        real_pack = be.pack_survivors
+        be.pack_survivors = lambda *a, **k: (packs.__setitem__(0, packs[0] + 1), real_pack(*a, **k))[1]
+        try:
+            for b in (0, 1, 0):
+                tx, ty, tp = zc.acquire(b)
+                tx.copy_(r["X"]); ty.copy_(r["Y"]); tp.copy_(r["opl"])
+                zc.start(b, tx, ty, tp, everyone, all_stats)
+            zc.drain()
+            assert packs[0] == 0 and zc.overflows == 0 and zc.host_syncs == 1
+            assert zc.nbytes[0] == be.survivor_bytes(sizes[rank], True)
+            zdense = zc.assemble(0)
+            # ... and a zero-copy shard that DID lose rays: its header says `unpacked`; settle() packs it from the sections and
+            # ships the exact records -- on every rank alike
+            lost_stats = r["stats_dev"].clone()          # (its slot 0 is the true count of survivors of last.alive)
+            tx, ty, tp = zc.acquire(1)
+            tx.copy_(r["X"]); ty.copy_(r["Y"]); tp.copy_(r["opl"])
+            zc.start(1, tx, ty, tp, last.alive, lost_stats)
+            lost_some = counts[rank] < sizes[rank]
+            zc.settle(1)
+            assert packs[0] == (1 if lost_some else 0) and zc.overflows == 1       # (some rank lost rays: the step was short)
+            zlost = zc.assemble(1)
+            # a short step nobody settles is dropped when its set is reused; its headers still teach the next prediction
+            tx, ty, tp = zc.acquire(0)
+            tx.copy_(r["X"]); ty.copy_(r["Y"]); tp.copy_(r["opl"])
+            zc.start(0, tx, ty, tp, last.alive, lost_stats)
+            zc.acquire(0)
+            assert zc.dropped == 1 and zc.overflows == 2
+            zc.start(0, r["X"], r["Y"], r["opl"], last.alive, r["stats_dev"])      # (not the targets: the packing path)
+            zc.drain()
+            assert zc.overflows == 2
+            zpacked = zc.assemble(0)
+        finally:
+            be.pack_survivors = real_pack
         # OVERFLOW: a gather sized from a step that lost most of its rays, followed by a step in which every ray survives
-        # (no margin, no slack: the prediction is the previous count).  The shipped size is too small; when that step's
-        # headers are settled the gather is issued again with the exact size -- on both ranks alike -- and the assembled
-        # result is the exact one.  A step that packs LESS than predicted is simply decoded by its own count.
+        # (no margin, no slack: the prediction is the previous count).  The shipped size is too small; when that step is
+        # settled its transfers are issued again with the exact sizes -- on both ranks alike -- and the assembled result is
+        # the exact one.  A step that packs LESS than predicted is simply decoded by its own count.
         few = torch.zeros_like(last.alive)
         few[::10] = last.alive[::10]
-        tight = sharding.SurvivorGather(_lib.get_backend(), sizes[rank], world, rank, dst=0, buffers=2, specs=specs,
-                                        margin=0.0, slack=0)
+        tight = sharding.SurvivorGather(be, sizes[rank], world, rank, dst=0, buffers=2, specs=specs, margin=0.0, slack=0)
         n0 = tight.start(0, r["X"], r["Y"], r["opl"], few)
         n1 = tight.start(1, r["X"], r["Y"], r["opl"], few)
         assert n0 == n1 and tight.host_syncs == 1
@@ -165,15 +208,25 @@ def _worker(rank, world, port, n_total, q):
         assert n2 == n0 and tight.overflows == 0
         n3 = tight.start(1, r["X"], r["Y"], r["opl"], last.alive)        # (packs more than `few` as well)
         tight.drain()
-        assert tight.overflows == 2 and tight.nbytes[0] == 16 + 24 * max(sizes) + (-24 * max(sizes)) % 16
+        assert tight.overflows == 2 and tight.host_syncs == 3 and tight.nbytes[0] == be.survivor_bytes(sizes[rank], True)
         over, after = tight.assemble(0), tight.assemble(1)
         n4 = tight.start(0, r["X"], r["Y"], r["opl"], few)               # predicted from the big step: shrinks again
         tight.drain()
         small = tight.assemble(0)
         assert n4 >= n0 and tight.overflows == 2
+        try:            # the records of an unsettled step are refused, not guessed
+            tight.start(1, r["X"], r["Y"], r["opl"], everyone)
+            tight.result(1)
+            raise AssertionError("result() of an unsettled short step was handed out")
+        except RuntimeError as e:
+            assert "not settled" in str(e)
+        tight.drain()
         if rank == 0:
             assert all(torch.equal(a_, b_) for a_, b_ in zip(over, dense))
             assert all(torch.equal(a_, b_) for a_, b_ in zip(after, surv))
+            assert all(torch.equal(a_, b_) for a_, b_ in zip(zdense, dense))
+            assert all(torch.equal(a_, b_) for a_, b_ in zip(zlost, surv))
+            assert all(torch.equal(a_, b_) for a_, b_ in zip(zpacked, surv))
             # the survivors of `few`: those of the full step whose slot index within their shard is a multiple of ten
             offs = torch.tensor([sp[0] for sp in specs])
             shard_of = torch.bucketize(surv[0], offs[1:], right=True)

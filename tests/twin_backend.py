@@ -396,7 +396,7 @@ class TwinBackend:
             send[24:24 + 4 * k] = torch.stack([X[slots], Y[slots], opl[slots], alive[slots].to(torch.float64)], dim=1).reshape(-1)
 
     def exchange_fold(self, recv, world, stride, out):
-        allv = recv.view(world, stride)[:, :24]
+        allv = torch.stack([recv.reshape(-1)[r * stride:r * stride + 24] for r in range(world)])      # (recv may start inside a block)
         res = allv.sum(dim=0)
         for s in (2, 4, 12):
             res[s] = allv[:, s].min()
@@ -422,10 +422,17 @@ class TwinBackend:
             num = number.numpy()[a] if number is not None else first + np.nonzero(a)[0] * step
             buf[16 + 24 * c:16 + 28 * c].view(np.int32)[:] = num.astype(np.int32)
 
-    def survivor_finish(self, stats_dev, n, send):
-        """art_survivor_finish: the header of a zero-copy send buffer."""
+    def survivor_finish(self, stats_dev, n, send, xhdr=None):
+        """art_survivor_finish: the header of a zero-copy send buffer (+ the rank's block of the header exchange)."""
         c = int(stats_dev[0].item())
         send.numpy()[:16].view(np.int64)[:] = [c, 1 if c == n else 2]
+        if xhdr is not None:
+            self.survivor_xheader(send, stats_dev, xhdr)
+
+    def survivor_xheader(self, send, stats_dev, xhdr):
+        x = xhdr.numpy()
+        x[:2].view(np.int64)[:] = send.numpy()[:16].view(np.int64)
+        x[2:26] = 0.0 if stats_dev is None else stats_dev.numpy()[:24]
 
     def make_extended_source(self, radius, divergence, n_points, per, rot, S, first, n, view):
         r = (C.c_double * 9)(*[float(v) for v in np.asarray(rot).reshape(9)])
