@@ -1787,7 +1787,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_count(const uint8_t* alive, 
   const int64_t base = (int64_t)blockIdx.x * kTile;
   int c = 0;
   if (base + kTile <= n && (reinterpret_cast<uintptr_t>(alive) & 7u) == 0) {     // (workgroup-uniform)
-    c = nonzero_bytes(ld_nt(reinterpret_cast<const unsigned long long*>(alive + base) + threadIdx.x));
+    c = nonzero_bytes(reinterpret_cast<const unsigned long long*>(alive + base)[threadIdx.x]);   // (default policy: the scatter pass reads the mask again)
   } else {
     uint8_t a[kTile / kBlock];
 #pragma unroll
@@ -1845,7 +1845,7 @@ __device__ __forceinline__ void tile_ranks(const uint8_t* alive, const int64_t n
 #pragma unroll
   for (int j = 0; j < P; ++j) {
     const int64_t i = base + j * kBlock + threadIdx.x;
-    raw[j] = (i < n) ? ld_nt(alive + i) : 0;
+    raw[j] = (i < n) ? alive[i] : 0;      // (default policy: the count pass has just read these lines)
   }
   int rank[P];
 #pragma unroll
@@ -1880,7 +1880,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_scatter(const uint8_t* alive
   tile_ranks(alive, n, base, s_cnt, q);
 #pragma unroll
   for (int j = 0; j < kTile / kBlock; ++j)
-    if (q.a[j]) st_nt(idx_out + run + q.pos[j], (int64_t)(base + j * kBlock + threadIdx.x));     // (written once, read by another kernel)
+    if (q.a[j]) idx_out[run + q.pos[j]] = base + j * kBlock + threadIdx.x;
 }
 
 // ------------------------------------------------------------------------------------------- survivor records
@@ -1915,8 +1915,9 @@ __global__ __launch_bounds__(kBlock) void k_survivor_scatter(const uint8_t* aliv
   const int64_t run = tile_offsets[blockIdx.x];
   TileRanks q;
   tile_ranks(alive, n, base, s_cnt, q);
-  // four passes at a time: their records are requested together (12-16 loads in flight per lane) and then stored,
-  // non-temporally (each record is written once and read by the transfer, not by this kernel's neighbours)
+  // four passes at a time: their records are requested together (12-16 loads in flight per lane) and then stored -- with
+  // the default cache policy: the records of a masked shard land at unaligned positions, and non-temporal partial-line
+  // stores measured 8 % slower (98.5 -> 106.5 us per 1e7 dense slots, profiles/r05_experiments.md)
   constexpr int P = kTile / kBlock, H = 4;
 #pragma unroll
   for (int j0 = 0; j0 < P; j0 += H) {
@@ -1934,8 +1935,8 @@ __global__ __launch_bounds__(kBlock) void k_survivor_scatter(const uint8_t* aliv
     for (int u = 0; u < H; ++u) {
       if (q.a[j0 + u]) {
         const int64_t p = run + q.pos[j0 + u];
-        st_nt(sx + p, xv[u]); st_nt(sy + p, yv[u]); st_nt(so + p, ov[u]);
-        if (!dense) st_nt(sn + p, (int32_t)nv[u]);
+        sx[p] = xv[u]; sy[p] = yv[u]; so[p] = ov[u];
+        if (!dense) sn[p] = (int32_t)nv[u];
       }
     }
   }

@@ -54,13 +54,14 @@ class SceneProgram:
     the trace; its return value is `self.post_result`.
 
     `readout_lite=True`: the fused read-outs reduce only count, sum of paths, bounding box and path range (ArtChainReadout.lite).
+    `readout_targets`: per chain None or (X, Y, opl) tensors of the caller the fused read-out writes into.
     `placement_tries` (default: ART_PLACEMENT_TRIES, else 1 = off): opt-in look at where the output bundles lie, see
     `_tune_placement` below.
 
     Results are bit-identical to `RayTracingCalculation`; the returned bundles are overwritten by the next `run()`."""
 
     def __init__(self, sources, element_lists, IgnoreDefects=True, post=None, capture=True, detectors=None, history=True,
-                 placement_tries=None, readout_lite=False):
+                 placement_tries=None, readout_lite=False, readout_targets=None):
         from . import ModuleProcessing as mp
         from . import _abi
         from .bundle import RayBundle
@@ -82,6 +83,9 @@ class SceneProgram:
         self._views_in = [s.view() for s in self.sources]
         self._bind(self._alloc_outputs())
         self._readout_lite = bool(readout_lite)
+        # readout_targets: per chain None or (X, Y, opl) caller-owned tensors the fused read-out writes into -- e.g. the
+        # dense sections of a survivor send buffer (sharding.SurvivorGather.acquire: zero-copy gather)
+        self._ro_targets = list(readout_targets) if readout_targets is not None else None
         self.detectors, self.readouts = None, None
         if detectors is not None and self.n <= self.be.MAX_FUSED_READOUT_RAYS:
             if len(detectors) != self.c:
@@ -217,10 +221,11 @@ class SceneProgram:
         self.detectors = list(detectors)
         if self.readouts is None:
             self.readouts = []
-            for d, s, area in zip(self.detectors, self.sources, self._ro_scratch):
+            for ci, (d, s, area) in enumerate(zip(self.detectors, self.sources, self._ro_scratch)):
                 d._iscomplete()
+                kw = {} if (self._ro_targets is None or self._ro_targets[ci] is None) else {"targets": self._ro_targets[ci]}
                 self.readouts.append(self.be.new_chain_readout(d._desc(), s.intensity, self.n, scratch=area,
-                                                               lite=self._readout_lite))
+                                                               lite=self._readout_lite, **kw))
         else:
             for d, ro in zip(self.detectors, self.readouts):
                 d._iscomplete()

@@ -348,7 +348,7 @@ class SurvivorGather:
 
     # ---- sizes ---------------------------------------------------------------------------------------------------------
     def _exact(self, headers):
-        return [self.be.survivor_bytes(c, bool(f & 1)) if c > 0 else 0 for c, f in headers]
+        return [self.be.survivor_bytes(c, bool(f & 1)) for c, f in headers]
 
     def _predicted(self, headers):
         out = []
@@ -361,15 +361,17 @@ class SurvivorGather:
 
     # ---- transfers -----------------------------------------------------------------------------------------------------
     def _issue(self, b, sizes):
-        """The payload of set b: every peer sends sizes[rank] bytes to dst, dst posts one receive per peer (one group)."""
+        """The payload of set b: every peer sends sizes[rank] bytes to dst, dst posts one receive per peer (one group).
+        A transfer of 16 bytes would carry the header alone, which the header exchange has delivered already: skipped,
+        on both sides alike."""
         self.sizes[b], self.nbytes[b] = list(sizes), int(sizes[self.rank])
         self.work[b] = []
         if not self._dist() or self.world == 1:
             return                                       # the root's own shard is read where it lies
         ops = []
         if self.rank == self.dst:
-            ops = [dist.P2POp(dist.irecv, self.recv[b][r][:sizes[r]], r) for r in range(self.world) if r != self.dst and sizes[r] > 0]
-        elif sizes[self.rank] > 0:
+            ops = [dist.P2POp(dist.irecv, self.recv[b][r][:sizes[r]], r) for r in range(self.world) if r != self.dst and sizes[r] > 16]
+        elif sizes[self.rank] > 16:
             ops = [dist.P2POp(dist.isend, self._src[b][:sizes[self.rank]], self.dst)]
         if ops:
             self.work[b] = dist.batch_isend_irecv(ops)
@@ -420,7 +422,7 @@ class SurvivorGather:
             self.acquire(b)
         self._acquired[b] = False
         first, step, _ = self.specs[self.rank]
-        zero = X.data_ptr() == self.targets(b)[0].data_ptr()
+        zero = self.n > 0 and X.data_ptr() == self.targets(b)[0].data_ptr()
         if zero:
             if stats_dev is None or number is not None:
                 raise ValueError("zero-copy survivor records need the read-out's statistics and implicit ray numbers")

@@ -34,6 +34,12 @@ def test_bench_gpus_2_spawns_two_ranks():
     # both N > 1 numbers are on the line: the statistics + sample step and the full-gather step
     assert j["value"] > 0 and j["value_full_gather"] > 0 and j["ms_per_step_full_gather"] > 0
     assert "all-gather" in j["config"]["step"] and "gather" in j["config"]["step_full_gather"]
+    # round 5: the headline step carries the survivor gather (zero-copy: every ray survives the relay, the read-out writes
+    # straight into the send buffers), the statistics-only exchange is the secondary number; one peer link was measured
+    c = j["config"]
+    assert "SURVIVING" in c["step"] and j["value_full_gather"] == j["value"] and j["value_stats_exchange"] > 0
+    assert c["gather_zero_copy"] is True and c["gather_overflows"] == 0 and c["gather_dropped"] == 0 and c["gather_host_syncs"] == 1
+    assert c["gather_bytes_per_peer"] == [16 + 24 * 5000] and c["gather_link_gbs_measured"] > 0
     # whole-job aggregate: 2 ranks x 5000 rays x 4 mirrors per step
     inter = 2 * 5000 * 4
     assert abs(j["value"] - inter * 3 / (j["ms_per_step"] * 3e-3)) <= 1e-6 * j["value"]

@@ -3,7 +3,9 @@
 `OpticalChain.get_output_rays()` + detector read-out, single Python thread.  SURVEY.md 8(d) "CPU baseline (1)".
 Only runs where the reference tree exists (the build container); writes a markdown table.
 
-usage: python tools/time_reference.py [out.md] [rays]"""
+usage: python tools/time_reference.py [out.md] [rays]      (also writes out.json: what bench.py quotes as
+cpu_baseline.reference_as_is -- a figure of the BUILD CONTAINER, the reference cannot travel to the GPU box)"""
+import json
 import os
 import sys
 import time
@@ -32,12 +34,25 @@ def scenes(n):
     yield "C1 singleparabola: OAP(f=100, 90 deg), plane wave", mp.OEPlacement(
         {"Divergence": 0, "SourceSize": 50, "Wavelength": 800e-6, "DeltaFT": 0.5, "NumberRays": n},
         [mmirror.MirrorParabolic(100, 90, msupp.SupportRoundHole(30, 5, 10, 5))], [200], [0], [0], "C1"), 100
+    R5, r5 = mmirror.ReturnOptimalToroidalRadii(500, 80)
+    tor5 = mmirror.MirrorToroidal(R5, r5, msupp.SupportRectangle(150, 32))
+    yield "C2 f-x-f: mask + 2 toroids (chain 5 of 11: d = 500 mm)", mp.OEPlacement(
+        dict(SPp), [mmask.Mask(msupp.SupportRoundHole(20, 14e-3 * 500, 0, 0)), tor5, tor5], [400, 100, 500],
+        [0, 80, -80], [0, 0, 0], "C2"), 500
     yield "C3 twisted: mask + 2 toroids", mp.OEPlacement(
         dict(SPp), [mmask.Mask(msupp.SupportRoundHole(30, 41e-3 / 2 * 500, 0, 0)), tor, tor], [500, 100, 600],
         [0, 80, -80], [0, 0, 30.0], "C3"), 600
     SP4 = dict(SPp, Divergence=0.02)
     yield "relay4: 4 toroids (the bench.py workload)", mp.OEPlacement(
         SP4, [tor] * 4, [600, 600, 1200, 600], [80, -80, 80, -80], [0, 0, 0, 0], "relay4"), 600
+    oap = mmirror.MirrorParabolic(200, 60, msupp.SupportRound(20))
+    plane = mmirror.MirrorPlane(msupp.SupportRound(30))
+    R4, r4 = mmirror.ReturnOptimalToroidalRadii(400, 78)
+    tor4 = mmirror.MirrorToroidal(R4, r4, msupp.SupportRectangle(180, 30))
+    oap2 = mmirror.MirrorParabolic(150, 45, msupp.SupportRound(25))
+    yield "C4 8-element mixed chain (OAP, plane, 2 toroids, 2 planes, OAP, plane)", mp.OEPlacement(
+        dict(SPp, Divergence=0.03), [oap, plane, tor4, tor4, plane, plane, oap2, plane], [200, 150, 250, 800, 650, 120, 140, 60],
+        [0, 45, 78, -78, 30, -30, 0, 20], [0, 0, 0, 0, 90, 0, 0, 45], "C4"), 100
     S = msupp.SupportRectangle(40, 40)
     Z = mdef.Zernike(S, {(2, 1): 1e-4, (3, 1): 5e-5, (4, 2): 2e-5, (3, 3): -3e-5, (5, 2): 1e-5, (6, 3): -4e-6, (2, 0): 2.5e-5})
     yield "C5 parabola + Zernike(order 6), IgnoreDefects=False", mp.OEPlacement(
@@ -72,6 +87,14 @@ def main():
     for r in rows:
         lines.append(f"| {r[0]} | {r[1]} | {r[2]} | {r[3]} | {r[4]:.2f} | {r[5]:.3g} | {4e7 / r[5] / 3600:.1f} h | {r[6]} rays in {r[7]:.2f} s |")
     open(out_path, "w").write("\n".join(lines) + "\n")
+    keys = {"C1": "C1", "C2": "C2", "C3": "C3", "relay4": "relay4", "C4": "C4", "C5": "C5"}
+    js = {"where": f"build container, one Python thread of {os.cpu_count()} cores, Python {sys.version.split()[0]}, NumPy {np.__version__}",
+          "tool": "tools/time_reference.py", "configs": {}}
+    for r in rows:
+        k = next(v for kk, v in keys.items() if r[0].startswith(kk))
+        js["configs"][k] = {"value": r[5], "unit": "intersections/s", "rays": r[1], "elements": r[2], "intersections": r[3],
+                            "seconds": r[4], "scene": r[0]}
+    open(os.path.splitext(out_path)[0] + ".json", "w").write(json.dumps(js, indent=1) + "\n")
     print("\n".join(lines))
 
 
