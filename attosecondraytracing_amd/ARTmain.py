@@ -128,6 +128,12 @@ def analyse_chain_list(OpticalChainList, SourceProperties, DetectorOptions, Anal
     (ART/ModuleProcessing.py:317-460) or the result summary (ART/ModuleAnalysisAndPlots.py:81-129) of every chain
     follows by arithmetic on the host.  Same numbers as calling run_ART chain by chain (which is this function with a
     list of one).  Returns [(OpticalChain, Detector, ETransmission, SpotSizeSD, DurationSD)]."""
+    from . import ModuleGeometry as mgeo
+    with mgeo.frozen_hashes():        # (nothing below modifies an element: one hash per element serves every cache key)
+        return _analyse_chain_list(OpticalChainList, SourceProperties, DetectorOptions, AnalysisOptions, loop, announce)
+
+
+def _analyse_chain_list(OpticalChainList, SourceProperties, DetectorOptions, AnalysisOptions, loop=True, announce=False):
     from . import analysis
     chains = list(OpticalChainList)
     k_an = DetectorOptions["ReflectionNumber"]

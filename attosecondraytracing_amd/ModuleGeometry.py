@@ -115,6 +115,43 @@ def IncludeDisk(R, Point):
     return bool((Point[0] ** 2 + Point[1] ** 2) <= R ** 2)
 
 
+# ------------------------------------------------------------------------------------------------- hash epochs
+# An OpticalElement's hash covers its pose and every parameter of its optic (like the reference's: it IS the cache key of
+# OpticalChain.get_output_rays) and is recomputed from the contents on every call -- arrays may be modified in place.  One
+# call of the host shell (trace_chain_list, analyse_chain_list, OEPlacement) asks for the hash of the same unchanged element
+# five to ten times (cache keys, descriptors, lazy-history scene keys): inside `with frozen_hashes():` -- code of this
+# package that does not modify an element between its first and last look at it -- the first result is reused.
+_HASH_MEMO = None
+
+
+class frozen_hashes:
+    """Context manager: element hashes computed inside it are memoised by object identity until it exits (re-entrant)."""
+
+    def __enter__(self):
+        global _HASH_MEMO
+        self._outer = _HASH_MEMO
+        if _HASH_MEMO is None:
+            _HASH_MEMO = {}
+        return self
+
+    def __exit__(self, *exc):
+        global _HASH_MEMO
+        _HASH_MEMO = self._outer
+        return False
+
+
+def memo_hash(obj, compute):
+    """hash of `obj` through the current epoch's memo (compute() when there is none, or on first sight).  The memo holds
+    the object itself: an id() cannot be recycled while the epoch lasts."""
+    memo = _HASH_MEMO
+    if memo is None:
+        return compute()
+    hit = memo.get(id(obj))
+    if hit is None:
+        hit = memo[id(obj)] = (compute(), obj)
+    return hit[0]
+
+
 # ------------------------------------------------------------------------------------------------- copies
 _SCALARS = (int, float, str, bool, type(None), np.floating, np.integer)
 

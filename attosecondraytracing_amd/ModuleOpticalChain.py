@@ -20,6 +20,11 @@ def trace_chain_list(chains, **kwargs):
     the chains' caches, so that the `get_output_rays()` calls that follow (ARTmain.run_ART, one per chain,
     ART/ARTmain.py:304-342) find their result ready.  A list as `OEPlacement` returns it -- chains that differ only in
     poses -- shares one scene table; anything else falls back to one launch per chain."""
+    with mgeo.frozen_hashes():        # (nothing below modifies an element: one hash per element serves every cache key)
+        return _trace_chain_list(chains, kwargs)
+
+
+def _trace_chain_list(chains, kwargs):
     stale = [ch for ch in chains if ch._cache_key(kwargs) != ch._last_key and getattr(ch, "_program", None) is None]
     lazy = kwargs.get("history") == "lazy"
     if len(stale) > 1 and not (lazy and kwargs.get("want", -1) not in (-1, len(stale[0].optical_elements) - 1)):

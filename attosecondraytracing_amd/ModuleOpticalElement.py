@@ -66,11 +66,14 @@ class OpticalElement:
 
     majoraxis = property(_get_majoraxis, _set_majoraxis)
 
-    def __hash__(self):
+    def _content_hash(self):
         # equal poses hash equal whatever their dtype and the sign of their zeros, like the reference's tuples of numbers
         # (ART/ModuleOpticalElement.py:107-112); through bytes, because this runs for every element of every trace call
-        pose = b"".join((np.asarray(v, dtype=float) + 0.0).tobytes() for v in (self._position, self._normal, self._majoraxis))
+        pose = (np.concatenate((self._position, self._normal, self._majoraxis)).astype(float) + 0.0).tobytes()
         return hash(pose) + hash(self.type)
+
+    def __hash__(self):
+        return mgeo.memo_hash(self, self._content_hash)
 
     # ------------------------------------------------------------------ (mis-)alignment, angles in degrees
     def _turn(self, which, axis, angle_deg):

@@ -3,6 +3,7 @@
 `RayTracingCalculation` is the drop-in boundary of this package: same name, arguments and return structure
 as ART/ModuleProcessing.py:250-313, but the per-ray Python loops are replaced by launches of the gfx950
 kernels in libart_hip.so on device-resident SoA bundles (bundle.RayBundle).  There is no CPU path."""
+import contextlib
 import copy
 import lzma
 import os
@@ -358,6 +359,12 @@ class LazyHistory:
 
 def RayTracingCalculationMany(source_rays_list, optical_elements_list, IgnoreDefects=True, history=True,
                               detectors=None, sums=False):
+    with mgeo.frozen_hashes():
+        return _RayTracingCalculationMany(source_rays_list, optical_elements_list, IgnoreDefects, history, detectors, sums)
+
+
+def _RayTracingCalculationMany(source_rays_list, optical_elements_list, IgnoreDefects=True, history=True,
+                               detectors=None, sums=False):
     """`RayTracingCalculation` for a LIST of chains in ONE launch (art_trace_scene): what `OEPlacement` returns when one
     of its arguments is a list -- 10-11 chains that differ only in poses (ART/ModuleProcessing.py:203-239), which the
     reference's `ARTmain.main` traces one after the other (ARTmain.py:304-342).  The element descriptors of all chains
@@ -497,6 +504,21 @@ def _placeChains(SourceProperties, OpticsList, variants, Description):
     c = len(variants)
     Source = _placement_source(SourceProperties, OpticsList[0])
     be = Source.backend
+    # The alignment rays live on a SIDE stream: their read-backs (one per mirror) then wait for a 64-thread kernel, not for
+    # the source generation enqueued above on the caller's stream (0.5 ms of device work per 1e7 rays that the placement
+    # arithmetic below overlaps instead of waiting for).  Only for optics without defect tables: those are uploaded
+    # while their descriptor is built, and a table must not change streams between its upload and its readers.
+    plain = not any(hasattr(O, "DeformationList") for O in OpticsList)
+    guide_ctx = be.side_stream_context("guides") if (plain and hasattr(be, "side_stream_context")) else contextlib.nullcontext()
+    with guide_ctx, mgeo.frozen_hashes():
+        chains = _placeChainsOn(be, Source, OpticsList, variants, Description, c)
+        if plain and hasattr(be, "side_stream_context"):
+            torch.cuda.current_stream().synchronize()       # (the side stream: idle by now -- every read-back drained it)
+    return chains
+
+
+def _placeChainsOn(be, Source, OpticsList, variants, Description, c):
+    from . import ModuleOpticalChain as moc
     plane_angles = [[np.deg2rad(a % 360) for a in v[2]] for v in variants]
     inc_angles = [[np.deg2rad(a % 360) for a in v[1]] for v in variants]
     centre = [np.array([0, 0, 0]) for _ in range(c)]

@@ -50,6 +50,7 @@ class HipBackend:
                                % (n, self.last_error()))
         self.device = torch.device("cuda", torch.cuda.current_device())
         self._scratch = {}
+        self._side_streams = {}
         self._scene_pool, self._scene_uploads = {}, {}
         self._job_pool = {}
         # bookkeeping for measurements: launches of the fused kernels over at least `count_from` slots, in issue order
@@ -86,6 +87,15 @@ class HipBackend:
 
     def stream_key(self):
         return torch.cuda.current_stream(self.device).cuda_stream
+
+    def side_stream_context(self, name):
+        """`with be.side_stream_context(name):` -- torch's current stream becomes a stream of this backend's own (one per
+        name) that has NOT waited for the caller's stream: for small latency-critical work (the alignment rays of a
+        placement) whose read-backs must not queue behind bulk kernels.  Tensors created inside belong to that stream."""
+        st = self._side_streams.get(name)
+        if st is None:
+            st = self._side_streams[name] = torch.cuda.Stream(device=self.device)
+        return torch.cuda.stream(st)
 
     def scratch(self, key, n, dtype):
         """Reused scratch memory `key` of the CURRENT stream (work of one stream is ordered, so one area per stream and

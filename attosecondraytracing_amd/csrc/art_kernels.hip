@@ -704,7 +704,9 @@ __device__ __forceinline__ void store_tile_lds4(const ArtBundleView& v, const in
 // its fields are wave-uniform and fetched by scalar loads where they are used.  Rays [first, first + n) of every view.
 // `bx` / `nbx`: this workgroup's index among the launch's tile workgroups and their number -- blockIdx.x / gridDim.x in the
 // tile-major launches, blockIdx.y / gridDim.y in the chain-interleaved scene launch (k_trace_scene, `transposed`).
-template <bool DEFECT>
+// KIND1 >= 0: a chain of ONE element whose optic kind is known at compile time (the one-element defect chains: C5) -- no
+// run-time switch on the kind, no element loop; ART_KIND_DYN: the general body.
+template <bool DEFECT, int KIND1 = ART_KIND_DYN>
 __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t first, const int64_t n, const int xmap,
                                            double* s_zern, const unsigned bx, const unsigned nbx, const bool keep_in = false) {
 #ifdef ART_ZERN_LDS
@@ -765,7 +767,11 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
       if (ok) ok = art::trace_ray_dyn<DEFECT>(a.e[k], zk, r);
       zk += a.e[k].n_defects * ART_ZERN_STRIDE;
 #else
-      if (ok) ok = art::trace_ray_dyn<DEFECT>(a.e[k], a.e[k].zern, r);
+      if (KIND1 != ART_KIND_DYN) {
+        if (ok) ok = art::trace_ray<(KIND1 < 0 ? 0 : KIND1), DEFECT>(a.e[0], a.e[0].zern, r);
+      } else {
+        if (ok) ok = art::trace_ray_dyn<DEFECT>(a.e[k], a.e[k].zern, r);
+      }
 #endif
 #endif
 #ifndef ART_STORE_DIRECT
@@ -774,7 +780,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
       // no history view for this element -> zero-length descriptors: every store is dropped by the range check
       store_slot(make_rsrc(a.out[k], a.out[k].alive != nullptr ? n : 0, first), i, r, ok);
 #endif
-    } while (++k < a.n_elems);
+    } while (KIND1 == ART_KIND_DYN && ++k < a.n_elems);
     if (a.flags & art::kFlagReadout) {
       // Fused detector read-out of the last bundle (art_trace_chain_readout): the ray is still in registers.  X, Y, opl
       // of dead rays are dropped by the range check.  Statistics: per wave wave_reduce24, per workgroup one partial,
@@ -1141,6 +1147,48 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_trace_scene(const ChainArgs* 
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
   const unsigned bx = transposed ? blockIdx.y : blockIdx.x, nbx = transposed ? gridDim.y : gridDim.x;   // (ONE copy of the body)
   chain_body<DEFECT>(tab[transposed ? blockIdx.x : blockIdx.y], first, n, xmap, s_dyn, bx, nbx, (transposed & 2) != 0);
+}
+
+// One-element chains WITH defects, the optic's kind a template parameter (round 5, C5: a deformed parabola + read-out).
+template <int KIND1, int WAVES>
+__global__ __launch_bounds__(kBlock, WAVES) void k_trace_scene1(const ChainArgs* __restrict__ tab, const int64_t first,
+                                                                const int64_t n, const int xmap, const int transposed) {
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  const unsigned bx = transposed ? blockIdx.y : blockIdx.x, nbx = transposed ? gridDim.y : gridDim.x;
+  chain_body<true, KIND1>(tab[transposed ? blockIdx.x : blockIdx.y], first, n, xmap, s_dyn, bx, nbx, (transposed & 2) != 0);
+}
+template <int KIND1, int WAVES>
+__global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain1(const ChainArgs, const int64_t n, const int xmap) {
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  typedef const ChainArgs __attribute__((address_space(4)))* kernarg_t;
+  chain_body<true, KIND1>(*(const ChainArgs*)(kernarg_t)__builtin_amdgcn_kernarg_segment_ptr(), 0, n, xmap, s_dyn, blockIdx.x,
+                          gridDim.x);
+}
+
+// One-element chains with defects whose optic is a plane, a sphere or a parabola (what a deformed mirror usually is: C5)
+// run a body compiled for that kind (k_trace_*1): no run-time switch, no torus state -- 98 VGPRs instead of 118.
+// ART_CHAIN_SPECIAL=0 switches it off, ART_CHAIN_SPECIAL_WAVES=5 selects the 5-wave build (96 VGPRs, one 8-byte spill per
+// ray in front of the stores); read per launch: the A/B tool alternates them inside one process.
+inline int special_waves() {
+  const char* e = getenv("ART_CHAIN_SPECIAL");
+  if (e && e[0] == '0') return 0;
+  const char* w = getenv("ART_CHAIN_SPECIAL_WAVES");
+  return (w && atoi(w) == 5) ? 5 : 4;
+}
+inline bool special_kind(const int kind) { return kind == ART_PLANE || kind == ART_SPHERE || kind == ART_PARABOLA; }
+template <int WAVES>
+void launch_scene1(const int kind, const dim3 g, hipStream_t s, const ChainArgs* seg, int64_t off, int64_t cnt, int xm, int tr) {
+  const dim3 b(kBlock);
+  if (kind == ART_PLANE) hipLaunchKernelGGL((k_trace_scene1<ART_PLANE, WAVES>), g, b, 0, s, seg, off, cnt, xm, tr);
+  else if (kind == ART_SPHERE) hipLaunchKernelGGL((k_trace_scene1<ART_SPHERE, WAVES>), g, b, 0, s, seg, off, cnt, xm, tr);
+  else hipLaunchKernelGGL((k_trace_scene1<ART_PARABOLA, WAVES>), g, b, 0, s, seg, off, cnt, xm, tr);
+}
+template <int WAVES>
+void launch_chain1(const int kind, const dim3 g, hipStream_t s, const ChainArgs& a, int64_t cnt, int xm) {
+  const dim3 b(kBlock);
+  if (kind == ART_PLANE) hipLaunchKernelGGL((k_trace_chain1<ART_PLANE, WAVES>), g, b, 0, s, a, cnt, xm);
+  else if (kind == ART_SPHERE) hipLaunchKernelGGL((k_trace_chain1<ART_SPHERE, WAVES>), g, b, 0, s, a, cnt, xm);
+  else hipLaunchKernelGGL((k_trace_chain1<ART_PARABOLA, WAVES>), g, b, 0, s, a, cnt, xm);
 }
 
 // ------------------------------------------------------------------------------------------- AoS -> SoA
@@ -2201,6 +2249,7 @@ inline size_t chain_dyn_lds() {
 }
 // (the fused kernel WITH defects stays at 4 waves: 112 VGPRs without spills; at 5 waves it spills 15 dwords and
 // measured 0.335 instead of 0.31 ms per 1e7 rays on C5, tools/r02_exp17.sh)
+
 }  // namespace
 
 static int trace_chain_impl(const ArtElementDesc* elems, int32_t n_elems, const ArtBundleView* in,
@@ -2276,7 +2325,12 @@ static int trace_chain_impl(const ArtElementDesc* elems, int32_t n_elems, const 
       // +1.6 % on C5 with the read-out, the same without; profiles/r03_experiments.md)
       const bool two = !(a.flags & art::kFlagDefects) && chain_rpl(has_mask) == 2;
       const dim3 g(grid_stream_mapped(two ? (cnt + 1) / 2 : cnt, xm)), b(kBlock);
-      if (a.flags & art::kFlagDefects)
+      const int sw = (!kDefectLoop && m == 1 && special_kind(a.e[0].kind)) ? special_waves() : 0;
+      if ((a.flags & art::kFlagDefects) && sw == 5)
+        launch_chain1<5>(a.e[0].kind, dim3(grid_stream_mapped(cnt, xm)), s, a, cnt, xm);
+      else if ((a.flags & art::kFlagDefects) && sw == 4)
+        launch_chain1<4>(a.e[0].kind, dim3(grid_stream_mapped(cnt, xm)), s, a, cnt, xm);
+      else if (a.flags & art::kFlagDefects)
         hipLaunchKernelGGL((k_trace_chain<true, 4>), dim3(kDefectLoop ? grid_for(cnt) : grid_stream_mapped(cnt, xm)), b, lds,
                            s, a, cnt, kDefectLoop ? 0 : xm);
       else if (two)       // 107 VGPRs: 4 waves per SIMD (3 and 5 measured the same or worse, tools/ab_kernel.py)
@@ -2358,6 +2412,14 @@ int art_trace_scene(const void* image_dev, const void* image_host, int64_t n, vo
     return ART_OK;
   }
   const int waves = chain_waves();
+  // one-element scenes with defects whose chains all carry the same simple optic: the body compiled for that kind
+  int kind1 = -1, special1 = 0;
+  if ((flags & 1) && n_elems == 1) {
+    const ChainArgs* ht = art::scene_table(image_host);
+    kind1 = ht[0].e[0].kind;
+    for (int c = 1; c < n_chains; ++c) kind1 = (ht[c].e[0].kind == kind1) ? kind1 : -1;
+    special1 = special_kind(kind1) ? special_waves() : 0;
+  }
   const int64_t chunk = max_rays_per_launch();
   for (int64_t off = 0; off < n; off += chunk) {
     const int64_t cnt = (n - off < chunk) ? n - off : chunk;
@@ -2372,7 +2434,11 @@ int art_trace_scene(const void* image_dev, const void* image_host, int64_t n, vo
       int tr = (scene_order((flags & art::kFlagSharedIn) != 0 && sg == 0 && n_chains > 1) && tiles <= 65535) ? 1 : 0;
       if (tr && scene_keep(cnt)) tr |= 2;
       const dim3 g = tr ? dim3(n_chains, tiles) : dim3(tiles, n_chains), b(kBlock);
-      if (flags & 1)
+      if ((flags & 1) && special1 == 5)
+        launch_scene1<5>(kind1, g, s, seg, off, cnt, xm, tr);
+      else if ((flags & 1) && special1 == 4)
+        launch_scene1<4>(kind1, g, s, seg, off, cnt, xm, tr);
+      else if (flags & 1)
         hipLaunchKernelGGL((k_trace_scene<true, 4>), g, b, 0, s, seg, off, cnt, xm, tr);
       else if (two)
         hipLaunchKernelGGL((k_trace_scene2<false, 4>), g, b, 0, s, seg, off, cnt, xm, tr);

@@ -240,3 +240,47 @@ def test_gpu_analysis_refuses_a_non_unit_manual_normal(hip):
     j.normal[:] = [0.0, 0.0, 2.0]
     with pytest.raises(ArtError, match="unit vector"):
         hip.analyse_bundles([j], n)
+
+
+def test_gpu_specialised_one_element_defect_chain(hip, monkeypatch):
+    """A one-element chain with defects on a plane / sphere / parabola runs the body compiled for that kind (k_trace_*1,
+    4 or 5 waves): same bits as the general body, by-value launch and scene launch, with read-out, with sums, bare."""
+    import torch
+    import bench
+    import ART.ModuleMirror as mmirror, ART.ModuleSupport as msupp, ART.ModuleDefects as mdef, ART.ModuleProcessing as mp
+    import ART.ModuleDetector as mdet
+    n = 70_001
+    S = msupp.SupportRectangle(40, 40)
+    Z = mdef.Zernike(S, {(2, 1): 1e-4, (3, 1): 5e-5, (4, 2): 2e-5, (3, 3): -3e-5, (5, 2): 1e-5})
+    SP = {"Divergence": 0, "SourceSize": 40, "Wavelength": 800e-6, "DeltaFT": 0, "NumberRays": 1000}
+    optics = {"parabola": mmirror.MirrorParabolic(25.4, 0, S), "sphere": mmirror.MirrorSpherical(60.0, S), "plane": mmirror.MirrorPlane(S)}
+    for name, M in optics.items():
+        ch = mp.OEPlacement(SP, [mmirror.DeformedMirror(M, [Z])], [15], [8.0], Description=name)
+        els = ch.optical_elements
+        src = bench.device_source(n, 0, n, hip, ("plane", 19.0), 800e-6)
+        src.intensity = torch.rand(n, dtype=torch.float64, device=hip.device) + 0.5
+        det = mdet.Detector(np.zeros(3), np.asarray(els[0].position, float) + np.array([-20.0, 3.0, 1.0]), np.array([0.9, -0.1, 0.05]) / np.linalg.norm([0.9, -0.1, 0.05]))
+        got = {}
+        for variant, env in (("general", {"ART_CHAIN_SPECIAL": "0"}), ("special4", {"ART_CHAIN_SPECIAL": "1"}),
+                             ("special5", {"ART_CHAIN_SPECIAL": "1", "ART_CHAIN_SPECIAL_WAVES": "5"})):
+            for k in ("ART_CHAIN_SPECIAL", "ART_CHAIN_SPECIAL_WAVES"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            a = mp.RayTracingCalculation(src, els, IgnoreDefects=False, detector=det)[-1]           # by-value launch + read-out
+            ra = det.readout(a, sync=False)
+            b = mp.RayTracingCalculationMany([src, src.copy()], [els, els], IgnoreDefects=False, detectors=[det, det])[1][-1]   # scene launch
+            rb = det.readout(b, sync=False)
+            c = mp.RayTracingCalculation(src, els, IgnoreDefects=False, history=False, sums=True)[-1]
+            got[variant] = (a.alive.clone(), a.data.clone(), ra["X"].clone(), ra["opl"].clone(), ra["stats_dev"].clone(),
+                            b.data.clone(), rb["stats_dev"].clone(), c.fused_sums()[:9].clone())
+        live = got["general"][0].bool()
+        assert 0 < int(live.sum()) <= n
+        for variant in ("special4", "special5"):
+            g, s_ = got["general"], got[variant]
+            assert torch.equal(g[0], s_[0]), (name, variant)
+            assert torch.equal(_bits(g[1][:, live]), _bits(s_[1][:, live])) and torch.equal(_bits(g[5][:, live]), _bits(s_[5][:, live]))
+            assert torch.equal(_bits(g[2][live]), _bits(s_[2][live])) and torch.equal(_bits(g[3][live]), _bits(s_[3][live]))
+            assert torch.equal(_bits(g[4]), _bits(s_[4])) and torch.equal(_bits(g[6]), _bits(s_[6])) and torch.equal(_bits(g[7]), _bits(s_[7]))
+        # the scene launch equals the by-value launch
+        assert torch.equal(_bits(got["general"][1][:, live]), _bits(got["general"][5][:, live]))

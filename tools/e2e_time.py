@@ -80,3 +80,22 @@ for rep in range(passes):
         pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
         pstats.Stats(pr).sort_stats("tottime").print_stats(25)
     del chains, res
+
+# The same workflow as a program runs it: NO synchronisation between the phases (construction, trace and analysis queue up
+# behind each other on the device while the host goes on; the one wait is the analysis' copy of its 64 doubles per chain).
+# The phase times above each end in a torch.cuda.synchronize(): their sum counts device work the host does not wait for.
+whole = []
+for rep in range(max(passes, 5)):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    chains = mp.OEPlacement(source, [mask, toroid, toroid], [500, 100, 600], [0, 80, -80], [0, 0, np.linspace(-90, 90, 10)], "C3")
+    if batched:
+        moc.trace_chain_list(chains, **kw)
+    else:
+        for ch in chains:
+            ch.get_output_rays()
+    res = analyse(chains)
+    torch.cuda.synchronize()
+    whole.append(1e3 * (time.perf_counter() - t0))
+    del chains, res
+print("whole workflow, one synchronisation at the end: " + " ".join(f"{t:.2f}" for t in whole) + f" ms; median {np.median(whole):.2f} ms", flush=True)
