@@ -105,11 +105,13 @@ class Detector:
         if not _is_number(NewDistance):
             raise TypeError("The new Detector Distance must be int or float.")
         self._centre = self._centre - (NewDistance - self.get_distance()) * self.normal
+        self._analysis = None         # (taken at the old pose)
 
     def shiftByDistance(self, Shift: float):
         if not _is_number(Shift):
             raise TypeError("The Detector Distance Shift must be int or float.")
         self._centre = self.centre - Shift * self.normal
+        self._analysis = None         # (taken at the old pose)
 
     def _iscomplete(self):
         if self.centre is None or self.normal is None:

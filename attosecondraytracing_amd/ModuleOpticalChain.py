@@ -25,18 +25,19 @@ def trace_chain_list(chains, **kwargs):
 
 
 def _trace_chain_list(chains, kwargs):
-    stale = [ch for ch in chains if ch._cache_key(kwargs) != ch._last_key and getattr(ch, "_program", None) is None]
+    keys = [ch._cache_key(kwargs) for ch in chains]          # once per chain: every step below compares or stores it
+    stale = [(ch, k) for ch, k in zip(chains, keys) if k != ch._last_key and getattr(ch, "_program", None) is None]
     lazy = kwargs.get("history") == "lazy"
-    if len(stale) > 1 and not (lazy and kwargs.get("want", -1) not in (-1, len(stale[0].optical_elements) - 1)):
+    if len(stale) > 1 and not (lazy and kwargs.get("want", -1) not in (-1, len(stale[0][0].optical_elements) - 1)):
         kw = {k: v for k, v in kwargs.items() if k not in ("history", "want")}
         # (lazy: what follows is the analysis of every chain's last bundle -- the launch forms its first pass)
-        outs = mp.RayTracingCalculationMany([ch.source_rays for ch in stale], [ch.optical_elements for ch in stale],
+        outs = mp.RayTracingCalculationMany([ch.source_rays for ch, _ in stale], [ch.optical_elements for ch, _ in stale],
                                             history=not lazy, sums=lazy, **kw)
-        for ch, o in zip(stale, outs):
+        for (ch, key), o in zip(stale, outs):
             # lazy: only the last bundle of every chain was written; the rest appears on first access (mp.LazyHistory)
             ch._output_rays = mp.LazyHistory(ch.source_rays, ch.optical_elements, first=o[-1], **kw) if lazy else o
-            ch._last_key = ch._cache_key(kwargs)
-    return [ch.get_output_rays(**kwargs) for ch in chains]
+            ch._last_key = key
+    return [ch._output_for(key, kwargs) for ch, key in zip(chains, keys)]
 
 
 class OpticalChain:
@@ -53,6 +54,23 @@ class OpticalChain:
         self._output_rays = None
         self._last_key = None
         self._program = None
+
+    @classmethod
+    def _adopt(cls, source_rays, optical_elements, description=""):
+        """OEPlacement's constructor: `optical_elements` were built for THIS chain alone (own element objects, own copies of
+        the optics: mp._placeChains), so they are adopted as they are -- the state `OpticalChain(source, elements)` reaches
+        through its deep copy --, and the source is an alias of the list's one source bundle (a bundle object of its own
+        over the SAME device arrays, bundle.RayBundle.alias, instead of a private copy of 65 bytes per ray)."""
+        new = cls.__new__(cls)
+        new.source_rays = source_rays.alias()
+        new.optical_elements = optical_elements
+        new.description = description
+        new.loop_variable_name = None
+        new.loop_variable_value = None
+        new._output_rays = None
+        new._last_key = None
+        new._program = None
+        return new
 
     # ------------------------------------------------------------------ properties
     @property
@@ -123,7 +141,10 @@ class OpticalChain:
         A chain that was `compile()`d re-traces by rewriting its device-resident scene table and replaying a captured
         HIP graph; the bundles it returns are then always the SAME objects (their arrays are overwritten by the next
         re-trace), which is what makes a pose scan on small bundles GPU-bound instead of launch-bound."""
-        key = self._cache_key(kwargs)
+        return self._output_for(self._cache_key(kwargs), kwargs)
+
+    def _output_for(self, key, kwargs):
+        """get_output_rays for a cache key the caller has computed already (trace_chain_list: once per chain)."""
         if key != self._last_key:
             prog = getattr(self, "_program", None)
             plain = {k: v for k, v in kwargs.items() if k != "want" and not (k == "history" and v in ("lazy", True))}

@@ -27,6 +27,17 @@ class OpticalElement:
 
     type = property(lambda self: self._type)
 
+    @classmethod
+    def _like(cls, other, Type):
+        """A new element with `other`'s pose (own copies of its three vectors, already validated and normalised there) and
+        the optic `Type`: what OEPlacement builds for the chains of a loop list that share a placement step."""
+        new = cls.__new__(cls)
+        new._type = Type
+        new._position = other._position.copy()
+        new._normal = other._normal.copy()
+        new._majoraxis = other._majoraxis.copy()
+        return new
+
     def _get_position(self):
         return self._position
 

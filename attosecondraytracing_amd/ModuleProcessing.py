@@ -529,10 +529,11 @@ def _placeChainsOn(be, Source, OpticsList, variants, Description, c):
     guides = be.from_numpy(np.tile(np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, np.nan]), (c, 1)))
     guide_alive = be.from_numpy(np.ones(c, dtype=np.uint8))
 
-    def advance(through):
-        """Every chain's guide ray through its element `through[j]`; chains whose element the guide kernel refuses
-        (Zernike tables in the recurrence layout) go through the element kernel, one ray at a time."""
-        descs = [element_descriptor(oe, True, be)[0] for oe in through]
+    def advance(through, ready):
+        """Every chain's guide ray through its element `through[j]` (`ready[j]`: its descriptor where the placement has
+        built it already); chains whose element the guide kernel refuses (Zernike tables in the recurrence layout) go
+        through the element kernel, one ray at a time."""
+        descs = [d if d is not None else element_descriptor(oe, True, be)[0] for oe, d in zip(through, ready)]
         if any(d.nonfinite for d in descs):
             # a mirror with NaN / inf parameters: the reference's np.roots raises for the first ray that reaches it
             # (see RayTracingCalculation), and the guide ray always does
@@ -554,48 +555,77 @@ def _placeChainsOn(be, Source, OpticsList, variants, Description, c):
         guides.copy_(be.from_numpy(host))
         guide_alive.copy_(be.from_numpy(al))
 
+    # Every chain gets its OWN element objects and its own copies of the optics (the reference's OpticalChain deep-copies
+    # its element list, ART/ModuleOpticalChain.py:88-95; an optic that appears twice in OpticsList stays ONE object inside
+    # a chain, as deepcopy's memo keeps it): built here directly, so that the chains adopt them without a second copy.
+    # The chains of a loop list are identical up to the varied entry: chains whose state in front of optic k is the same
+    # (bit for bit: central ray, incidence plane, position, distance, angles) share ONE evaluation of the placement
+    # arithmetic and ONE descriptor; the others repeat the reference's sequence (ART/ModuleProcessing.py:60-98).
+    optic_copies = [{} for _ in range(c)]
+    open_mask = None
     for k, Optic in enumerate(OpticsList):
         if not ("Mirror" in Optic.type or Optic.type == "Mask"):
             raise NameError("I don`t recognize the type of optical element " + Optic.type + ".")
-        through = []
+        convex = Optic.type in ("SphericalCX Mirror", "CylindricalCX Mirror")
+        shareable = not hasattr(Optic, "DeformationList")       # (defect tables belong to one optic object)
+        groups, through, through_descs = {}, [], []
         for j in range(c):
-            if Optic.type in ("SphericalCX Mirror", "CylindricalCX Mirror"):
+            if convex:
                 inc_angles[j][k] = np.pi - inc_angles[j][k]  # convex: reflect off the "back side"
-            centre[j] = central[j] * variants[j][0][k] + centre[j]
-            if abs(plane_angles[j][k] - np.pi) < 1e-10:
-                rot_axis[j] = -rot_axis[j]
+            dist_ = variants[j][0][k]
+            mine = optic_copies[j].get(id(Optic))
+            if mine is None:
+                mine = optic_copies[j][id(Optic)] = copy.deepcopy(Optic)
+            key = (central[j].tobytes(), central[j].dtype.char, rot_axis[j].tobytes(), rot_axis[j].dtype.char, centre[j].tobytes(),
+                   centre[j].dtype.char, type(dist_).__name__, float(dist_), plane_angles[j][k], inc_angles[j][k])
+            g = groups.get(key)
+            if g is None:
+                ctr = central[j] * dist_ + centre[j]
+                if abs(plane_angles[j][k] - np.pi) < 1e-10:
+                    ra = -rot_axis[j]
+                else:
+                    ra = mgeo.RotationAroundAxis(central[j], -plane_angles[j][k], rot_axis[j])
+                # (mgeo._cross3: np.cross for 3-vectors, the same products and differences, a tenth of its call overhead)
+                normal = mgeo.RotationAroundAxis(ra, -np.pi / 2 + inc_angles[j][k], mgeo._cross3(central[j], ra))
+                major = mgeo._cross3(ra, normal)
+                element = moe.OpticalElement(mine, ctr, normal, major)       # (validates and normalises)
+                g = groups[key] = {"ctr": ctr, "ra": ra, "first": element, "desc": None, "guide": None}
+                if Optic.type == "Mask":
+                    # the guide ray must always pass: a fully open stand-in mask (only for the guide)
+                    if open_mask is None:
+                        open_mask = mmask.Mask(msupp.SupportRoundHole(Radius=100, RadiusHole=100, CenterHoleX=0, CenterHoleY=0))
+                    g["guide"] = moe.OpticalElement(open_mask, ctr, normal, major)
+                if shareable:
+                    d, keep = _build_descriptor(element, True, be)
+                    g["desc"] = (hash(element), d, keep)
             else:
-                rot_axis[j] = mgeo.RotationAroundAxis(central[j], -plane_angles[j][k], rot_axis[j])
-            # (mgeo._cross3: np.cross for 3-vectors, the same products and differences, a tenth of its call overhead)
-            normal = mgeo.RotationAroundAxis(rot_axis[j], -np.pi / 2 + inc_angles[j][k], mgeo._cross3(central[j], rot_axis[j]))
-            major = mgeo._cross3(rot_axis[j], normal)
-            element = moe.OpticalElement(Optic, centre[j], normal, major)
+                element = moe.OpticalElement._like(g["first"], mine)          # own object and arrays, the same values
+            centre[j], rot_axis[j] = g["ctr"], g["ra"]
             elements[j].append(element)
-            if Optic.type == "Mask":
-                # the guide ray must always pass: a fully open stand-in mask (only for the guide)
-                open_mask = mmask.Mask(msupp.SupportRoundHole(Radius=100, RadiusHole=100, CenterHoleX=0, CenterHoleY=0))
-                through.append(moe.OpticalElement(open_mask, centre[j], normal, major))
-            else:
-                through.append(element)
+            if g["desc"] is not None:
+                h, d, keep = g["desc"]
+                if len(_DESC_CACHE) > 4096:
+                    _DESC_CACHE.clear()
+                _DESC_CACHE[(id(element), True)] = (h, d, keep, element)       # the trace finds it: equal content, equal hash
+            guide_el = g["guide"] if g["guide"] is not None else element
+            through.append(guide_el)
+            through_descs.append(g["desc"][1] if (g["desc"] is not None and g["guide"] is None) else None)
         if k == len(OpticsList) - 1 and Optic.type == "Mask":
             break                              # nothing is placed behind it
-        advance(through)
+        advance(through, through_descs)
         if "Mirror" in Optic.type:
             host, al = guides.cpu().numpy(), guide_alive.cpu().numpy()      # the one read-back of this optic
+            seen = {}
             for j in range(c):
                 if not al[j]:
                     raise IndexError("list index out of range")     # the reference indexes an empty survivor list here
                 v = host[j, 3:6]
-                central[j] = v / np.linalg.norm(v)                  # (the Ray.vector setter, ModuleOpticalRay.py:85-90)
-    chains = [moc.OpticalChain(Source, els, Description, _placed=True) for els in elements]
-    # the chains hold deep copies of the elements placed above (as in the reference): hand the descriptors built for the
-    # guide rays over to the copies, whose contents -- and therefore hashes -- are the same (the trace finds them cached)
-    for els, ch in zip(elements, chains):
-        for old, new in zip(els, ch.optical_elements):
-            hit = _DESC_CACHE.get((id(old), True))
-            if hit is not None and hit[3] is old and hit[0] == hash(new):
-                _DESC_CACHE[(id(new), True)] = (hit[0], hit[1], hit[2], new)
-    return chains
+                kk = v.tobytes()
+                u = seen.get(kk)
+                if u is None:
+                    u = seen[kk] = v / np.linalg.norm(v)            # (the Ray.vector setter, ModuleOpticalRay.py:85-90)
+                central[j] = u
+    return [moc.OpticalChain._adopt(Source, els, Description) for els in elements]
 
 
 def _singleOEPlacement(SourceProperties, OpticsList, DistanceList, IncidenceAngleList, IncidencePlaneAngleList,

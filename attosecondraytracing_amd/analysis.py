@@ -20,8 +20,10 @@ class BundleAnalysis:
     """One row of art_analyse_bundles' output on the host (layout: include/art_hip.h)."""
 
     def __init__(self, row, bundle, mode):
-        self.row, self.bundle, self.mode = row, bundle, mode
-        self.version = bundle.version
+        # the analysed bundle is remembered by IDENTITY (serial number + version), not held: a Detector keeps its analysis,
+        # and a detector kept in `kept_data` must not pin 650 MB of device memory per 1e7 rays for its lifetime
+        self.row, self.mode = row, mode
+        self._serial, self.version = bundle._serial, bundle.version
 
     count = property(lambda self: self.row[0])
     sum_w = property(lambda self: self.row[7])
@@ -51,7 +53,8 @@ class BundleAnalysis:
         return lo > self.kink_below and hi < self.kink_above
 
     def matches(self, bundle, detector_key=None):
-        return self.bundle is bundle and self.version == bundle.version and (detector_key is None or detector_key == self.key())
+        return (self._serial == bundle._serial and self.version == bundle.version
+                and (detector_key is None or detector_key == self.key()))
 
     def key(self):
         return (self.row[10:13].tobytes(), self.row[13:16].tobytes())

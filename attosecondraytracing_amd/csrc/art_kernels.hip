@@ -229,6 +229,9 @@ __device__ __forceinline__ void store_ray(const ArtBundleView& v, int64_t i, con
 // nothing.  The values of a dead slot are unspecified by contract (possibly NaN): they are dropped by the select, never
 // multiplied by 0.  The fold ORDER is unchanged: lane t of workgroup b still folds slots b*256 + t + k*stride for
 // k = 0, 1, ... one after the other, so the results are the bits they were.
+// MASKED bundles (a third of C3's slots are dead, in one contiguous range): these loops read the dead slots' streams too.
+// The two kernels of the loop-list analysis, where that matters (k_analysis_sums, k_analysis_moments), request a slot's
+// data at an out-of-range buffer offset when it is dead -- no traffic -- with the alive byte fetched one slot ahead.
 // (the pointer is stated to be GLOBAL memory: one that was itself fetched from a table in memory -- a job's bundle view --
 // would otherwise be a generic pointer and compile to flat_load, which also occupies the LDS counter)
 template <typename T>
@@ -242,7 +245,6 @@ __device__ __forceinline__ void st_nt(T* p, const T v) {
   __builtin_nontemporal_store(v, (gptr_t)p);
 }
 constexpr int kRedUnroll = 4;
-
 // ------------------------------------------------------------------------------------------- reductions
 // Deterministic: fixed grid, each lane accumulates its grid-stride slice, wave shuffle tree, LDS across the
 // 4 waves, one partial per workgroup into `scratch`, then fold_slot(): one workgroup per statistic folds the
@@ -1387,9 +1389,10 @@ struct SlotBatch {
   double w[kU];
   bool live[kU];
 };
+// every stream of the batch, unconditionally (a lane beyond the end re-reads slot n - 1 and is dead)
 template <int kU, bool HAS_W>
-__device__ __forceinline__ void load_batch(const ArtBundleView& b, const double* w, const int64_t i0, const int64_t stride,
-                                           const int64_t n, SlotBatch<kU>& q) {
+__device__ __forceinline__ void load_batch_all(const ArtBundleView& b, const double* w, const int64_t i0, const int64_t stride,
+                                               const int64_t n, SlotBatch<kU>& q) {
   const int64_t last = n - 1;
 #pragma unroll
   for (int u = 0; u < kU; ++u) {
@@ -1401,7 +1404,6 @@ __device__ __forceinline__ void load_batch(const ArtBundleView& b, const double*
     q.w[u] = HAS_W ? ld_nt(w + c) : 1.0;
   }
 }
-
 template <bool HAS_W>
 __global__ __launch_bounds__(kBlock) void k_scan_moments_partial(const ArtDetectorDesc d, const ArtBundleView b,
                                                                  const double* w, const int64_t n, const double co,
@@ -1413,7 +1415,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_moments_partial(const ArtDetect
   constexpr int kU = 1;     // (two slots per iteration need 148 VGPRs = 3 waves per SIMD: 0.65 of peak; one: 4 waves)
   for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < n; i0 += kU * stride) {
     SlotBatch<kU> q;
-    load_batch<kU, HAS_W>(b, w, i0, stride, n, q);
+    load_batch_all<kU, HAS_W>(b, w, i0, stride, n, q);
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       const bool l = q.live[u];
@@ -1649,14 +1651,17 @@ __global__ __launch_bounds__(kBlock) void k_analysis_sums(const ArtAnalysisJob* 
   __shared__ __attribute__((aligned(16))) double s_tile[(kBlock / 64) * 8 * kTileStride];
   __shared__ double s_run[(kBlock / 64) * kSumRows];
   const unsigned t = threadIdx.x;
-  const int64_t i = (int64_t)blockIdx.x * kBlock + t, c = i < n ? i : n - 1;
-  const ArtBundleView& b = jb.b;
-  const bool live = (ld_nt(b.alive + c) != 0) & (i < n);
+  // buffer descriptors (n <= 2^28, checked by the host): slots beyond the end read alive = 0, and a dead slot's data is
+  // requested at an out-of-range offset, i.e. not at all (a workgroup of dead slots -- the shadow of a mask -- moves 256 bytes)
+  const unsigned i = blockIdx.x * kBlock + t;
+  const BundleRsrc rb = make_rsrc(jb.b, n);
+  const bool live = __builtin_amdgcn_raw_buffer_load_b8(rb.alive, (int)i, 0, ART_LD_AUX) != 0;
+  const unsigned o8 = live ? i * 8u : kDropOffset;
   art::Ray r;
-  r.ox = ld_nt(b.ox + c); r.oy = ld_nt(b.oy + c); r.oz = ld_nt(b.oz + c);
-  r.dx = ld_nt(b.dx + c); r.dy = ld_nt(b.dy + c); r.dz = ld_nt(b.dz + c);
-  r.path = ld_nt(b.path + c);
-  const double w = jb.w ? ld_nt(jb.w + c) : 1.0;
+  r.ox = ld_f64(rb.ox, o8); r.oy = ld_f64(rb.oy, o8); r.oz = ld_f64(rb.oz, o8);
+  r.dx = ld_f64(rb.dx, o8); r.dy = ld_f64(rb.dy, o8); r.dz = ld_f64(rb.dz, o8);
+  r.path = ld_f64(rb.path, o8);
+  const double w = jb.w ? ld_f64(rsrc_of(const_cast<double*>(jb.w), (unsigned)(n * 8)), o8) : 1.0;
   double v[8];
   sums_values(v, live, r, w);
   const double tot = run_sums8(v, s_tile + (t >> 6) * (8 * kTileStride), t & 63);
@@ -1738,12 +1743,17 @@ __device__ __forceinline__ void moments_body(const ArtAnalysisJob& jb, const int
   const __amdgpu_buffer_rsrc_t rw = rsrc_of(const_cast<double*>(w), HAS_W ? (unsigned)(n * 8) : 0u);
   const unsigned ustride = (unsigned)stride, un_ = (unsigned)n;
   int cnt = 0;
-  for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < un_; i += ustride) {
-    const double cox = ld_f64(rb.ox, i * 8u), coy = ld_f64(rb.oy, i * 8u), coz = ld_f64(rb.oz, i * 8u);
-    const double cdx = ld_f64(rb.dx, i * 8u), cdy = ld_f64(rb.dy, i * 8u), cdz = ld_f64(rb.dz, i * 8u);
-    const bool l = __builtin_amdgcn_raw_buffer_load_b8(rb.alive, (int)i, 0, ART_LD_AUX) != 0;
-    const double pth = ld_f64(rb.path, i * 8u);
-    const double wv = HAS_W ? ld_f64(rw, i * 8u) : 1.0;
+  unsigned i = blockIdx.x * kBlock + threadIdx.x;
+  bool l = __builtin_amdgcn_raw_buffer_load_b8(rb.alive, (int)i, 0, ART_LD_AUX) != 0;
+  for (; i < un_; i += ustride) {
+    // the data of an ALIVE slot only (a dead one is requested out of range: no traffic; its fields read 0 and are selected
+    // away below), and the NEXT slot's alive byte in flight behind it
+    const unsigned o8 = l ? i * 8u : kDropOffset;
+    const unsigned char nl_raw = __builtin_amdgcn_raw_buffer_load_b8(rb.alive, (int)(i + ustride), 0, ART_LD_AUX);
+    const double cox = ld_f64(rb.ox, o8), coy = ld_f64(rb.oy, o8), coz = ld_f64(rb.oz, o8);
+    const double cdx = ld_f64(rb.dx, o8), cdy = ld_f64(rb.dy, o8), cdz = ld_f64(rb.dz, o8);
+    const double pth = ld_f64(rb.path, o8);
+    const double wv = HAS_W ? ld_f64(rw, o8) : 1.0;
     art::Ray r;
     r.ox = cox; r.oy = coy; r.oz = coz; r.dx = cdx; r.dy = cdy; r.dz = cdz; r.path = pth; r.inc = 0.0;
     double q0[3], sq[3], sk, un;
@@ -1772,6 +1782,7 @@ __device__ __forceinline__ void moments_body(const ArtAnalysisJob& jb, const int
       acc[16 + o + 2] = fma(wq, a0, acc[16 + o + 2]); acc[16 + o + 3] = fma(wq, s0, acc[16 + o + 3]);
       acc[16 + o + 4] = fma(ws, s0, acc[16 + o + 4]);
     }
+    l = nl_raw != 0;
   }
   acc[0] = (double)cnt;      // (a lane folds < 2^31 slots: the integer count is exact, as the sum of 1.0s was)
 }

@@ -84,18 +84,25 @@ for rep in range(passes):
 # The same workflow as a program runs it: NO synchronisation between the phases (construction, trace and analysis queue up
 # behind each other on the device while the host goes on; the one wait is the analysis' copy of its 64 doubles per chain).
 # The phase times above each end in a torch.cuda.synchronize(): their sum counts device work the host does not wait for.
-whole = []
+whole, marks = [], []
 for rep in range(max(passes, 5)):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     chains = mp.OEPlacement(source, [mask, toroid, toroid], [500, 100, 600], [0, 80, -80], [0, 0, np.linspace(-90, 90, 10)], "C3")
+    t1 = time.perf_counter()
     if batched:
         moc.trace_chain_list(chains, **kw)
     else:
         for ch in chains:
             ch.get_output_rays()
+    t2 = time.perf_counter()
     res = analyse(chains)
+    t3 = time.perf_counter()
     torch.cuda.synchronize()
     whole.append(1e3 * (time.perf_counter() - t0))
+    marks.append((1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2)))
     del chains, res
 print("whole workflow, one synchronisation at the end: " + " ".join(f"{t:.2f}" for t in whole) + f" ms; median {np.median(whole):.2f} ms", flush=True)
+m = np.median(np.array(marks), axis=0)
+print(f"   host time until each phase RETURNS (no synchronisation; the analysis waits for its result): construction {m[0]:.2f} ms, "
+      f"trace enqueue {m[1]:.2f} ms, analysis {m[2]:.2f} ms", flush=True)
