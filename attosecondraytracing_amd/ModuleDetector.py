@@ -63,9 +63,10 @@ class Detector:
 
     # ------------------------------------------------------------------ placement
     def copy_detector(self):
-        d = Detector(self.refpoint, self.centre, self.normal)
-        if self._normal is not None:
-            d._normal = self._normal      # (bit for bit: the setter's renormalisation may move the last bit)
+        # the three vectors were validated when this detector got them (and the normal normalised: used bit for bit -- the
+        # setter's renormalisation could move its last bit); like the reference's copy, the new detector REFERS to them
+        d = Detector.__new__(Detector)
+        d._centre, d._normal, d._refpoint = self._centre, self._normal, self._refpoint
         d._analysis = getattr(self, "_analysis", None)
         return d
 

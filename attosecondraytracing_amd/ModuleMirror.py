@@ -49,8 +49,11 @@ class _Mirror:
         hit = ReflectionMirrorRayList(self, [Ray], IgnoreDefects=True)
         return hit[0].point if len(hit) == 1 else None
 
-    def __hash__(self):
+    def _content_hash(self):
         return hash((self.type, hash(self.support)) + tuple(float(v) for v in self._abi_params()))
+
+    def __hash__(self):
+        return mgeo.memo_hash(self, self._content_hash)      # (recomputed from the contents, once per hash epoch)
 
     _cloud_has_outline = True      # the point cloud of get_grid3D starts with the outline of the support
 

@@ -484,7 +484,15 @@ def _placement_source(SourceProperties, FirstOptic):
     else:
         SourceRayList = msource.ExtendedSource(SourcePosition, SourceDirection, SourceSize, Divergence, RayNumber,
                                                Wavelength=Wavelength)
-    return msource.ApplyGaussianIntensityToRayList(SourceRayList, 1 / np.e ** 2)
+    Source = msource.ApplyGaussianIntensityToRayList(SourceRayList, 1 / np.e ** 2)
+    # The analysis of whatever is traced from this source needs its sum of intensities (the transmission's denominator,
+    # ART/ModuleAnalysisAndPlots.py:62-77): formed HERE, while the device has nothing else to do (the placement that follows
+    # is host arithmetic), and carried by the bundle like the sums a tracing launch forms (bundle.fused_sums) -- so the
+    # analysis of a loop list does not spend a pass over the source on its critical path.
+    be = Source.backend
+    if hasattr(be, "bundle_sums9") and Source.n_slots > 0:
+        _attach_sums(Source, {"sums_dev": be.bundle_sums9(Source)})
+    return Source
 
 
 def _placeChains(SourceProperties, OpticsList, variants, Description):

@@ -86,8 +86,12 @@ def ApplyGaussianIntensityToRayList(RayList, IntensityFraction=1 / np.e ** 2):
     from . import ModuleProcessing as mp
     B = RayList if isinstance(RayList, RayBundle) else RayBundle.from_ray_list(RayList)
     before = B.content_key()
-    axis = mp.FindCentralRay(B).vector
-    B.intensity = B.backend.gaussian_intensity(B.view(), axis, IntensityFraction, B.n_slots)
+    if hasattr(B.backend, "gaussian_intensity_central") and B.n_slots > 0:
+        # the axis (FindCentralRay's mean vector) is formed on the device from the bundle's sums: no host round trip
+        B.intensity = B.backend.gaussian_intensity_central(B.view(), IntensityFraction, B.n_slots)
+    else:
+        axis = mp.FindCentralRay(B).vector
+        B.intensity = B.backend.gaussian_intensity(B.view(), axis, IntensityFraction, B.n_slots)
     B.touch()
     if before[0] != "bundle":       # weights of a tagged bundle are a pure function of its tag and the fraction
         B.tag_content((before, "gaussian intensity", float(IntensityFraction)))

@@ -27,8 +27,11 @@ class Support(ABC):
     def _abi_params(self):
         """Up to six doubles, layout documented in include/art_hip.h (enum ArtSupportKind)."""
 
-    def __hash__(self):
+    def _content_hash(self):
         return hash((type(self).__name__,) + tuple(float(v) for v in self._abi_params()))
+
+    def __hash__(self):
+        return mgeo.memo_hash(self, self._content_hash)      # (recomputed from the contents, once per hash epoch)
 
     def _ContourSupport(self, Figure):
         """Outline of the support (and of its hole) on a new equal-aspect axes of `Figure`; used by MirrorProjection

@@ -137,6 +137,8 @@ PROTOTYPES = {
                                   C.c_void_p]),
     "art_gaussian_intensity": (C.c_int, [C.POINTER(ArtBundleView), c_double_p, C.c_double, C.c_int64, C.c_void_p,
                                          C.c_void_p, C.c_void_p]),
+    "art_gaussian_intensity_central": (C.c_int, [C.POINTER(ArtBundleView), C.c_double, C.c_int64, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p]),
     "art_bundle_max_angle": (C.c_int, [C.POINTER(ArtBundleView), c_double_p, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
     "art_compact_scratch_ints": (C.c_int64, [C.c_int64]),

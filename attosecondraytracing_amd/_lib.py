@@ -327,6 +327,16 @@ class HipBackend:
                    "art_gaussian_intensity")
         return w
 
+    def gaussian_intensity_central(self, view, fraction, n):
+        """Gaussian weights about the bundle's own central ray, axis formed on the device (art_gaussian_intensity_central);
+        nothing returns to the host."""
+        w = self.empty(n)
+        sums8 = self.empty(8)
+        self.check(self.fn["art_gaussian_intensity_central"](C.byref(view), float(fraction), n, self._red_scratch().data_ptr(),
+                                                             sums8.data_ptr(), w.data_ptr(), self.stream_ptr()),
+                   "art_gaussian_intensity_central")
+        return w
+
     def bundle_max_angle(self, view, axis, n):
         """(largest angle to `axis`, largest |point|) over the alive rays; host floats."""
         if n == 0:
@@ -433,6 +443,16 @@ class HipBackend:
         self.check(self.fn["art_analyse_bundles"](dev.data_ptr(), arr, c, int(n), scratch.data_ptr(), out.data_ptr(),
                                                   self.stream_ptr()), "art_analyse_bundles")
         return out
+
+    def bundle_sums9(self, bundle):
+        """DEVICE tensor [64] whose first nine doubles are the analysis sums of `bundle` (count, sum point, sum vector, sum
+        intensity, sum path: art_analyse_bundles with ONE job of mode ART_JOB_SUMS -- the canonical fold order, the same
+        bits as the analysis' own pass or the tail of a tracing launch); nothing is read back."""
+        j = _abi.ArtAnalysisJob()
+        j.b = bundle.view()
+        j.w = None if bundle.intensity is None else bundle.intensity.data_ptr()
+        j.mode = _abi.ART_JOB_SUMS
+        return self.analyse_bundles([j], bundle.n_slots)[0]
 
     def make_extended_source(self, radius, divergence, n_points, per, rot, S, first, n, view):
         r = (C.c_double * 9)(*[float(v) for v in np.asarray(rot).reshape(9)])

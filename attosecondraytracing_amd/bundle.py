@@ -386,6 +386,9 @@ class RayBundle:
         hit = getattr(self, "_sum_w", None)
         if hit is not None and hit[0] == self.version:
             out._sum_w = (out.version, hit[1])
+        fs = self._fused_sums
+        if fs is not None and fs[0] == self.version:       # the same arrays, the same weights: the same sums
+            out._fused_sums = (out.version, fs[1], fs[2])
         return out
 
     def __deepcopy__(self, memo):

@@ -1543,8 +1543,20 @@ __device__ __forceinline__ double tan2_half_angle_to_axis(const Axis3 ax, const 
   return art::dot3(ax_, ay_, az_, ax_, ay_, az_) * art::rcp_full(art::dot3(bx_, by_, bz_, bx_, by_, bz_));
 }
 
-__global__ __launch_bounds__(kBlock) void k_gauss_max_partial(const ArtBundleView b, const Axis3 ax, const int64_t n,
-                                                              double* scratch) {
+// `axis_sums` (or NULL): DEVICE, the 8 sums of art_bundle_sums -- the axis is then the bundle's own central ray, mean vector
+// normalised (FindCentralRay + the Ray.vector setter, ART/ModuleProcessing.py:464-482, ART/ModuleOpticalRay.py:85-90), formed
+// here instead of on the host: no round trip between the sums and the weights
+__device__ __forceinline__ Axis3 axis_of(const Axis3 given, const double* axis_sums) {
+  if (axis_sums == nullptr) return given;
+  const double c = axis_sums[0];
+  const double x = axis_sums[4] / c, y = axis_sums[5] / c, z = axis_sums[6] / c;
+  const double nrm = sqrt(art::dot3(x, y, z, x, y, z));
+  return Axis3{x / nrm, y / nrm, z / nrm};
+}
+
+__global__ __launch_bounds__(kBlock) void k_gauss_max_partial(const ArtBundleView b, const Axis3 ax_in, const double* axis_sums,
+                                                              const int64_t n, double* scratch) {
+  const Axis3 ax = axis_of(ax_in, axis_sums);
   const int ops[kSumSlots] = {RMAX, RMAX, RSUM, RSUM, RSUM, RSUM, RSUM, RSUM};
   double acc[kSumSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
   const int64_t stride = (int64_t)gridDim.x * kBlock, last = n - 1;
@@ -1582,8 +1594,9 @@ __global__ __launch_bounds__(kBlock) void k_gauss_max_final(const double* scratc
   block_reduce_store<kSumSlots>(acc, ops, out);
 }
 
-__global__ __launch_bounds__(kBlock) void k_gauss_weights(const ArtBundleView b, const Axis3 ax, const double kexp,
-                                                          const double* maxima, const int64_t n, double* w) {
+__global__ __launch_bounds__(kBlock) void k_gauss_weights(const ArtBundleView b, const Axis3 ax_in, const double* axis_sums,
+                                                          const double kexp, const double* maxima, const int64_t n, double* w) {
+  const Axis3 ax = axis_of(ax_in, axis_sums);
   const double div = maxima[0], maxdist = maxima[1];
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
@@ -1644,9 +1657,12 @@ __device__ __forceinline__ int ana_mom_slot(const int q) { // where partial q la
 
 // Pass (1) for the jobs that do not bring their sums along (ArtAnalysisJob.sums): one workgroup per tile of 256 slots, one
 // ray per lane, the canonical order of run_sums8.  rows: [job][kSumRows][ntiles] (+ the chunk totals of a two-stage fold).
-__global__ __launch_bounds__(kBlock) void k_analysis_sums(const ArtAnalysisJob* __restrict__ jobs, const int64_t n,
-                                                          double* rows, const int64_t job_stride) {
-  const ArtAnalysisJob& jb = jobs[blockIdx.y];
+// (launched per RUN of consecutive jobs that need it -- job = job0 + blockIdx.y: a grid over all jobs would dispatch 39 063
+// workgroups per 1e7-ray job only to let them return)
+__global__ __launch_bounds__(kBlock) void k_analysis_sums(const ArtAnalysisJob* __restrict__ jobs, const int job0,
+                                                          const int64_t n, double* rows, const int64_t job_stride) {
+  const int job = job0 + (int)blockIdx.y;
+  const ArtAnalysisJob& jb = jobs[job];
   if (jb.sums != nullptr) return;      // (workgroup-uniform) formed by the tracing launch already
   __shared__ __attribute__((aligned(16))) double s_tile[(kBlock / 64) * 8 * kTileStride];
   __shared__ double s_run[(kBlock / 64) * kSumRows];
@@ -1665,14 +1681,16 @@ __global__ __launch_bounds__(kBlock) void k_analysis_sums(const ArtAnalysisJob* 
   double v[8];
   sums_values(v, live, r, w);
   const double tot = run_sums8(v, s_tile + (t >> 6) * (8 * kTileStride), t & 63);
-  tile_sums_store(tot, __ballot(live), s_run, t, rows + (int64_t)blockIdx.y * job_stride, gridDim.x, blockIdx.x);
+  tile_sums_store(tot, __ballot(live), s_run, t, rows + (int64_t)job * job_stride, gridDim.x, blockIdx.x);
 }
 // grids (kSumRows, kFoldChunks, jobs) and (kSumRows, 1, jobs): the folds of launch_sums_fold_*, or a copy of the sums a job
 // brought along
-__global__ __launch_bounds__(kFoldBlock) void k_analysis_sums_fold1(const ArtAnalysisJob* __restrict__ jobs, double* rows,
-                                                                    const int64_t job_stride, const int64_t ntiles) {
-  if (jobs[blockIdx.z].sums != nullptr) return;
-  sums_fold1(rows + (int64_t)blockIdx.z * job_stride, ntiles);
+__global__ __launch_bounds__(kFoldBlock) void k_analysis_sums_fold1(const ArtAnalysisJob* __restrict__ jobs, const int job0,
+                                                                    double* rows, const int64_t job_stride,
+                                                                    const int64_t ntiles) {
+  const int job = job0 + (int)blockIdx.z;
+  if (jobs[job].sums != nullptr) return;
+  sums_fold1(rows + (int64_t)job * job_stride, ntiles);
 }
 __global__ __launch_bounds__(kFoldBlock) void k_analysis_sums_fold2(const ArtAnalysisJob* __restrict__ jobs, double* rows,
                                                                     const int64_t job_stride, const int64_t ntiles,
@@ -2621,8 +2639,27 @@ int art_bundle_sums(const ArtBundleView* bv, const double* w, int64_t n, double*
   return ART_OK;
 }
 
+static int gaussian_impl(const ArtBundleView* bv, const double axis[3], const double* axis_sums, double fraction, int64_t n,
+                         double* scratch, double* w_out, void* stream);
+
 int art_gaussian_intensity(const ArtBundleView* bv, const double axis[3], double fraction, int64_t n, double* scratch,
                            double* w_out, void* stream) {
+  if (!axis) return fail(ART_ERR_BAD_ARG, "NULL argument");
+  return gaussian_impl(bv, axis, nullptr, fraction, n, scratch, w_out, stream);
+}
+
+int art_gaussian_intensity_central(const ArtBundleView* bv, double fraction, int64_t n, double* scratch, double* sums8,
+                                   double* w_out, void* stream) {
+  if (!view_ok(bv) || !scratch || !sums8 || !w_out) return fail(ART_ERR_BAD_ARG, "NULL argument");
+  if (n <= 0) return (n == 0) ? ART_OK : fail(ART_ERR_BAD_ARG, "negative ray count");
+  const int rc = art_bundle_sums(bv, nullptr, n, scratch, sums8, stream);       // the central ray's sums, left on the device
+  if (rc) return rc;
+  const double none[3] = {0.0, 0.0, 0.0};
+  return gaussian_impl(bv, none, sums8, fraction, n, scratch, w_out, stream);
+}
+
+static int gaussian_impl(const ArtBundleView* bv, const double axis[3], const double* axis_sums, double fraction, int64_t n,
+                         double* scratch, double* w_out, void* stream) {
   if (!view_ok(bv) || !axis || !scratch || !w_out) return fail(ART_ERR_BAD_ARG, "NULL argument");
   if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
   if (!(fraction > 0.0 && fraction < 1.0)) return fail(ART_ERR_BAD_ARG, "fraction must be in (0, 1)");
@@ -2633,9 +2670,9 @@ int art_gaussian_intensity(const ArtBundleView* bv, const double axis[3], double
   const Axis3 ax = {axis[0], axis[1], axis[2]};
   // partials in scratch[0 .. nb*8), the two maxima right behind them
   double* maxima = scratch + (int64_t)kRedBlocks * kSumSlots;
-  hipLaunchKernelGGL(k_gauss_max_partial, dim3(nb), dim3(kBlock), 0, s, *bv, ax, n, scratch);
+  hipLaunchKernelGGL(k_gauss_max_partial, dim3(nb), dim3(kBlock), 0, s, *bv, ax, axis_sums, n, scratch);
   hipLaunchKernelGGL(k_gauss_max_final, dim3(1), dim3(kBlock), 0, s, scratch, nb, maxima);
-  hipLaunchKernelGGL(k_gauss_weights, dim3(grid_for(n)), dim3(kBlock), 0, s, *bv, ax, -0.5 * log(fraction), maxima, n,
+  hipLaunchKernelGGL(k_gauss_weights, dim3(grid_for(n)), dim3(kBlock), 0, s, *bv, ax, axis_sums, -0.5 * log(fraction), maxima, n,
                      w_out);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_gaussian_intensity launch");
@@ -2657,7 +2694,7 @@ int art_bundle_max_angle(const ArtBundleView* bv, const double axis[3], int64_t 
   const int nb = (int)(b > kRedBlocks ? kRedBlocks : b);
   const Axis3 ax = {axis[0], axis[1], axis[2]};
   double* tmp = scratch + (int64_t)kRedBlocks * kSumSlots;   // 8 doubles: the folded partials
-  hipLaunchKernelGGL(k_gauss_max_partial, dim3(nb), dim3(kBlock), 0, s, *bv, ax, n, scratch);
+  hipLaunchKernelGGL(k_gauss_max_partial, dim3(nb), dim3(kBlock), 0, s, *bv, ax, (const double*)nullptr, n, scratch);
   hipLaunchKernelGGL(k_gauss_max_final, dim3(1), dim3(kBlock), 0, s, scratch, nb, tmp);
   hipError_t e1 = hipMemcpyAsync(out2, tmp, 2 * sizeof(double), hipMemcpyDeviceToDevice, s);
   if (e1 != hipSuccess) return fail_hip(e1, "hipMemcpyAsync");
@@ -2851,9 +2888,16 @@ int art_analyse_bundles(const ArtAnalysisJob* jobs_dev, const ArtAnalysisJob* jo
   double* place = mom + (int64_t)n_jobs * P * kAnaMom;
   const int direct = ntiles <= kFoldDirect;
   if (!all_given && n > 0) {
-    hipLaunchKernelGGL(k_analysis_sums, dim3((unsigned)ntiles, n_jobs), dim3(kBlock), 0, s, jobs_dev, n, rows, rstride);
-    if (!direct)
-      hipLaunchKernelGGL(k_analysis_sums_fold1, dim3(kSumRows, kFoldChunks, n_jobs), dim3(kFoldBlock), 0, s, jobs_dev, rows, rstride, ntiles);
+    for (int j0 = 0; j0 < n_jobs;) {       // one launch per run of consecutive jobs without sums of their own
+      if (jobs_host[j0].sums != nullptr) { ++j0; continue; }
+      int j1 = j0;
+      while (j1 < n_jobs && jobs_host[j1].sums == nullptr) ++j1;
+      hipLaunchKernelGGL(k_analysis_sums, dim3((unsigned)ntiles, j1 - j0), dim3(kBlock), 0, s, jobs_dev, j0, n, rows, rstride);
+      if (!direct)
+        hipLaunchKernelGGL(k_analysis_sums_fold1, dim3(kSumRows, kFoldChunks, j1 - j0), dim3(kFoldBlock), 0, s, jobs_dev, j0, rows,
+                           rstride, ntiles);
+      j0 = j1;
+    }
   }
   // (n == 0: no tiles were written; a fold over zero tiles leaves the sums' identities -- all zero)
   hipLaunchKernelGGL(k_analysis_sums_fold2, dim3(kSumRows, 1, n_jobs), dim3(direct ? fold_threads(n > 0 ? ntiles : 0) : kBlock), 0, s,

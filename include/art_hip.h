@@ -298,6 +298,12 @@ int art_bundle_sums(const ArtBundleView* b, const double* w, int64_t n, double* 
  * Two passes on the stream (max reduction, then weights); nothing returns to the host.  w_out: DEVICE, n doubles. */
 int art_gaussian_intensity(const ArtBundleView* b, const double axis[3], double fraction, int64_t n,
                            double* scratch, double* w_out, void* stream);
+/* The same about the bundle's OWN central ray (what ApplyGaussianIntensityToRayList passes: FindCentralRay's mean vector,
+ * normalised by the Ray.vector setter, ART/ModuleProcessing.py:464-482): art_bundle_sums into `sums8` (DEVICE, 8 doubles,
+ * left there for the caller), then the axis is formed ON THE DEVICE from those sums -- four launches, no host round trip
+ * between the central ray and the weights (0.2 ms of waiting at the start of every OEPlacement).                          */
+int art_gaussian_intensity_central(const ArtBundleView* b, double fraction, int64_t n, double* scratch, double* sums8,
+                                   double* w_out, void* stream);
 
 /* Largest angle between `axis` and the direction of any alive ray, and largest |point| (ReturnNumericalAperture,
  * ART/ModuleProcessing.py:536-566; also the first pass of art_gaussian_intensity).  out2: DEVICE, 2 doubles.          */

@@ -284,3 +284,18 @@ def test_gpu_specialised_one_element_defect_chain(hip, monkeypatch):
             assert torch.equal(_bits(g[4]), _bits(s_[4])) and torch.equal(_bits(g[6]), _bits(s_[6])) and torch.equal(_bits(g[7]), _bits(s_[7]))
         # the scene launch equals the by-value launch
         assert torch.equal(_bits(got["general"][1][:, live]), _bits(got["general"][5][:, live]))
+
+
+def test_gpu_gaussian_weights_about_the_device_side_central_ray(hip):
+    """art_gaussian_intensity_central forms the axis (FindCentralRay's mean vector, normalised) on the device: the weights equal
+    the host-axis call's to rounding, for a diverging and a collimated source."""
+    import bench
+    import ART.ModuleProcessing as mp
+    for kind in (("point", 0.03), ("plane", 12.0)):
+        n = 300_001
+        src = bench.device_source(n, 0, n, hip, kind)
+        axis = mp.FindCentralRay(src).vector
+        ref = hip.gaussian_intensity(src.view(), axis, 1 / np.e ** 2, n)
+        got = hip.gaussian_intensity_central(src.view(), 1 / np.e ** 2, n)
+        assert float((got - ref).abs().max()) <= 1e-13, kind
+        assert 0.13 < float(got.min()) < 0.14 and abs(float(got.max()) - 1.0) < 1e-9

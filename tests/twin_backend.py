@@ -422,6 +422,13 @@ class TwinBackend:
             num = number.numpy()[a] if number is not None else first + np.nonzero(a)[0] * step
             buf[16 + 24 * c:16 + 28 * c].view(np.int32)[:] = num.astype(np.int32)
 
+    def bundle_sums9(self, bundle):
+        j = _abi.ArtAnalysisJob()
+        j.b = bundle.view()
+        j.w = None if bundle.intensity is None else bundle.intensity.data_ptr()
+        j.mode = _abi.ART_JOB_SUMS
+        return self.analyse_bundles([j], bundle.n_slots)[0]
+
     def survivor_finish(self, stats_dev, n, send, xhdr=None):
         """art_survivor_finish: the header of a zero-copy send buffer (+ the rank's block of the header exchange)."""
         c = int(stats_dev[0].item())

@@ -21,6 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("rays", nargs="?", type=float, default=1e7)
     ap.add_argument("--masked", type=float, default=0.0)
+    ap.add_argument("--tail", type=float, default=0.0, help="the LAST fraction of the slots is dead (the shadow of C3's mask)")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--jobs", type=int, default=10)
     args = ap.parse_args()
@@ -44,6 +45,8 @@ def main():
     if args.masked > 0:
         k = torch.arange(n, device=be.device)
         b.alive[((k // 2) % 1000) < int(1000 * args.masked)] = 0
+    if args.tail > 0:
+        b.alive[int(n * (1.0 - args.tail)):] = 0
     live = int(b.alive.sum().item())
     det = mdet.Detector(np.zeros(3))
     det.autoplace(b, 100.0)
