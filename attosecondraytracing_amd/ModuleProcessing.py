@@ -448,10 +448,6 @@ def _RayTracingCalculationMany(source_rays_list, optical_elements_list, IgnoreDe
         ros = [be.new_chain_sums(s_.intensity, n, scratch=area) for s_, area in zip(sources, be.chain_readout_scratch(n, c))]
     host, dev = be.scene_alloc(c, m, transient=True)
     be.scene_pack(descs, [s.view() for s in sources], views, c, m, host, ros)
-    if hasattr(be, "scene_hint") and all(s._parent is not None or s._parent_resolver is not None for s in sources):
-        # every input is a TRACED bundle (the suffixes of a loop list start from their shared prefix's last bundle): it may
-        # hold ranges of dead slots -- the shadow of a mask -- whose data the launch need not read
-        be.scene_hint(host, _abi.ART_HINT_SPARSE_INPUT)
     be.scene_upload(host, dev)
     be.trace_scene(dev, host, n, segments=-(-m // 8))
     for ci, outs in enumerate(grid):

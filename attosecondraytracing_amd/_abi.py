@@ -84,7 +84,6 @@ class ArtChainReadout(C.Structure):
 
 ART_GUIDES_MAX = 8
 ART_XHDR_DOUBLES = 26
-ART_HINT_SPARSE_INPUT = 1
 ART_ANALYSIS_DOUBLES = 64
 ART_JOB_AUTOPLACE, ART_JOB_MANUAL, ART_JOB_SUMS = range(3)
 
@@ -119,7 +118,6 @@ PROTOTYPES = {
     "art_scene_pack": (C.c_int, [C.POINTER(ArtElementDesc), C.c_int32, C.c_int32, C.POINTER(ArtBundleView),
                                  C.POINTER(ArtBundleView), C.POINTER(ArtChainReadout), C.c_void_p]),
     "art_trace_scene": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
-    "art_scene_hint": (C.c_int, [C.c_void_p, C.c_int32]),
     "art_pack_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(ArtBundleView), C.c_void_p]),
     "art_transform_bundle": (C.c_int, [c_double_p, c_double_p, C.c_int32, C.POINTER(ArtBundleView),
                                        C.POINTER(ArtBundleView), C.c_int64, C.c_void_p]),

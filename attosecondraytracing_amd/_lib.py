@@ -224,10 +224,6 @@ class HipBackend:
             self.check(rc, "art_scene_pack")
         return rc
 
-    def scene_hint(self, host_image, hints):
-        """Launch hints of a packed scene (art_scene_hint), before it is uploaded."""
-        self.check(self.fn["art_scene_hint"](host_image.data_ptr(), int(hints)), "art_scene_hint")
-
     def scene_upload(self, host_image, dev_image):
         """Host image -> device image on the current stream; returns an event the host waits for before it re-packs."""
         dev_image.copy_(host_image, non_blocking=True)

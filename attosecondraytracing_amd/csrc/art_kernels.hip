@@ -189,25 +189,6 @@ __device__ __forceinline__ void load_slot_keep(const BundleRsrc& b, int64_t i, a
   r.dx = ld_f64_keep(b.dx, o8); r.dy = ld_f64_keep(b.dy, o8); r.dz = ld_f64_keep(b.dz, o8);
   r.path = ld_f64_keep(b.path, o8);
 }
-// The input of a launch that is known to hold DEAD slots (the bundle behind a mask: a third of C3's slots, in one contiguous
-// range): the alive byte first, then the seven streams of the alive slots only (a dead slot is requested out of range: no
-// traffic).  One more memory latency at the head of the kernel, before any store is in flight; worth it only where whole
-// cache lines are dead -- the launch says so (ART_HINT_SPARSE_INPUT), it is not the default.
-__device__ __forceinline__ void load_slot_sparse(const BundleRsrc& b, int64_t i, art::Ray& r, uint8_t& alive, const bool keep) {
-  const unsigned o1 = (unsigned)i;
-  alive = keep ? __builtin_amdgcn_raw_buffer_load_b8(b.alive, (int)o1, 0, 0)
-               : __builtin_amdgcn_raw_buffer_load_b8(b.alive, (int)o1, 0, ART_LD_AUX);
-  const unsigned o8 = alive ? o1 * 8u : kDropOffset;
-  if (keep) {
-    r.ox = ld_f64_keep(b.ox, o8); r.oy = ld_f64_keep(b.oy, o8); r.oz = ld_f64_keep(b.oz, o8);
-    r.dx = ld_f64_keep(b.dx, o8); r.dy = ld_f64_keep(b.dy, o8); r.dz = ld_f64_keep(b.dz, o8);
-    r.path = ld_f64_keep(b.path, o8);
-  } else {
-    r.ox = ld_f64(b.ox, o8); r.oy = ld_f64(b.oy, o8); r.oz = ld_f64(b.oz, o8);
-    r.dx = ld_f64(b.dx, o8); r.dy = ld_f64(b.dy, o8); r.dz = ld_f64(b.dz, o8);
-    r.path = ld_f64(b.path, o8);
-  }
-}
 __device__ __forceinline__ void store_slot(const BundleRsrc& b, int64_t i, const art::Ray& r, bool ok) {
   const unsigned o1 = (unsigned)i;
 #ifdef ART_DIAG_NOSTORE   // timing-only build: keep the compute, drop the 8 data stores (results are wrong)
@@ -729,8 +710,7 @@ __device__ __forceinline__ void store_tile_lds4(const ArtBundleView& v, const in
 // run-time switch on the kind, no element loop; ART_KIND_DYN: the general body.
 template <bool DEFECT, int KIND1 = ART_KIND_DYN>
 __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t first, const int64_t n, const int xmap,
-                                           double* s_zern, const unsigned bx, const unsigned nbx, const bool keep_in = false,
-                                           const bool sparse_in = false) {
+                                           double* s_zern, const unsigned bx, const unsigned nbx, const bool keep_in = false) {
 #ifdef ART_ZERN_LDS
   if (DEFECT) {
     int off = 0;
@@ -767,8 +747,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, const int64_t fir
     art::Ray r;
     r.inc = 0.0;
     uint8_t al;
-    if (sparse_in) load_slot_sparse(bi, i, r, al, keep_in);      // (wave-uniform: the launch's hints)
-    else if (keep_in) load_slot_keep(bi, i, r, al);              // (wave-uniform: the launch's grid shape)
+    if (keep_in) load_slot_keep(bi, i, r, al);      // (wave-uniform: the launch's grid shape)
     else load_slot(bi, i, r, al);
     // Weight of the fused read-out: fetched with the ray (a zero-length descriptor without read-out or weights) and
     // parked in LDS until the tail needs it -- held in registers across the chain it costs the 2 VGPRs that push the
@@ -1154,8 +1133,8 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain2(const ChainArgs,
 template <bool DEFECT, int WAVES>
 __global__ __launch_bounds__(kBlock, WAVES) void k_trace_scene2(const ChainArgs* __restrict__ tab, const int64_t first,
                                                                 const int64_t n, const int xmap, const int transposed) {
-  const unsigned bx = (transposed & 1) ? blockIdx.y : blockIdx.x, nbx = (transposed & 1) ? gridDim.y : gridDim.x;
-  chain_body2<DEFECT>(tab[(transposed & 1) ? blockIdx.x : blockIdx.y], first, n, xmap, bx, nbx, (transposed & 2) != 0);
+  const unsigned bx = transposed ? blockIdx.y : blockIdx.x, nbx = transposed ? gridDim.y : gridDim.x;
+  chain_body2<DEFECT>(tab[transposed ? blockIdx.x : blockIdx.y], first, n, xmap, bx, nbx, (transposed & 2) != 0);
 }
 
 // Many chains in one launch, descriptors in the device-resident scene table (art_scene.h).  Two grid shapes:
@@ -1168,10 +1147,8 @@ template <bool DEFECT, int WAVES>
 __global__ __launch_bounds__(kBlock, WAVES) void k_trace_scene(const ChainArgs* __restrict__ tab, const int64_t first,
                                                                const int64_t n, const int xmap, const int transposed) {
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-  // transposed: bit 0 = chain-interleaved grid, bit 1 = shared input with the default cache policy, bit 2 = sparse input
-  const unsigned bx = (transposed & 1) ? blockIdx.y : blockIdx.x, nbx = (transposed & 1) ? gridDim.y : gridDim.x;   // (ONE copy of the body)
-  chain_body<DEFECT>(tab[(transposed & 1) ? blockIdx.x : blockIdx.y], first, n, xmap, s_dyn, bx, nbx, (transposed & 2) != 0,
-                     (transposed & 4) != 0);
+  const unsigned bx = transposed ? blockIdx.y : blockIdx.x, nbx = transposed ? gridDim.y : gridDim.x;   // (ONE copy of the body)
+  chain_body<DEFECT>(tab[transposed ? blockIdx.x : blockIdx.y], first, n, xmap, s_dyn, bx, nbx, (transposed & 2) != 0);
 }
 
 // One-element chains WITH defects, the optic's kind a template parameter (round 5, C5: a deformed parabola + read-out).
@@ -1179,9 +1156,8 @@ template <int KIND1, int WAVES>
 __global__ __launch_bounds__(kBlock, WAVES) void k_trace_scene1(const ChainArgs* __restrict__ tab, const int64_t first,
                                                                 const int64_t n, const int xmap, const int transposed) {
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-  const unsigned bx = (transposed & 1) ? blockIdx.y : blockIdx.x, nbx = (transposed & 1) ? gridDim.y : gridDim.x;
-  chain_body<true, KIND1>(tab[(transposed & 1) ? blockIdx.x : blockIdx.y], first, n, xmap, s_dyn, bx, nbx, (transposed & 2) != 0,
-                          (transposed & 4) != 0);
+  const unsigned bx = transposed ? blockIdx.y : blockIdx.x, nbx = transposed ? gridDim.y : gridDim.x;
+  chain_body<true, KIND1>(tab[transposed ? blockIdx.x : blockIdx.y], first, n, xmap, s_dyn, bx, nbx, (transposed & 2) != 0);
 }
 template <int KIND1, int WAVES>
 __global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain1(const ChainArgs, const int64_t n, const int xmap) {
@@ -2436,17 +2412,6 @@ int art_scene_pack(const ArtElementDesc* elems, int32_t n_chains, int32_t n_elem
   return rc;
 }
 
-int art_scene_hint(void* image_host, int32_t hints) {
-  if (!image_host) return fail(ART_ERR_BAD_ARG, "scene image is NULL");
-  art::SceneHeader h;
-  memcpy(&h, image_host, sizeof(h));
-  if (h.magic != art::kSceneMagic) return fail(ART_ERR_BAD_ARG, "host image was not written by art_scene_pack");
-  if (hints & ~ART_HINT_SPARSE_INPUT) return fail(ART_ERR_BAD_ARG, "unknown hint");
-  h.flags = (h.flags & ~art::kFlagSparseIn) | ((hints & ART_HINT_SPARSE_INPUT) ? art::kFlagSparseIn : 0);
-  memcpy(image_host, &h, sizeof(h));
-  return ART_OK;
-}
-
 int art_trace_scene(const void* image_dev, const void* image_host, int64_t n, void* stream) {
   if (!image_dev || !image_host) return fail(ART_ERR_BAD_ARG, "scene image is NULL");
   // Counts and flags are read from the header art_scene_pack wrote, not taken from the caller: a read-out bit without
@@ -2457,7 +2422,7 @@ int art_trace_scene(const void* image_dev, const void* image_host, int64_t n, vo
   if (h.magic != art::kSceneMagic) return fail(ART_ERR_BAD_ARG, "host image was not written by art_scene_pack");
   const int32_t n_chains = h.n_chains, n_elems = h.n_elems, flags = h.flags;
   if (n_chains <= 0 || n_chains > 65535 || n_elems <= 0 || h.n_segments != art::scene_segments(n_elems) ||
-      (flags & ~(art::kFlagDefects | art::kFlagReadout | art::kFlagMask | art::kFlagSharedIn | art::kFlagSums | art::kFlagSparseIn)))
+      (flags & ~(art::kFlagDefects | art::kFlagReadout | art::kFlagMask | art::kFlagSharedIn | art::kFlagSums)))
     return fail(ART_ERR_BAD_ARG, "scene header is corrupt");
   if (n < 0) return fail(ART_ERR_BAD_ARG, "negative ray count");
 #ifdef ART_ZERN_LDS
@@ -2498,7 +2463,6 @@ int art_trace_scene(const void* image_dev, const void* image_host, int64_t n, vo
       int tr = (scene_order((flags & art::kFlagSharedIn) != 0 && sg == 0 && n_chains > 1) && tiles <= 65535) ? 1 : 0;
       if (tr && scene_keep(cnt)) tr |= 2;
       const dim3 g = tr ? dim3(n_chains, tiles) : dim3(tiles, n_chains), b(kBlock);
-      if ((flags & art::kFlagSparseIn) && sg == 0 && !two) tr |= 4;     // (the hint of art_scene_hint: the input holds dead ranges)
       if ((flags & 1) && special1 == 5)
         launch_scene1<5>(kind1, g, s, seg, off, cnt, xm, tr);
       else if ((flags & 1) && special1 == 4)

@@ -32,7 +32,6 @@ struct ChainArgs {
 constexpr int kFlagDefects = 1, kFlagReadout = 2;
 constexpr int kFlagMask = 4;     // scene header only: some chain contains a mask (selects the body of the launch)
 constexpr int kFlagSharedIn = 8; // scene header only: every chain reads the SAME input bundle (selects the grid shape)
-constexpr int kFlagSparseIn = 32; // scene header only (art_scene_hint): the chains' inputs hold ranges of dead slots (a bundle behind a mask)
 constexpr int kFlagSums = 16;    // scene header only: the tails form the analysis' sums (ArtChainReadout.sums), not a read-out
 
 inline bool readout_ok(const ArtChainReadout& r) {

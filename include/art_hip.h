@@ -222,12 +222,6 @@ int64_t art_scene_bytes(int32_t n_chains, int32_t n_elems);
 int art_scene_pack(const ArtElementDesc* elems, int32_t n_chains, int32_t n_elems, const ArtBundleView* ins,
                    const ArtBundleView* outs, const ArtChainReadout* readouts, void* image_host);
 int art_trace_scene(const void* image_dev, const void* image_host, int64_t n, void* stream);
-/* Launch hints, set in the HOST image's header after art_scene_pack (art_trace_scene reads them there; results never depend
- * on them).  ART_HINT_SPARSE_INPUT: the chains' input bundles hold whole ranges of dead slots -- the bundle behind a mask,
- * e.g. the suffixes of a loop list traced from their shared prefix's last bundle (a third of C3's slots): the kernels then
- * fetch the alive byte first and the seven streams of alive slots only, instead of reading dead slots' data.              */
-#define ART_HINT_SPARSE_INPUT 1
-int art_scene_hint(void* image_host, int32_t hints);
 
 /* Bundle from array-of-structs input (the layout a caller holding ART Ray lists / (n,3) NumPy arrays has):
  * points[n][3], vectors[n][3] (DEVICE, row-major) -> SoA view; directions normalised like the Ray.vector setter

@@ -299,34 +299,3 @@ def test_gpu_gaussian_weights_about_the_device_side_central_ray(hip):
         got = hip.gaussian_intensity_central(src.view(), 1 / np.e ** 2, n)
         assert float((got - ref).abs().max()) <= 1e-13, kind
         assert 0.13 < float(got.min()) < 0.14 and abs(float(got.max()) - 1.0) < 1e-9
-
-
-def test_gpu_sparse_input_hint_changes_nothing_but_the_traffic(hip):
-    """A scene whose inputs are traced bundles (the suffixes of a loop list behind their shared prefix) is launched with
-    ART_HINT_SPARSE_INPUT: alive byte first, data of alive slots only.  Same bundles, bit for bit, as without the hint."""
-    import torch
-    import bench
-    import ART.ModuleProcessing as mp
-    from attosecondraytracing_amd import _abi
-    element_lists, kind, _ = bench.scene_c3()
-    n = 300_007
-    src = bench.device_source(n, 0, n, hip, kind)
-    hinted = []
-    real = hip.scene_hint
-    hip.scene_hint = lambda host, h: (hinted.append(h), real(host, h))[1]
-    try:
-        with_hint = mp.RayTracingCalculationMany([src] * len(element_lists), element_lists)      # prefix shared: suffixes hinted
-    finally:
-        del hip.scene_hint
-    assert hinted == [_abi.ART_HINT_SPARSE_INPUT]
-    hip.scene_hint = lambda host, h: None
-    try:
-        without = mp.RayTracingCalculationMany([src] * len(element_lists), element_lists)
-    finally:
-        del hip.scene_hint
-    for a, b in zip(with_hint, without):
-        for x, y in zip(a, b):
-            assert torch.equal(x.alive, y.alive)
-            live = x.alive.bool()
-            assert torch.equal(_bits(x.data[:, live]), _bits(y.data[:, live]))
-    assert 0 < int(with_hint[3][-1].alive.sum()) < n

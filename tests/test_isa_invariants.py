@@ -100,9 +100,7 @@ def test_scene_descriptors_are_scalar_loads(kernels):
     # chain-interleaved launch), behind a wave-uniform branch
     code = kernels["k_trace_scene<false, 5>"]["code"]
     assert not [l for l in code if re.search(r"\b(global_load|flat_load)\b", l)]
-    # ... and, since round 5, two more copies of those 8 behind the SPARSE-INPUT hint (alive first, data of alive slots only;
-    # non-temporal and default policy): 9 + 8 + 16
-    assert sum("buffer_load" in l for l in code) == 33
+    assert sum("buffer_load" in l for l in code) == 17
     assert sum("buffer_load" in l for l in kernels["k_trace_chain<false, 5>"]["code"]) == 9
 
 
