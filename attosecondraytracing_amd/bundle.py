@@ -218,6 +218,18 @@ class RayBundle:
         v.alive = self.alive.data_ptr()
         return v
 
+    def slots(self, lo, hi):
+        """A bundle OBJECT over slots [lo, hi) of this one's arrays (no copy: the rows are unit-stride streams, a range of
+        slots is a range of every row).  For tiled launches: the tiles of one trace write disjoint ranges of the same
+        output bundles.  `lo` should be a multiple of 64 so that every row of the range starts on a 512-byte boundary."""
+        lo, hi = int(lo), int(hi)
+        cut = lambda t: None if t is None else t[lo:hi]
+        out = RayBundle(self.data[:, lo:hi], self.alive[lo:hi], cut(self.number), cut(self.intensity), self.wavelength, None,
+                        self._backend)
+        if self.number is None and lo != 0:
+            out.number = torch.arange(lo, hi, dtype=torch.int64, device=self.alive.device)     # slot i of the range is ray lo + i
+        return out
+
     # ------------------------------------------------------------------ content identity
     def tag_content(self, key):
         """Declare that this bundle's contents (ray state, numbers, intensities, wavelength) are a pure function of the

@@ -55,13 +55,14 @@ class SceneProgram:
 
     `readout_lite=True`: the fused read-outs reduce only count, sum of paths, bounding box and path range (ArtChainReadout.lite).
     `readout_targets`: per chain None or (X, Y, opl) tensors of the caller the fused read-out writes into.
+    `outputs`: [chain][element] bundles of the caller to trace into, instead of bundles of the program's own.
     `placement_tries` (default: ART_PLACEMENT_TRIES, else 1 = off): opt-in look at where the output bundles lie, see
     `_tune_placement` below.
 
     Results are bit-identical to `RayTracingCalculation`; the returned bundles are overwritten by the next `run()`."""
 
     def __init__(self, sources, element_lists, IgnoreDefects=True, post=None, capture=True, detectors=None, history=True,
-                 placement_tries=None, readout_lite=False, readout_targets=None):
+                 placement_tries=None, readout_lite=False, readout_targets=None, outputs=None):
         from . import ModuleProcessing as mp
         from . import _abi
         from .bundle import RayBundle
@@ -81,7 +82,9 @@ class SceneProgram:
             raise ValueError("SceneProgram(history=False) covers chains of at most 8 elements")
         self._history = bool(history)
         self._views_in = [s.view() for s in self.sources]
-        self._bind(self._alloc_outputs())
+        # outputs: [chain][element] bundles of the caller to trace into (None entries where history=False) instead of bundles
+        # of the program's own -- e.g. ranges (RayBundle.slots) of one set of bundles shared by the tiles of a tiled step
+        self._bind(outputs if outputs is not None else self._alloc_outputs())
         self._readout_lite = bool(readout_lite)
         # readout_targets: per chain None or (X, Y, opl) caller-owned tensors the fused read-out writes into -- e.g. the
         # dense sections of a survivor send buffer (sharding.SurvivorGather.acquire: zero-copy gather)

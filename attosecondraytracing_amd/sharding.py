@@ -298,10 +298,17 @@ class SurvivorGather:
     `host_syncs` counts the exceptions (first step, settled short steps).
 
     `start(b, ...)` enqueues a step, `settle(b)` / `drain()` complete it (them), `result(b)` -> per-rank list of (number
-    int64, X, Y, path) views on dst, `assemble(b)` -> the four arrays of the whole job in global ray order."""
+    int64, X, Y, path) views on dst, `assemble(b)` -> the four arrays of the whole job in global ray order.
+
+    TILES (`tiles=T` > 1, zero-copy shards): the caller traces its step as T launches over consecutive slot ranges
+    (`tile_range(t)`; bundle.RayBundle.slots, graph.SceneProgram(outputs=...)) and calls `start_tile(b, t)` behind each: the
+    records of tile t leave while tile t + 1 is traced, so the transfer of a step overlaps THAT step's trace, not only the
+    next one's (what matters for a single step: trace / T + transfer instead of trace + transfer).  Which ranks tile is
+    decided from the same headers as the sizes -- a rank that was dense two steps ago (`tiling(b)`), on every rank alike;
+    `start` then ships only what did not travel in tiles.  A tiled shard that did lose rays is short like any other."""
 
     def __init__(self, backend, n, world, rank, dst=0, buffers=2, specs=None, margin=1.0 / 16, slack=1024, predict=True,
-                 zero_copy=False):
+                 zero_copy=False, tiles=1):
         self.be, self.n, self.world, self.rank, self.dst = backend, int(n), int(world), int(rank), int(dst)
         # (first, step, n) of every rank's shard: for the implicit numbers of dense shards on the root
         self.specs = specs if specs is not None else [(0, 1, self.n)] * self.world
@@ -310,6 +317,9 @@ class SurvivorGather:
             raise ValueError("ray numbers up to %d do not fit the int32 of a survivor record" % top)
         dev = backend.device
         self.margin, self.slack, self.predict, self.zero_copy = float(margin), int(slack), bool(predict), bool(zero_copy)
+        self.n_tiles = max(1, int(tiles))
+        self._tiled = [frozenset()] * buffers       # ranks whose records of the step on set b travel tile by tile
+        self._tiles_started = [0] * buffers
         # capacity of every buffer: the longest shard with every slot alive and explicit numbers (28 B per ray)
         self.cap = backend.survivor_bytes(max([self.n] + [s[2] for s in self.specs]), False)
         self.send = [torch.empty(self.cap, dtype=torch.uint8, device=dev) for _ in range(buffers)]
@@ -346,6 +356,48 @@ class SurvivorGather:
         sec = self.send[b][16:16 + 24 * self.n].view(torch.float64).view(3, self.n)
         return sec[0], sec[1], sec[2]
 
+    # ---- tiles ---------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _tile_range(n, t, T):
+        per = -(-n // T)
+        per = -(-per // 64) * 64                  # every tile starts on a 512-byte boundary of every row
+        return min(n, t * per), min(n, (t + 1) * per)
+
+    def tile_range(self, t):
+        """Slots [lo, hi) of this rank's tile t."""
+        return self._tile_range(self.n, t, self.n_tiles)
+
+    def _tiling_ranks(self):
+        if self.n_tiles <= 1 or not self.predict or self._known is None:
+            return frozenset()
+        return frozenset(r for r, (c, f) in enumerate(self._known) if (f & 1) and c == self.specs[r][2])
+
+    def tiling(self, b):
+        """After acquire(b): does THIS rank send the step on set b tile by tile (it was dense two steps ago)?"""
+        return self.zero_copy and self.rank in self._tiled[b]
+
+    def start_tile(self, b, t):
+        """Tile t of the step on set b has been traced (its read-out wrote slots tile_range(t) of the zero-copy sections on
+        the caller's stream): its records leave now -- three ranges (X, Y, path) per tiling peer into the root."""
+        assert t == self._tiles_started[b], "tiles are started in order, each once"
+        self._tiles_started[b] = t + 1
+        if not self._dist() or self.world == 1:
+            return
+        ops = []
+        for r in (sorted(self._tiled[b]) if self.rank == self.dst else ([self.rank] if self.rank in self._tiled[b] else [])):
+            if r == self.dst:
+                continue
+            n_r = self.specs[r][2]
+            lo, hi = self._tile_range(n_r, t, self.n_tiles)
+            if hi <= lo:
+                continue
+            buf = self.recv[b][r] if self.rank == self.dst else self.send[b]
+            for k in range(3):
+                piece = buf[16 + 8 * (k * n_r + lo):16 + 8 * (k * n_r + hi)]
+                ops.append(dist.P2POp(dist.irecv, piece, r) if self.rank == self.dst else dist.P2POp(dist.isend, piece, self.dst))
+        if ops:
+            self.work[b] = list(self.work[b]) + list(dist.batch_isend_irecv(ops))
+
     # ---- sizes ---------------------------------------------------------------------------------------------------------
     def _exact(self, headers):
         return [self.be.survivor_bytes(c, bool(f & 1)) for c, f in headers]
@@ -360,21 +412,24 @@ class SurvivorGather:
         return out
 
     # ---- transfers -----------------------------------------------------------------------------------------------------
-    def _issue(self, b, sizes):
-        """The payload of set b: every peer sends sizes[rank] bytes to dst, dst posts one receive per peer (one group).
+    def _issue(self, b, sizes, skip=frozenset()):
+        """The payload of set b: every peer sends sizes[rank] bytes to dst, dst posts one receive per peer (one group);
+        `skip`: ranks whose records have travelled already (tile by tile).
         A transfer of 16 bytes would carry the header alone, which the header exchange has delivered already: skipped,
         on both sides alike."""
         self.sizes[b], self.nbytes[b] = list(sizes), int(sizes[self.rank])
-        self.work[b] = []
+        if not skip:
+            self.work[b] = []
         if not self._dist() or self.world == 1:
             return                                       # the root's own shard is read where it lies
         ops = []
         if self.rank == self.dst:
-            ops = [dist.P2POp(dist.irecv, self.recv[b][r][:sizes[r]], r) for r in range(self.world) if r != self.dst and sizes[r] > 16]
-        elif sizes[self.rank] > 16:
+            ops = [dist.P2POp(dist.irecv, self.recv[b][r][:sizes[r]], r) for r in range(self.world)
+                   if r != self.dst and sizes[r] > 16 and r not in skip]
+        elif sizes[self.rank] > 16 and self.rank not in skip:
             ops = [dist.P2POp(dist.isend, self._src[b][:sizes[self.rank]], self.dst)]
         if ops:
-            self.work[b] = dist.batch_isend_irecv(ops)
+            self.work[b] = list(self.work[b]) + list(dist.batch_isend_irecv(ops))
 
     def _wait(self, b):
         for w in self.work[b]:
@@ -413,6 +468,8 @@ class SurvivorGather:
         self._state[b] = "idle"
         self._src[b] = self.send[b]
         self._acquired[b] = True
+        self._tiled[b] = self._tiling_ranks()
+        self._tiles_started[b] = 0
         return self.targets(b) if self.zero_copy else None
 
     def start(self, b, X, Y, opl, alive, stats_dev=None, number=None):
@@ -421,6 +478,9 @@ class SurvivorGather:
         if not self._acquired[b]:
             self.acquire(b)
         self._acquired[b] = False
+        if self._tiled[b]:        # (a rank that does not tile itself still posts its side of the peers' tile transfers)
+            for t in range(self._tiles_started[b], self.n_tiles):
+                self.start_tile(b, t)
         first, step, _ = self.specs[self.rank]
         zero = self.n > 0 and X.data_ptr() == self.targets(b)[0].data_ptr()
         if zero:
@@ -459,7 +519,7 @@ class SurvivorGather:
             self._check(b)                    # exact by construction -- unless a zero-copy shard came out unpacked (settle repairs)
             return self.nbytes[b]
         sizes = self._predicted(self._known)
-        self._issue(b, sizes)
+        self._issue(b, sizes, skip=self._tiled[b])
         return self.nbytes[b]
 
     def settle(self, b):

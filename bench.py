@@ -79,6 +79,9 @@ def main(argv=None):
     ap.add_argument("--gather-copy", default="zero", choices=["zero", "pack"],
                     help="N > 1: zero (default) = a shard that loses nothing writes its read-out straight into the gather's "
                          "send buffer; pack = always compact through art_pack_survivors (the round-4 path, for A/B)")
+    ap.add_argument("--gather-tiles", type=int, default=1,
+                    help="N > 1, zero-copy shards: trace the step as T launches over consecutive slot ranges and send each "
+                         "range's records while the next is traced (default 1: the whole step's records leave behind it)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="rays of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--placement-tries", type=int, default=1,
                     help="opt-in: let the step's program time its launch into N candidate output allocations and keep the "

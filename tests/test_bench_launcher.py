@@ -45,6 +45,18 @@ def test_bench_gpus_2_spawns_two_ranks():
     assert abs(j["value"] - inter * 3 / (j["ms_per_step"] * 3e-3)) <= 1e-6 * j["value"]
 
 
+def test_bench_gather_in_tiles_two_ranks():
+    """--gather-tiles T: the step of a zero-copy shard is traced as T launches over consecutive slot ranges of the same
+    bundles and each range's records leave behind it; from the third step on (the ranks tile once the headers of two steps
+    earlier say `dense`) -- same records on rank 0 (the worker asserts them), nothing short."""
+    p = _run(["--gpus", "2", "--steps", "4", "--warmup", "2", "--rays", "5000", "--cpu-sample", "0", "--gather-tiles", "3"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    j = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    c = j["config"]
+    assert c["gather_tiles"] == 3 and c["gather_tiled_steps"] >= 4 and c["gather_zero_copy"] is True
+    assert c["gather_overflows"] == 0 and c["gather_dropped"] == 0 and j["value"] > 0
+
+
 def test_bench_multichain_config_two_ranks():
     """A loop-list configuration (C2: 11 chains in one scene-table launch) through the same launcher."""
     p = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "C2", "--rays", "2000", "--cpu-sample", "0"])

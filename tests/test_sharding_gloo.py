@@ -192,6 +192,25 @@ def _worker(rank, world, port, n_total, q):
             zc.drain()
             assert zc.overflows == 2
             zpacked = zc.assemble(0)
+            # TILES: the step's records leave in T ranges of the zero-copy sections, each behind "its" part of the trace;
+            # which ranks tile follows from the headers of two steps earlier (here: every rank was dense) -- same records
+            tz = sharding.SurvivorGather(be, sizes[rank], world, rank, dst=0, buffers=2, specs=specs, zero_copy=True, tiles=3)
+            used_tiles = []
+            for step_, b in enumerate((0, 1, 0, 1)):
+                tx, ty, tp = tz.acquire(b)
+                if tz.tiling(b):
+                    for t in range(3):
+                        lo, hi = tz.tile_range(t)
+                        tx[lo:hi].copy_(r["X"][lo:hi]); ty[lo:hi].copy_(r["Y"][lo:hi]); tp[lo:hi].copy_(r["opl"][lo:hi])
+                        tz.start_tile(b, t)
+                    used_tiles.append(step_)
+                else:
+                    tx.copy_(r["X"]); ty.copy_(r["Y"]); tp.copy_(r["opl"])
+                tz.start(b, tx, ty, tp, everyone, all_stats)
+            tz.drain()
+            assert used_tiles == [1, 2, 3] and tz.overflows == 0 and tz.host_syncs == 1       # (the first step has nothing to go by)
+            assert tz.tile_range(0)[0] == 0 and tz.tile_range(2)[1] == sizes[rank] and tz.tile_range(1)[0] % 64 == 0
+            ztiled = [tz.assemble(0), tz.assemble(1)]
         finally:
             be.pack_survivors = real_pack
         # OVERFLOW: a gather sized from a step that lost most of its rays, followed by a step in which every ray survives
@@ -225,6 +244,7 @@ def _worker(rank, world, port, n_total, q):
             assert all(torch.equal(a_, b_) for a_, b_ in zip(over, dense))
             assert all(torch.equal(a_, b_) for a_, b_ in zip(after, surv))
             assert all(torch.equal(a_, b_) for a_, b_ in zip(zdense, dense))
+            assert all(torch.equal(a_, b_) for zt in ztiled for a_, b_ in zip(zt, dense))
             assert all(torch.equal(a_, b_) for a_, b_ in zip(zlost, surv))
             assert all(torch.equal(a_, b_) for a_, b_ in zip(zpacked, surv))
             # the survivors of `few`: those of the full step whose slot index within their shard is a multiple of ten

@@ -158,19 +158,34 @@ def worker(args):
     zero_copy = False
     if use_dist:
         zero_copy = bool(fuse and surv_last[-1] == n and not lite and args.gather_copy == "zero")
-        gather = sharding.SurvivorGather(be, n, world, rank, dst=0, buffers=2, specs=specs, zero_copy=zero_copy)
+        gather = sharding.SurvivorGather(be, n, world, rank, dst=0, buffers=2, specs=specs, zero_copy=zero_copy,
+                                         tiles=args.gather_tiles)
 
-    def make_program(targets=None, **kw):
-        ro_t = None if targets is None else [None] * (n_chains - 1) + [targets]
-        return SceneProgram([src] * n_chains, element_lists, IgnoreDefects=ignore_defects, post=readouts, capture=use_graph,
+    def make_program(targets=None, lo=0, hi=None, **kw):
+        """The step's program; with a slot range [lo, hi): one TILE of it (the same output bundles, ranges of them)."""
+        hi = n if hi is None else hi
+        whole = lo == 0 and hi == n
+        s_ = src if whole else src.slots(lo, hi)
+        ro_t = None if targets is None else [None] * (n_chains - 1) + [tuple(t_[lo:hi] for t_ in targets)]
+        if not whole:
+            kw["outputs"] = [[b_.slots(lo, hi) for b_ in outs] for outs in kw["outputs"]]
+        return SceneProgram([s_] * n_chains, element_lists, IgnoreDefects=ignore_defects, post=readouts, capture=use_graph,
                             detectors=dets if fuse else None, readout_lite=lite, readout_targets=ro_t, **kw)
 
     program = None
-    if batched or use_graph:
+    if batched or use_graph or (zero_copy and args.gather_tiles > 1):
         program = make_program(gather.targets(0) if zero_copy else None, placement_tries=args.placement_tries)
     programs = [program, program]
     if zero_copy and program is not None:
         programs[1] = make_program(gather.targets(1))
+    # --gather-tiles T > 1 (zero-copy shards): each buffer set's step also exists as T tile programs over consecutive slot
+    # ranges of the SAME output bundles; the records of tile t leave while tile t + 1 is traced (sharding.SurvivorGather)
+    tile_programs, tile_stats = [None, None], None
+    if zero_copy and program is not None and args.gather_tiles > 1:
+        for b_ in (0, 1):
+            tile_programs[b_] = [make_program(gather.targets(b_), *gather.tile_range(t_), outputs=programs[b_].outputs)
+                                 for t_ in range(args.gather_tiles) if gather.tile_range(t_)[1] > gather.tile_range(t_)[0]]
+        tile_stats = [torch.zeros(24, dtype=torch.float64, device=be.device) for _ in (0, 1)]
 
     # the same step WITHOUT the intermediate bundles (what ARTmain's lazy history traces: the analysed bundle + its
     # read-out; the rest of the history only when somebody looks at it) -- reported beside `value`, never as `value`
@@ -212,7 +227,20 @@ def worker(args):
         if kind == "gather":
             b = state["step"] % 2
             gather.acquire(b)            # the stream waits for set b's previous transfers: its send buffer is rewritten now
-            o, r = trace_and_readout(b)
+            if tile_programs[b] is not None and gather.tiling(b):
+                parts = []
+                for t_, prog in enumerate(tile_programs[b]):
+                    prog.run()
+                    gather.start_tile(b, t_)                 # tile t's records leave while tile t + 1 is traced
+                    parts.append(prog.post_result[-1]["stats_dev"])
+                be.exchange_fold(torch.stack(parts).view(-1), len(parts), 24, tile_stats[b])     # the step's statistics
+                o = programs[b].outputs
+                o[-1][-1].touch()
+                tg = gather.targets(b)
+                r = [None] * (n_chains - 1) + [{"X": tg[0], "Y": tg[1], "opl": tg[2], "stats_dev": tile_stats[b]}]
+                state["tiled_steps"] = state.get("tiled_steps", 0) + 1
+            else:
+                o, r = trace_and_readout(b)
             state["gather_bytes"] = gather.start(b, r[-1]["X"], r[-1]["Y"], r[-1]["opl"], o[-1][-1].alive, r[-1]["stats_dev"])
             state["step"] += 1
             return o, r
@@ -288,8 +316,14 @@ def worker(args):
             assert S.shape == (world, sample_k, 4)
             own = torch.stack([r[-1]["X"], r[-1]["Y"], r[-1]["opl"]]).index_select(1, exchange.slots).T
             assert torch.equal(S[0][:, 0:3].contiguous().view(torch.int64), own.contiguous().view(torch.int64))   # own part of the sample
-            # both routes to the global statistics give the same bits (same fold, rank order)
-            assert torch.equal(gstats.view(torch.int64), state["stats"].view(torch.int64))
+            # both routes to the global statistics give the same bits (same fold, rank order) -- unless the step was traced in
+            # tiles: their partial sums are folded tile by tile (count, minima and maxima stay exact)
+            if state.get("tiled_steps", 0) == 0:
+                assert torch.equal(gstats.view(torch.int64), state["stats"].view(torch.int64))
+            else:
+                exact = [0, 2, 3, 4, 5, 12, 13]
+                assert torch.equal(gstats[exact], state["stats"][exact])
+                assert torch.allclose(gstats, state["stats"], rtol=1e-11, atol=0.0)
     # ------------------------------------------------------------------ kernel durations (HIP events on the launch stream)
     # Right after the timed region(s), on the same resident data: EVENT_STEPS more passes of trace + read-out with every
     # launch bracketed by HIP events recorded on the launch stream.  NOT inside the timed region: every timing event is a
@@ -400,6 +434,8 @@ def worker(args):
                        "that plots a sample and prints global statistics needs; NOT the headline)",
                        "step_full_gather": None if not use_dist else "= step (the headline carries the gather since round 5)",
                        "gather_zero_copy": None if not use_dist else zero_copy,
+                       "gather_tiles": None if not use_dist else args.gather_tiles,
+                       "gather_tiled_steps": None if not use_dist else state.get("tiled_steps", 0),
                        "gather_host_syncs": None if not use_dist else gather.host_syncs,
                        "gather_overflows": None if not use_dist else gather.overflows,
                        "gather_dropped": None if not use_dist else gather.dropped,
