@@ -129,8 +129,22 @@ def analyse_chain_list(OpticalChainList, SourceProperties, DetectorOptions, Anal
     follows by arithmetic on the host.  Same numbers as calling run_ART chain by chain (which is this function with a
     list of one).  Returns [(OpticalChain, Detector, ETransmission, SpotSizeSD, DurationSD)]."""
     from . import ModuleGeometry as mgeo
+    chains = list(OpticalChainList)
     with mgeo.frozen_hashes():        # (nothing below modifies an element: one hash per element serves every cache key)
-        return _analyse_chain_list(OpticalChainList, SourceProperties, DetectorOptions, AnalysisOptions, loop, announce)
+        try:
+            return _analyse_chain_list(chains, SourceProperties, DetectorOptions, AnalysisOptions, loop, announce)
+        except Exception:
+            if len(chains) <= 1:
+                raise
+        # One chain of the list cannot be analysed (all its rays lost, a zero search amplitude, ...).  The reference's loop
+        # (ART/ARTmain.py:304-342) reports every chain in front of it before it fails: so does this second pass, chain by
+        # chain (the traces are cached), which ends in the same exception.
+        out = []
+        for i, ch in enumerate(chains):
+            if announce:
+                print("Optical Chain " + str(i) + "/" + str(len(chains)) + " ", end="", flush=True)
+            out.append(_analyse_chain_list([ch], SourceProperties, DetectorOptions, AnalysisOptions, loop, False)[0])
+        return out
 
 
 def _analyse_chain_list(OpticalChainList, SourceProperties, DetectorOptions, AnalysisOptions, loop=True, announce=False):
@@ -172,8 +186,10 @@ def _analyse_chain_list(OpticalChainList, SourceProperties, DetectorOptions, Ana
         detectors.append(Detector)
     optima = None
     if DetectorOptions["AutoDetectorDistance"]:
+        # (the search itself is silent here: what the reference prints per chain -- the searched range, the "no minimum"
+        # remark -- is printed below, under the chain it belongs to)
         optima = mp._optimise_many([(d, B, res[i]) for i, (d, B) in enumerate(zip(detectors, analysed))],
-                                   DetectorOptions["OptFor"], None, 3, True, False)
+                                   DetectorOptions["OptFor"], None, 3, True, False, announce=False)
     results = []
     for i, (ch, B) in enumerate(zip(chains, analysed)):
         if announce:
@@ -187,7 +203,13 @@ def _analyse_chain_list(OpticalChainList, SourceProperties, DetectorOptions, Ana
                 print("For " + ch.loop_variable_name + " = " + "{:f}".format(ch.loop_variable_value) + ":\n")
                 print("The optical setup has an energy transmission of " + "{:.1f}".format(ETransmission) + "%.\n")
         if optima is not None:
-            Detector, SpotSizeSD, DurationSD = optima[i]
+            Detector, SpotSizeSD, DurationSD, (outside, lo_, hi_) = optima[i]
+            if AnalysisOptions["verbose"]:     # (the reference's progress line, ART/ModuleProcessing.py:436-441, erased like there)
+                print(f"Searching optimal detector position for *{DetectorOptions['OptFor']}* within [{lo_:.3f}, {hi_:.3f}] mm...",
+                      end="", flush=True)
+                print("\r\033[K", end="", flush=True)
+            if outside:
+                print("There`s no minimum-size/duration focus in the searched range.")
             if AnalysisOptions["verbose"]:
                 _report_optimum(Detector, SpotSizeSD, DurationSD, DetectorOptions["OptFor"], True)
         else:

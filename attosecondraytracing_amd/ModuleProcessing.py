@@ -745,7 +745,7 @@ def _spot_duration_at(M, shifts, weighted):
     return np.sqrt(var[:, 0] + var[:, 1]), np.sqrt(var[:, 2]) / LightSpeed * 1e15
 
 
-def _optimise_many(items, OptFor, Amplitude, Precision, IntensityWeighted, verbose=False):
+def _optimise_many(items, OptFor, Amplitude, Precision, IntensityWeighted, verbose=False, announce=True):
     """The search of FindOptimalDistance (ART/ModuleProcessing.py:317-460) for MANY (Detector, RayList, analysis) triples at
     once: every scan level evaluates the positions of all bundles in one broadcast.  The read-out of every ray is linear
     in a shift of the detector along its normal, so spot size and duration at all positions follow from the ONE set of
@@ -753,7 +753,18 @@ def _optimise_many(items, OptFor, Amplitude, Precision, IntensityWeighted, verbo
     bundle per position: arithmetic on 64 doubles per bundle.  Returns [(moved detector, spot size, duration)].
 
     Scan levels as in the reference: positions centre - A_k + i Step_k, i < int(2 A_k / Step_k) (19 or 20, by rounding:
-    per bundle), A_k = Amplitude 0.1^k, k <= Precision; the best position of a level is the centre of the next."""
+    per bundle), A_k = Amplitude 0.1^k, k <= Precision; the best position of a level is the centre of the next.
+
+    One set of moments serves every level.  The variances it yields, (qq + 2 s qs + s^2 ss) / m0 - mean^2, are quadratics
+    in s evaluated near their minimum: their terms are of the size N X0^2 of the START pose and cancel down to N sigma^2 at
+    the focus, so a variance carries an absolute error of ~1e-16 X0^2 -- against differences between neighbouring positions
+    of the finest level of ~ss (1e-4 A)^2 ~ 1e-8 X0^2 (X0 ~ slope x amplitude): eight orders of room.  Shifting the
+    moments to a level's centre first (q' = q + s0 sq, ...) would bake the same rounding into q', qq'; it is the quadratic
+    itself that cancels.  tests/test_host_shell.py::test_autofocus_of_a_tight_focus checks the chosen positions of a
+    sub-micrometre focus against a position-by-position evaluation.
+
+    announce=False: the "no minimum in the searched range" remark is not printed here; every result gets a fourth entry
+    (remark due?, lower end, upper end of the searched range) and the caller of a LIST prints under the chain it belongs to."""
     if OptFor not in ["intensity", "size", "duration"]:
         raise NameError("I don`t recognize what you want to optimize the detector distance for. OptFor must be "
                         "either 'intensity', 'size' or 'duration'.")
@@ -819,11 +830,13 @@ def _optimise_many(items, OptFor, Amplitude, Precision, IntensityWeighted, verbo
     for j, (det, _, _) in enumerate(items):
         moving = det.copy_detector()
         moving.shiftByDistance(float(shift[j]))
-        if not first[j] - amp[j] + 10 ** -Precision < moving.get_distance() < first[j] + amp[j] - 10 ** -Precision:
+        outside = not first[j] - amp[j] + 10 ** -Precision < moving.get_distance() < first[j] + amp[j] - 10 ** -Precision
+        if outside and announce:
             print("There`s no minimum-size/duration focus in the searched range.")
         if verbose:
             print("\r\033[K", end="", flush=True)
-        results.append((moving, np.nan if OptFor == "duration" else float(spot[j]), float(dur[j])))
+        res = (moving, np.nan if OptFor == "duration" else float(spot[j]), float(dur[j]))
+        results.append(res if announce else res + ((outside, first[j] - amp[j], first[j] + amp[j]),))
     return results
 
 

@@ -322,7 +322,10 @@ class SurvivorGather:
         self._tiles_started = [0] * buffers
         # capacity of every buffer: the longest shard with every slot alive and explicit numbers (28 B per ray)
         self.cap = backend.survivor_bytes(max([self.n] + [s[2] for s in self.specs]), False)
-        self.send = [torch.empty(self.cap, dtype=torch.uint8, device=dev) for _ in range(buffers)]
+        # (a send buffer starts 496 bytes into its allocation: the zero-copy sections begin behind the 16-byte header, and the
+        # read-out's stores should meet whole cache lines -- a row that starts 16 bytes off a line costs bandwidth)
+        self._send_raw = [torch.empty(self.cap + 512, dtype=torch.uint8, device=dev) for _ in range(buffers)]
+        self.send = [t[496:496 + self.cap] for t in self._send_raw]
         self.alt = [None] * buffers           # where an unpacked zero-copy shard is packed when its step is settled
         self._src = list(self.send)           # the buffer this rank's records of set b lie in
         self.recv = [[None if r == self.rank else torch.empty(self.cap, dtype=torch.uint8, device=dev) for r in range(self.world)]

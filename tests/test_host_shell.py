@@ -352,3 +352,32 @@ def test_guide_rays_on_the_twin(twin):
 def test_lockstep_placement_on_the_twin(twin):
     import scene_cases
     scene_cases.run_lockstep_placement()
+
+
+def test_autofocus_of_a_tight_focus(twin):
+    """ONE set of moments, taken at the start pose, serves every level of the autofocus search (mp._optimise_many).  A plane
+    wave 0.05 deg off the axis of a parabola focuses to a 0.2-um spot 10 mm from the start pose, where the spot is 1 mm wide:
+    the variances cancel by (1 mm / 0.2 um)^2 = 3e7 there.  The spot size and duration the moment form reports at its
+    optimum must be those of a direct read-out at that position, and no position of a finer grid around it may be better
+    by more than the finest level's step."""
+    import ART.ModuleMirror as mmirror
+    import ART.ModuleSupport as msupp
+    import ART.ModuleProcessing as mp
+    import ART.ModuleDetector as mdet
+    SP = {"Divergence": 0, "SourceSize": 20, "Wavelength": 800e-6, "DeltaFT": 0.5, "NumberRays": 800}
+    ch = mp.OEPlacement(SP, [mmirror.MirrorParabolic(100, 0, msupp.SupportRound(15))], [300], [0.05], Description="tight")
+    last = ch.get_output_rays()[-1]
+    det = mdet.Detector(np.asarray(ch.optical_elements[-1].position, float))
+    det.autoplace(last, 90.0)                       # 10 mm short of the focus
+    D, spot, dur = mp.FindOptimalDistance(det, last, "intensity", 20.0, 3, False, False)      # finest step: 2 um
+    assert 99.5 < D.get_distance() < 100.5 and spot < 1e-3
+    direct_spot = mp.StandardDeviation(list(D.get_PointList2DCentre(last)))
+    direct_dur = mp.StandardDeviation(list(D.get_Delays(last)))
+    assert abs(spot - direct_spot) <= 1e-6 * direct_spot and abs(dur - direct_dur) <= 1e-6 * direct_dur
+    fits = []
+    for s_ in np.linspace(-4e-3, 4e-3, 9):          # position by position, the reference's way, on a 1-um grid
+        here = D.copy_detector()
+        here.shiftByDistance(float(s_))
+        fits.append((mp.StandardDeviation(list(here.get_PointList2DCentre(last))) ** 2
+                     * mp.StandardDeviation(list(here.get_Delays(last))), float(s_)))
+    assert abs(min(fits)[1]) <= 2e-3 + 1e-9, min(fits)
