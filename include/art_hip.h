@@ -353,7 +353,8 @@ int art_exchange_fold(const double* recv, int32_t world, int64_t stride_doubles,
  * slot order, into `send` (DEVICE, 8-byte aligned, capacity send_bytes >= art_survivor_bytes(n, 0)):
  *   [0, 8)   int64 count                     number of alive slots
  *   [8, 16)  int64 flags                     bit 0 "dense": every slot is alive and the numbers are implicit -> the number
- *                                            section is absent (24 B per ray)
+ *                                            section is absent (24 B per ray); bit 1 "unpacked": written by
+ *                                            art_survivor_finish only (below) -- never by art_pack_survivors
  *   [16 ...) double X[count], Y[count], path[count], then int32 number[count] (absent when dense)
  * number[j] = number ? number[slot_j] : first + slot_j * step (the global index of a shard generated by
  * art_make_source / art_make_source_strided; must fit int32, ART_ERR_UNSUPPORTED otherwise).  A rank sends the first
@@ -416,6 +417,7 @@ int art_trace_guides(const ArtElementDesc* elems, int32_t count, double* rays, u
  *   [55] largest angle to the mean vector (rad)
  *   [56] min X [57] max X [58] min Y [59] max Y [60] min opl [61] max opl   (s = 0; +inf / -inf if nothing is alive)
  *   [62..63] 0
+ * One call covers bundles of n <= 2^28 slots (ART_ERR_UNSUPPORTED beyond: 32-bit buffer offsets, as in the tracing launches).
  * A job without alive rays gets count 0, NaN detector fields and zero moments.  A manual detector's normal must be a unit
  * vector (| |normal|^2 - 1 | <= 1e-12, ART_ERR_BAD_ARG otherwise); a manual detector parallel to the mean ray (mean vector .
  * normal = 0) makes the provisional path centre infinite and every path moment NaN -- as the reference's read-out of such a

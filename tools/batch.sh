@@ -6,7 +6,8 @@
 #     --pytest ["-k expr"]        run the GPU suite first (stop the batch if it fails)
 #     --configs "relay4 C2 ..."   bench.py configurations to run (default: relay4)
 #     --variants "A=1 B=2|A=2"    '|'-separated variants, each a list of environment assignments ("-" = none);
-#                                 a variant may set ART_HIP_LIB=<path> to A/B another build of the library
+#                                 (another BUILD of the library is compared with tools/ab_kernel.py --variants "...;LIB=<path>":
+#                                 the product loader takes no library from the environment)
 #     --args "..."                extra bench.py arguments for every run (e.g. "--steps 20 --warmup 5")
 #     --reps N                    repeat the whole variant x config matrix N times (default 1), variants interleaved
 #     --floor                     tools/_build/stream_floor 10000000 (the bare access pattern of this box)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Arbitrary PMC passes of a bench line (one rocprofv3 --pmc run per group of <= 8 SQ counters, kernel trace only):
 #   tools/prof_counters.sh TAG "CNT_A CNT_B ...|CNT_C ..." [bench args...]
-# Environment knobs of the library (ART_CHAIN_RPL=..., ART_HIP_LIB=...) are exported by the caller: rocprofv3 must start
+# Environment knobs of the library (ART_CHAIN_RPL=..., ART_CHAIN_SPECIAL=...) are exported by the caller: rocprofv3 must start
 # python3 itself (no env / bash hop between the profiler and the program).  Output: gpurun_out/cnt_TAG/pass<k>/...
 set -e
 TAG=$1; GROUPS_=$2; shift 2
