@@ -536,7 +536,8 @@ def _roofline(args, cfg, be, program, mode, fuse, lite, src, element_lists, live
     rpl_env = os.environ.get("ART_CHAIN_RPL", "")
     two = (rpl_env == "2" or (rpl_env != "1" and has_mask)) and not defects
     if program is not None:
-        kprefix, kpat = f"k_trace_scene{'2' if two else ''}<{tf}", rf"k_trace_scene2?<{tf}"
+        # (a one-element chain with defects on a simple optic runs the body compiled for its kind: k_trace_scene1<kind, waves>)
+        kprefix, kpat = f"k_trace_scene{'2' if two else ''}<{tf}", (rf"k_trace_scene(2?<{tf}|1<)" if defects else rf"k_trace_scene2?<{tf}")
     elif mode == "chain" and (n_elems > 1 or fuse):
         kprefix, kpat = f"k_trace_chain{'2' if two else ''}<{tf}", rf"k_trace_chain2?<{tf}"
     else:                       # per-element launches; a one-element chain without read-out is that kernel too

@@ -173,7 +173,8 @@ def main():
     out += ["## HBM traffic per launch (`--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separate passes)", "",
             "(fused kernels: averaged over the launches inside the timed region of each pass -- " + "; ".join(cut_note.values()) + ")", ""]
     # (bench.py launches k_bundle_sums_partial once on its all-alive source bundle for exactly this calibration)
-    cal_r = fe.get("k_bundle_sums_partial", 0) / (49.0 * n) if fe.get("k_bundle_sums_partial") else None
+    ksum = "k_bundle_sums_partial<false>" if "k_bundle_sums_partial<false>" in fe else "k_bundle_sums_partial"     # (a template since round 5)
+    cal_r = fe.get(ksum, 0) / (49.0 * n) if fe.get(ksum) else None
     cal_w = wr.get("k_make_source", 0) / (65.0 * n) if wr.get("k_make_source") else None
     out.append(f"calibration on known byte counts ({n} rays): FETCH_SIZE/true read bytes = "
                f"{cal_r if cal_r is None else round(cal_r, 4)} (k_bundle_sums_partial, 49 B/ray; guide says 0.5 on gfx950), "
