@@ -6,9 +6,11 @@ same kind), full per-element history, fp64.  Three ways of issuing the trace:
   chain    one fused launch per chain, eager (art_trace_chain)
   element  one launch per element, eager (art_trace_element)
   program  graph.SceneProgram: device-resident scene table, one launch for ALL chains, replayed from a HIP graph
-Two fractions of the 8 TB/s HBM peak per row: `alg` on the ALGORITHMIC 128 B per intersection and `moved`
-on the bytes the launch really moves (57 B per slot read once per chain or element launch + 65 B per live slot and
-element written; the PMC counters agree with this count to 0.1 %, profiles/).  Writes a markdown table."""
+One fraction of the 8 TB/s HBM peak per row, on the bytes the launch must move (57 B per slot read once per chain or
+element launch + 65 B per live slot and element written; the PMC counters agree with this count to 0.1 %, profiles/).
+(SURVEY 8d's 128 B per intersection prices an UNFUSED element step; a fused chain moves fewer bytes than that, so a
+fraction on 128 B would pass 1 and is not printed -- the intersections/s column is the rate it would scale.)
+Writes a markdown table."""
 import os
 import sys
 
@@ -98,7 +100,7 @@ def main():
     def add(name, src, element_lists, mode, reps, **kw):
         ms, inter, moved, surv = time_trace(src, element_lists, mode, reps, **kw)
         rows.append((name, src.n_slots, len(element_lists[0]), len(element_lists), mode, ms, inter / ms * 1e3,
-                     128 * inter / ms * 1e3 / 8e12, moved / ms * 1e3 / 8e12, surv))
+                     moved / ms * 1e3 / 8e12, surv))
         print(rows[-1], flush=True)
 
     for M in (2, 4, 8):
@@ -134,10 +136,10 @@ def main():
     for ign in (True, False):
         for mode in ("chain", "element"):
             add(f"C5 parabola + Zernike(order 6), IgnoreDefects={ign}", src, lists, mode, 10, IgnoreDefects=ign)
-    out = ["| scene | rays | elements | chains | issue | ms / trace | intersections/s | frac of 8 TB/s (alg. 128 B) | frac of 8 TB/s (bytes moved) | survivors |",
-           "|---|---:|---:|---:|---|---:|---:|---:|---:|---:|"]
+    out = ["| scene | rays | elements | chains | issue | ms / trace | intersections/s | frac of 8 TB/s (bytes moved) | survivors |",
+           "|---|---:|---:|---:|---|---:|---:|---:|---:|"]
     for r in rows:
-        out.append(f"| {r[0]} | {r[1]:.0e} | {r[2]} | {r[3]} | {r[4]} | {r[5]:.4f} | {r[6]:.3e} | {r[7]:.2f} | {r[8]:.2f} | {r[9]:.3f} |")
+        out.append(f"| {r[0]} | {r[1]:.0e} | {r[2]} | {r[3]} | {r[4]} | {r[5]:.4f} | {r[6]:.3e} | {r[7]:.2f} | {r[8]:.3f} |")
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "sweep.md")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     open(path, "w").write("\n".join(out) + "\n")
