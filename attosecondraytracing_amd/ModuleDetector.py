@@ -38,8 +38,8 @@ class Detector:
     def normal(self, Normal):
         if Normal is None:
             self._normal = None
-        elif isinstance(Normal, np.ndarray) and Normal.shape == (3,) and np.linalg.norm(Normal) > 0:
-            self._normal = Normal / np.linalg.norm(Normal)
+        elif isinstance(Normal, np.ndarray) and Normal.shape == (3,) and mgeo._norm(Normal) > 0:
+            self._normal = Normal / mgeo._norm(Normal)
         else:
             raise TypeError("Detector Normal must be a 3D-vector of norm >0, given as numpy.ndarray of shape (3,).")
 
@@ -100,7 +100,7 @@ class Detector:
     def get_distance(self):
         """ART/ModuleDetector.py:139-145."""
         I = mgeo.IntersectionLinePlane(self.refpoint, -self.normal, self.centre, self.normal)
-        return np.linalg.norm(self.refpoint - I)
+        return np.float64(mgeo._norm(self.refpoint - I))
 
     def shiftToDistance(self, NewDistance: float):
         if not _is_number(NewDistance):

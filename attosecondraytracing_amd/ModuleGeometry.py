@@ -13,6 +13,8 @@ def _norm(v):
     """np.linalg.norm of a real float array -- sqrt(x . x), the same two operations, so the same bits -- without its
     argument handling (5 us per call; placing a loop list normalises 300 vectors)."""
     v = v.ravel()
+    if v.dtype != np.float64:
+        v = v.astype(float)          # (as np.linalg.norm does: integer vectors must not overflow in the dot product)
     return math.sqrt(v.dot(v))
 
 

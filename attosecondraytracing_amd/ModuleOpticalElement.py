@@ -9,7 +9,7 @@ _EPS_ORTHO = 1e-12
 
 
 def _is_vec3(v, nonzero=False):
-    return isinstance(v, np.ndarray) and len(v) == 3 and (not nonzero or np.linalg.norm(v) > 0)
+    return isinstance(v, np.ndarray) and len(v) == 3 and (not nonzero or mgeo._norm(v) > 0)
 
 
 class OpticalElement:

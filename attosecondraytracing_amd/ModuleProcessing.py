@@ -631,7 +631,7 @@ def _placeChainsOn(be, Source, OpticsList, variants, Description, c):
                 kk = v.tobytes()
                 u = seen.get(kk)
                 if u is None:
-                    u = seen[kk] = v / np.linalg.norm(v)            # (the Ray.vector setter, ModuleOpticalRay.py:85-90)
+                    u = seen[kk] = v / mgeo._norm(v)            # (the Ray.vector setter, ModuleOpticalRay.py:85-90)
                 central[j] = u
     return [moc.OpticalChain._adopt(Source, els, Description) for els in elements]
 
