@@ -1130,25 +1130,47 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain2(const ChainArgs,
   typedef const ChainArgs __attribute__((address_space(4)))* kernarg_t;
   chain_body2<DEFECT>(*(const ChainArgs*)(kernarg_t)__builtin_amdgcn_kernarg_segment_ptr(), 0, n, xmap, blockIdx.x, gridDim.x);
 }
+// Which (chain, tile) a workgroup of a scene launch works on.  `shape`: 0 = tile-major grid (tiles, chains); bit 0 =
+// chain-interleaved grid (chains, tiles); bit 2 = XCD-GROUPED: a 1-D grid of chains x tiles workgroups (tiles a multiple of
+// 8, chain count in bits 8 and up) in which the C workgroups of one tile all run on ONE XCD.  The dispatcher hands
+// consecutive workgroup ids to the 8 XCDs in turn (id mod 8) and every XCD has its own L2: in the plain interleaved grid
+// the C workgroups that read the same input tile land on 8 different XCDs, so the tile crosses the fabric 8 times (from
+// the memory-side cache after the first) and the L2s share nothing.  Here id = 8 k + xcd; inside an XCD consecutive k
+// run through the chains of one tile (chain = k mod C), then the next tile of that XCD (tile = 8 (k / C) + xcd): the
+// tile is fetched into that XCD's L2 once and the other C - 1 workgroups, dispatched right behind, hit it there.
+// (bit 1 = the shared input is loaded with the default cache policy, see scene_keep.)
+struct SceneWG { unsigned chain, bx, nbx; };
+__device__ __forceinline__ SceneWG scene_wg(const int shape) {
+  if (shape & 4) {
+    const unsigned C = (unsigned)shape >> 8, id = blockIdx.x;
+    const unsigned k = id >> 3, tq = k / C;
+    return {k - tq * C, tq * 8u + (id & 7u), gridDim.x / C};
+  }
+  if (shape & 1) return {blockIdx.x, blockIdx.y, gridDim.y};
+  return {blockIdx.y, blockIdx.x, gridDim.x};
+}
+
 template <bool DEFECT, int WAVES>
 __global__ __launch_bounds__(kBlock, WAVES) void k_trace_scene2(const ChainArgs* __restrict__ tab, const int64_t first,
                                                                 const int64_t n, const int xmap, const int transposed) {
-  const unsigned bx = transposed ? blockIdx.y : blockIdx.x, nbx = transposed ? gridDim.y : gridDim.x;
-  chain_body2<DEFECT>(tab[transposed ? blockIdx.x : blockIdx.y], first, n, xmap, bx, nbx, (transposed & 2) != 0);
+  const SceneWG w = scene_wg(transposed);
+  chain_body2<DEFECT>(tab[w.chain], first, n, xmap, w.bx, w.nbx, (transposed & 2) != 0);
 }
 
-// Many chains in one launch, descriptors in the device-resident scene table (art_scene.h).  Two grid shapes:
-//   tile-major   grid (tiles, chains): blockIdx.y = chain -- the dispatcher works through one chain's tiles after the other;
-//   transposed   grid (chains, tiles): blockIdx.x = chain -- the workgroups of ONE tile of ALL chains are dispatched together.
-// The second is for scenes whose chains all read the SAME input bundle (a loop list traced from one source or from its
-// shared prefix, art_scene.h kFlagSharedIn): the tile of the input that chain 0 fetches from HBM is still in the memory-side
-// cache when chains 1 .. C-1 ask for it a few microseconds later, instead of being streamed from HBM once per chain.
+// Many chains in one launch, descriptors in the device-resident scene table (art_scene.h).  Three grid shapes (scene_wg):
+//   tile-major    grid (tiles, chains): blockIdx.y = chain -- the dispatcher works through one chain's tiles after the other;
+//   interleaved   grid (chains, tiles): blockIdx.x = chain -- the workgroups of ONE tile of ALL chains are dispatched together;
+//   XCD-grouped   1-D grid: ... and on the same XCD, so that they share the tile in that XCD's L2.
+// The last two are for scenes whose chains all read the SAME input bundle (a loop list traced from one source or from its
+// shared prefix, art_scene.h kFlagSharedIn): interleaved, the tile of the input that chain 0 fetches from HBM is still in the
+// memory-side cache when chains 1 .. C-1 ask for it a few microseconds later, instead of being streamed from HBM once per
+// chain; XCD-grouped (the default), it does not even leave the L2.
 template <bool DEFECT, int WAVES>
 __global__ __launch_bounds__(kBlock, WAVES) void k_trace_scene(const ChainArgs* __restrict__ tab, const int64_t first,
                                                                const int64_t n, const int xmap, const int transposed) {
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-  const unsigned bx = transposed ? blockIdx.y : blockIdx.x, nbx = transposed ? gridDim.y : gridDim.x;   // (ONE copy of the body)
-  chain_body<DEFECT>(tab[transposed ? blockIdx.x : blockIdx.y], first, n, xmap, s_dyn, bx, nbx, (transposed & 2) != 0);
+  const SceneWG w = scene_wg(transposed);   // (ONE copy of the body)
+  chain_body<DEFECT>(tab[w.chain], first, n, xmap, s_dyn, w.bx, w.nbx, (transposed & 2) != 0);
 }
 
 // One-element chains WITH defects, the optic's kind a template parameter (round 5, C5: a deformed parabola + read-out).
@@ -1156,8 +1178,8 @@ template <int KIND1, int WAVES>
 __global__ __launch_bounds__(kBlock, WAVES) void k_trace_scene1(const ChainArgs* __restrict__ tab, const int64_t first,
                                                                 const int64_t n, const int xmap, const int transposed) {
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-  const unsigned bx = transposed ? blockIdx.y : blockIdx.x, nbx = transposed ? gridDim.y : gridDim.x;
-  chain_body<true, KIND1>(tab[transposed ? blockIdx.x : blockIdx.y], first, n, xmap, s_dyn, bx, nbx, (transposed & 2) != 0);
+  const SceneWG w = scene_wg(transposed);
+  chain_body<true, KIND1>(tab[w.chain], first, n, xmap, s_dyn, w.bx, w.nbx, (transposed & 2) != 0);
 }
 template <int KIND1, int WAVES>
 __global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain1(const ChainArgs, const int64_t n, const int xmap) {
@@ -2241,29 +2263,35 @@ inline int chain_waves() {
 // two-ray body is 4-7 % faster on chains behind a MASK (C2, C3: a third to a half of the slots are dead -- it skips a
 // dead pair with one branch and two dropped offsets, where the one-ray body still stages, synchronises and issues the
 // workgroup's stores) and -3 ... +9 % elsewhere, box-dependent; so it is the default exactly where a mask is part of the
-// launch.  ART_CHAIN_RPL=1|2 overrides (read at every call: the A/B tool alternates the variants inside one process).
+// launch -- and in a one-segment scene whose chains share their input (XCD-grouped grid, scene_wg): -8 % without a mask,
+// -9 % behind one, where a lone chain (relay4) is 7 % SLOWER with it (profiles/r05_experiments.md batch s).
+// ART_CHAIN_RPL=1|2 overrides (read at every call: the A/B tool alternates the variants inside one process).
 // (One getenv + atoi per launch, ~0.1 us, on purpose: a cached value could not be alternated by the A/B tool.)
 inline int chain_rpl(const bool has_mask) {
   const char* e = getenv("ART_CHAIN_RPL");
   const int v = e ? atoi(e) : 0;
   return (v == 1 || v == 2) ? v : (has_mask ? 2 : 1);
 }
-// Grid shape of a scene launch whose chains share their input: chain-interleaved (transposed) by default.
-// ART_SCENE_ORDER=tile forces the tile-major grid, =chain the interleaved one for every scene (read per launch: A/B).
-inline bool scene_order(const bool shared_in) {
+// Grid shape of a scene launch whose chains share their input: XCD-grouped by default (scene_wg).  -> 0 tile-major, 1
+// chain-interleaved 2-D grid, 4 XCD-grouped.  ART_SCENE_ORDER=tile|chain|xcd forces one shape for every scene (read per
+// launch: the A/B tools alternate them inside one process).
+inline int scene_order(const bool shared_in) {
   const char* e = getenv("ART_SCENE_ORDER");
-  if (e && e[0] == 't') return false;
-  if (e && e[0] == 'c') return true;
-  return shared_in;
+  if (e && e[0] == 't') return 0;
+  if (e && e[0] == 'c') return 1;
+  if (e && e[0] == 'x') return 4;
+  return shared_in ? 4 : 0;
 }
-// ... and whether that shared input is loaded with the default cache policy instead of non-temporal loads: worth it while
-// the input (57 B per slot) fits the 256-MB memory-side cache -- measured in-process (profiles/r04_experiments.md, batch 8):
-// 11 chains x 1e6 rays -10 %, 10 chains x 4e6 rays (228 MB) -15 %, but 10 chains x 1e7 rays (570 MB) +6 ... +8 %, where the
-// interleaved grid with non-temporal loads is the fastest form (-4 %).  ART_SCENE_KEEP=0|1 overrides (A/B).
-inline bool scene_keep(const int64_t n) {
+// ... and whether that shared input is loaded with the default cache policy instead of non-temporal loads.  XCD-grouped:
+// always -- the C - 1 re-reads of a tile follow within microseconds in the same L2 (profiles/r05_experiments.md batch r: 10
+// chains x 1e7 rays 3.167 against 3.280 ms, 11 x 1e6 0.299 against 0.314).  In the interleaved 2-D grid the re-reads come
+// from the memory-side cache: worth it while the input (57 B per slot) fits its 256 MB -- 11 chains x 1e6 rays -10 %, 10
+// chains x 4e6 rays (228 MB) -15 %, but 10 chains x 1e7 rays (570 MB) +6 ... +8 % (profiles/r04_experiments.md, batch 8).
+// ART_SCENE_KEEP=0|1 overrides (A/B).
+inline bool scene_keep(const int64_t n, const bool xcd_grouped) {
   const char* e = getenv("ART_SCENE_KEEP");
   if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
-  return n * 57 <= ((int64_t)256 << 20);
+  return xcd_grouped || n * 57 <= ((int64_t)256 << 20);
 }
 // ART_CHAIN_DYN_LDS=<bytes>: unused dynamic LDS per workgroup of the fused kernel, i.e. FEWER resident workgroups per CU
 // (20 KB static + 20480 -> 4, + 33000 -> 3).  An experiment knob: the bare access pattern gains 3-7 % of bandwidth with 2-3
@@ -2453,16 +2481,22 @@ int art_trace_scene(const void* image_dev, const void* image_host, int64_t n, vo
   for (int64_t off = 0; off < n; off += chunk) {
     const int64_t cnt = (n - off < chunk) ? n - off : chunk;
     const int xm = xcd_map();
-    const bool two = !(flags & 1) && chain_rpl((flags & art::kFlagMask) != 0) == 2;
+    const bool two = !(flags & 1) && chain_rpl((flags & art::kFlagMask) != 0 ||
+                                               ((flags & art::kFlagSharedIn) != 0 && n_chains > 1 && S == 1)) == 2;
     const int tiles = grid_stream_mapped(two ? (cnt + 1) / 2 : cnt, xm);
     for (int sg = 0; sg < S; ++sg) {
       const ChainArgs* seg = tab + (int64_t)sg * n_chains;
       // chains that share their input (first segment only: later segments read their own hand-over bundles) are
       // interleaved tile by tile (see k_trace_scene); ART_SCENE_ORDER=tile|chain overrides (A/B)
       // bit 0: interleaved grid; bit 1: the shared input is loaded with the default cache policy (scene_keep)
-      int tr = (scene_order((flags & art::kFlagSharedIn) != 0 && sg == 0 && n_chains > 1) && tiles <= 65535) ? 1 : 0;
-      if (tr && scene_keep(cnt)) tr |= 2;
-      const dim3 g = tr ? dim3(n_chains, tiles) : dim3(tiles, n_chains), b(kBlock);
+      int tr = scene_order((flags & art::kFlagSharedIn) != 0 && sg == 0 && n_chains > 1);
+      const int tiles8 = (tiles + 7) / 8 * 8;       // (tiles beyond the bundle do nothing; the scratch areas allow for them)
+      if (tr == 4 && ((int64_t)tiles8 * n_chains > 0x7fffffffLL || n_chains > 0x7fffff)) tr = 1;
+      if (tr == 1 && tiles > 65535) tr = 0;
+      if (tr && scene_keep(cnt, (tr & 4) != 0)) tr |= 2;
+      if (tr & 4) tr |= n_chains << 8;
+      const dim3 g = (tr & 4) ? dim3((unsigned)(tiles8 * n_chains)) : ((tr & 1) ? dim3(n_chains, tiles) : dim3(tiles, n_chains)),
+                 b(kBlock);
       if ((flags & 1) && special1 == 5)
         launch_scene1<5>(kind1, g, s, seg, off, cnt, xm, tr);
       else if ((flags & 1) && special1 == 4)
@@ -2478,7 +2512,7 @@ int art_trace_scene(const void* image_dev, const void* image_host, int64_t n, vo
       if ((flags & art::kFlagSums) && sg == S - 1)
         launch_sums_fold_scene(seg, n_chains, analysis_tiles(cnt), s);
       else if ((flags & art::kFlagReadout) && sg == S - 1)
-        launch_fold_scene(seg, n_chains, (int64_t)tiles, s);
+        launch_fold_scene(seg, n_chains, (int64_t)((tr & 4) ? tiles8 : tiles), s);     // (the row stride the kernel used)
     }
   }
   hipError_t err = hipGetLastError();

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """In-process A/B of the grid shape and cache policy of a scene launch whose chains share their input (the library reads
-ART_SCENE_ORDER / ART_SCENE_KEEP at every launch): tile-major grid with non-temporal loads, chain-interleaved grid with
-non-temporal loads, chain-interleaved grid with the input loaded through the caches -- alternating round by round through
+ART_SCENE_ORDER / ART_SCENE_KEEP at every launch): tile-major grid, chain-interleaved 2-D grid, XCD-grouped 1-D grid (the C
+workgroups of a tile on ONE XCD), the shared input loaded non-temporally or through the caches -- alternating round by round through
 graph.SceneProgram._launch() (eager, fused read-outs) on the same resident data, every launch bracketed by HIP events.
 
     python tools/ab_scene.py C2|C3 RAYS full|last        (full = every per-element bundle written, last = lazy history)
@@ -31,7 +31,7 @@ for els in lists:
     dets.append(d)
     del out
 prog = SceneProgram([src] * len(lists), lists, capture=False, detectors=dets, history=hist)
-variants = [("tile", "0"), ("chain", "0"), ("chain", "1")]
+variants = [("tile", "0"), ("chain", "0"), ("chain", "1"), ("xcd", "0"), ("xcd", "1")]
 times = {v: [] for v in variants}
 for rnd in range(9):                       # round 0 warms every variant up
     for v in variants:

@@ -6,7 +6,9 @@ knobs (ART_CHAIN_RPL, ART_CHAIN_WAVES, ART_SCENE_ORDER, ART_SCENE_KEEP), alterna
 Timed with HIP events around the call (device idle before it: the interval includes the ~0.5 ms of host enqueue that
 precedes the last launch, the same for every variant).
 
-    python tools/ab_workflow_trace.py [rays] [--rounds 7] [--variants "NAME=VAL,NAME=VAL;..."]"""
+    python tools/ab_workflow_trace.py [rays] [--rounds 7] [--variants="NAME=VAL,NAME=VAL;..."] [--nomask]
+
+(`--variants=...` with the equals sign: a list that starts with "-", the default build, would read as an option.)"""
 import argparse
 import os
 import sys
@@ -19,7 +21,8 @@ import ART.ModuleMask as mmask, ART.ModuleMirror as mmirror, ART.ModuleProcessin
 import ART.ModuleOpticalChain as moc
 
 KNOBS = ("ART_CHAIN_RPL", "ART_CHAIN_WAVES", "ART_SCENE_ORDER", "ART_SCENE_KEEP")
-DEFAULT = "-;ART_CHAIN_RPL=2;ART_CHAIN_WAVES=4;ART_CHAIN_RPL=2,ART_CHAIN_WAVES=5;ART_SCENE_KEEP=1;ART_SCENE_ORDER=tile"
+DEFAULT = ("-;ART_SCENE_ORDER=chain;ART_SCENE_ORDER=chain,ART_SCENE_KEEP=1;ART_SCENE_KEEP=1;ART_SCENE_KEEP=0;ART_SCENE_ORDER=tile;"
+           "ART_CHAIN_RPL=2;ART_CHAIN_RPL=2,ART_SCENE_KEEP=1;ART_CHAIN_WAVES=4")
 
 
 def main():
@@ -27,6 +30,7 @@ def main():
     ap.add_argument("rays", nargs="?", type=float, default=1e7)
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--variants", default=DEFAULT)
+    ap.add_argument("--nomask", action="store_true", help="the same list without the mask (prefix toroid 1, suffix 10 x toroid 2): every slot alive")
     args = ap.parse_args()
     source = dict(Divergence=25e-3, SourceSize=0, Wavelength=50e-6, DeltaFT=0.5, NumberRays=int(args.rays))
     R, r = mmirror.ReturnOptimalToroidalRadii(600, 80)
@@ -42,8 +46,11 @@ def main():
                 for kv in v.split(","):
                     k, val = kv.split("=")
                     os.environ[k] = val
-            chains = mp.OEPlacement(source, [mask, toroid, toroid], [500, 100, 600], [0, 80, -80],
-                                    [0, 0, np.linspace(-90, 90, 10)], "C3")
+            if args.nomask:
+                chains = mp.OEPlacement(source, [toroid, toroid], [600, 600], [80, -80], [0, np.linspace(-90, 90, 10)], "C3 without mask")
+            else:
+                chains = mp.OEPlacement(source, [mask, toroid, toroid], [500, 100, 600], [0, 80, -80],
+                                        [0, 0, np.linspace(-90, 90, 10)], "C3")
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -56,7 +63,7 @@ def main():
     for k in KNOBS:
         os.environ.pop(k, None)
     base = np.median(times[variants[0]])
-    print(f"# C3 workflow, trace phase (prefix launch + suffix scene launch with the sums tail), {int(args.rays)} rays x 10 chains, "
+    print(("# WITHOUT the mask: " if args.nomask else "") + f"# C3 workflow, trace phase (prefix launch + suffix scene launch with the sums tail), {int(args.rays)} rays x 10 chains, "
           f"{args.rounds} rounds, in-process A/B")
     for v in variants:
         t = np.array(times[v])

@@ -530,11 +530,13 @@ def _roofline(args, cfg, be, program, mode, fuse, lite, src, element_lists, live
     inter_per_launch = inter_per_step_rank / launches
     defects = any(len(getattr(oe.type, "DeformationList", [])) > 0 for els in element_lists for oe in els)
     tf = "true" if defects else "false"
-    # the body is chosen by the library (csrc/art_kernels.hip chain_rpl(): two rays per lane exactly where a mask is part
-    # of a launch without defects): match either name; the label is used when no profile names the kernel
+    # the body is chosen by the library (csrc/art_kernels.hip chain_rpl(): two rays per lane where a mask is part of a launch
+    # without defects, or where the chains of a scene share their input): match either name; the label is used when no
+    # profile names the kernel
     has_mask = any(oe.type.type == "Mask" for els in element_lists for oe in els)
     rpl_env = os.environ.get("ART_CHAIN_RPL", "")
-    two = (rpl_env == "2" or (rpl_env != "1" and has_mask)) and not defects
+    shared = program is not None and n_chains > 1          # (bench scenes trace every chain from the one source shard)
+    two = (rpl_env == "2" or (rpl_env != "1" and (has_mask or shared))) and not defects
     if program is not None:
         # (a one-element chain with defects on a simple optic runs the body compiled for its kind: k_trace_scene1<kind, waves>)
         kprefix, kpat = f"k_trace_scene{'2' if two else ''}<{tf}", (rf"k_trace_scene(2?<{tf}|1<)" if defects else rf"k_trace_scene2?<{tf}")
