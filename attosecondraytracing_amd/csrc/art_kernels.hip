@@ -1139,22 +1139,26 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain2(const ChainArgs,
 // run through the chains of one tile (chain = k mod C), then the next tile of that XCD (tile = 8 (k / C) + xcd): the
 // tile is fetched into that XCD's L2 once and the other C - 1 workgroups, dispatched right behind, hit it there.
 // (bit 1 = the shared input is loaded with the default cache policy, see scene_keep.)
-struct SceneWG { unsigned chain, bx, nbx; };
-__device__ __forceinline__ SceneWG scene_wg(const int shape) {
+// The grid holds C x (tiles rounded up to a multiple of 8) workgroups; the launch's TRUE tile count arrives in the `xmap`
+// parameter (the tile mapping of tile_of does not apply to this shape): workgroups of the padding leave at once, and the
+// per-tile partials of a read-out keep the layout and fold order of the other shapes (same bits whatever the shape).
+struct SceneWG { unsigned chain, bx, nbx; int xmap; bool idle; };
+__device__ __forceinline__ SceneWG scene_wg(const int shape, const int xmap) {
   if (shape & 4) {
     const unsigned C = (unsigned)shape >> 8, id = blockIdx.x;
-    const unsigned k = id >> 3, tq = k / C;
-    return {k - tq * C, tq * 8u + (id & 7u), gridDim.x / C};
+    const unsigned k = id >> 3, tq = k / C, bx = tq * 8u + (id & 7u);
+    return {k - tq * C, bx, (unsigned)xmap, 0, bx >= (unsigned)xmap};
   }
-  if (shape & 1) return {blockIdx.x, blockIdx.y, gridDim.y};
-  return {blockIdx.y, blockIdx.x, gridDim.x};
+  if (shape & 1) return {blockIdx.x, blockIdx.y, gridDim.y, xmap, false};
+  return {blockIdx.y, blockIdx.x, gridDim.x, xmap, false};
 }
 
 template <bool DEFECT, int WAVES>
 __global__ __launch_bounds__(kBlock, WAVES) void k_trace_scene2(const ChainArgs* __restrict__ tab, const int64_t first,
                                                                 const int64_t n, const int xmap, const int transposed) {
-  const SceneWG w = scene_wg(transposed);
-  chain_body2<DEFECT>(tab[w.chain], first, n, xmap, w.bx, w.nbx, (transposed & 2) != 0);
+  const SceneWG w = scene_wg(transposed, xmap);
+  if (w.idle) return;
+  chain_body2<DEFECT>(tab[w.chain], first, n, w.xmap, w.bx, w.nbx, (transposed & 2) != 0);
 }
 
 // Many chains in one launch, descriptors in the device-resident scene table (art_scene.h).  Three grid shapes (scene_wg):
@@ -1169,8 +1173,9 @@ template <bool DEFECT, int WAVES>
 __global__ __launch_bounds__(kBlock, WAVES) void k_trace_scene(const ChainArgs* __restrict__ tab, const int64_t first,
                                                                const int64_t n, const int xmap, const int transposed) {
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-  const SceneWG w = scene_wg(transposed);   // (ONE copy of the body)
-  chain_body<DEFECT>(tab[w.chain], first, n, xmap, s_dyn, w.bx, w.nbx, (transposed & 2) != 0);
+  const SceneWG w = scene_wg(transposed, xmap);   // (ONE copy of the body)
+  if (w.idle) return;
+  chain_body<DEFECT>(tab[w.chain], first, n, w.xmap, s_dyn, w.bx, w.nbx, (transposed & 2) != 0);
 }
 
 // One-element chains WITH defects, the optic's kind a template parameter (round 5, C5: a deformed parabola + read-out).
@@ -1178,8 +1183,9 @@ template <int KIND1, int WAVES>
 __global__ __launch_bounds__(kBlock, WAVES) void k_trace_scene1(const ChainArgs* __restrict__ tab, const int64_t first,
                                                                 const int64_t n, const int xmap, const int transposed) {
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-  const SceneWG w = scene_wg(transposed);
-  chain_body<true, KIND1>(tab[w.chain], first, n, xmap, s_dyn, w.bx, w.nbx, (transposed & 2) != 0);
+  const SceneWG w = scene_wg(transposed, xmap);
+  if (w.idle) return;
+  chain_body<true, KIND1>(tab[w.chain], first, n, w.xmap, s_dyn, w.bx, w.nbx, (transposed & 2) != 0);
 }
 template <int KIND1, int WAVES>
 __global__ __launch_bounds__(kBlock, WAVES) void k_trace_chain1(const ChainArgs, const int64_t n, const int xmap) {
@@ -2490,29 +2496,30 @@ int art_trace_scene(const void* image_dev, const void* image_host, int64_t n, vo
       // interleaved tile by tile (see k_trace_scene); ART_SCENE_ORDER=tile|chain overrides (A/B)
       // bit 0: interleaved grid; bit 1: the shared input is loaded with the default cache policy (scene_keep)
       int tr = scene_order((flags & art::kFlagSharedIn) != 0 && sg == 0 && n_chains > 1);
-      const int tiles8 = (tiles + 7) / 8 * 8;       // (tiles beyond the bundle do nothing; the scratch areas allow for them)
+      const int tiles8 = (tiles + 7) / 8 * 8;       // (the padding workgroups leave at once: scene_wg)
       if (tr == 4 && ((int64_t)tiles8 * n_chains > 0x7fffffffLL || n_chains > 0x7fffff)) tr = 1;
       if (tr == 1 && tiles > 65535) tr = 0;
       if (tr && scene_keep(cnt, (tr & 4) != 0)) tr |= 2;
       if (tr & 4) tr |= n_chains << 8;
       const dim3 g = (tr & 4) ? dim3((unsigned)(tiles8 * n_chains)) : ((tr & 1) ? dim3(n_chains, tiles) : dim3(tiles, n_chains)),
                  b(kBlock);
+      const int xarg = (tr & 4) ? tiles : xm;      // (XCD-grouped: the true tile count travels in the mapping's parameter)
       if ((flags & 1) && special1 == 5)
-        launch_scene1<5>(kind1, g, s, seg, off, cnt, xm, tr);
+        launch_scene1<5>(kind1, g, s, seg, off, cnt, xarg, tr);
       else if ((flags & 1) && special1 == 4)
-        launch_scene1<4>(kind1, g, s, seg, off, cnt, xm, tr);
+        launch_scene1<4>(kind1, g, s, seg, off, cnt, xarg, tr);
       else if (flags & 1)
-        hipLaunchKernelGGL((k_trace_scene<true, 4>), g, b, 0, s, seg, off, cnt, xm, tr);
+        hipLaunchKernelGGL((k_trace_scene<true, 4>), g, b, 0, s, seg, off, cnt, xarg, tr);
       else if (two)
-        hipLaunchKernelGGL((k_trace_scene2<false, 4>), g, b, 0, s, seg, off, cnt, xm, tr);
+        hipLaunchKernelGGL((k_trace_scene2<false, 4>), g, b, 0, s, seg, off, cnt, xarg, tr);
       else if (waves == 6)
-        hipLaunchKernelGGL((k_trace_scene<false, 6>), g, b, 0, s, seg, off, cnt, xm, tr);
+        hipLaunchKernelGGL((k_trace_scene<false, 6>), g, b, 0, s, seg, off, cnt, xarg, tr);
       else
-        hipLaunchKernelGGL((k_trace_scene<false, 5>), g, b, 0, s, seg, off, cnt, xm, tr);
+        hipLaunchKernelGGL((k_trace_scene<false, 5>), g, b, 0, s, seg, off, cnt, xarg, tr);
       if ((flags & art::kFlagSums) && sg == S - 1)
         launch_sums_fold_scene(seg, n_chains, analysis_tiles(cnt), s);
       else if ((flags & art::kFlagReadout) && sg == S - 1)
-        launch_fold_scene(seg, n_chains, (int64_t)((tr & 4) ? tiles8 : tiles), s);     // (the row stride the kernel used)
+        launch_fold_scene(seg, n_chains, (int64_t)tiles, s);
     }
   }
   hipError_t err = hipGetLastError();

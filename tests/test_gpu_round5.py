@@ -299,3 +299,56 @@ def test_gpu_gaussian_weights_about_the_device_side_central_ray(hip):
         got = hip.gaussian_intensity_central(src.view(), 1 / np.e ** 2, n)
         assert float((got - ref).abs().max()) <= 1e-13, kind
         assert 0.13 < float(got.min()) < 0.14 and abs(float(got.max()) - 1.0) < 1e-9
+
+
+@pytest.mark.parametrize("n", [70_001, 1_000_003])
+def test_gpu_scene_grid_shapes_agree_bit_for_bit(hip, monkeypatch, n):
+    """A scene launch whose chains share their input, in its three grid shapes (tile-major, chain-interleaved, XCD-grouped
+    -- the default) and both cache policies of the shared input: the same bundles, read-outs and read-out statistics, bit
+    for bit (the per-tile partials keep one layout and one fold order; the XCD-grouped grid is padded to a multiple of 8
+    tiles per chain and its padding workgroups leave at once).  Ray counts that are no multiple of a tile."""
+    import torch
+    import bench
+    import ART.ModuleProcessing as mp
+    import ART.ModuleDetector as mdet
+    element_lists, kind, dist = bench.scene_c3()
+    element_lists = element_lists[:7]                    # (7 chains: no divisor of 8)
+    src = bench.device_source(n, 0, n, hip, kind)
+    src.intensity = torch.rand(n, dtype=torch.float64, device=hip.device) + 0.25
+    dets = []
+    for els in element_lists:
+        out = mp.RayTracingCalculation(src, els, history=False)
+        d = mdet.Detector(np.asarray(els[-1].position, dtype=float))
+        d.autoplace(out[-1], dist)
+        dets.append(d)
+
+    def run():
+        outs = mp.RayTracingCalculationMany([src] * len(element_lists), element_lists, detectors=dets)
+        res = []
+        for o, d in zip(outs, dets):
+            r = d.readout(o[-1], sync=True)
+            last = o[-1].alive.bool()
+            # (slots of dead rays are not written: only the alive ones are compared)
+            res.append([_bits(b.data[:, b.alive.bool()]).clone() for b in o] + [b.alive.clone() for b in o]
+                       + [_bits(r[k][last]).clone() for k in ("X", "Y", "opl")]
+                       + [torch.from_numpy(r["stats"].view(np.int64).copy())])
+        return res
+
+    monkeypatch.setenv("ART_SCENE_ORDER", "tile")
+    monkeypatch.setenv("ART_SCENE_KEEP", "0")
+    ref = run()
+    assert int(ref[3][3].sum()) > 0      # (something survives the mask)
+    for order in ("chain", "xcd"):
+        for keep in ("0", "1"):
+            monkeypatch.setenv("ART_SCENE_ORDER", order)
+            monkeypatch.setenv("ART_SCENE_KEEP", keep)
+            got = run()
+            for c, (a, b) in enumerate(zip(ref, got)):
+                for k, (x, y) in enumerate(zip(a, b)):
+                    assert torch.equal(x.cpu(), y.cpu()), (order, keep, c, k)
+    monkeypatch.delenv("ART_SCENE_ORDER")
+    monkeypatch.delenv("ART_SCENE_KEEP")
+    got = run()                               # the default shape
+    for a, b in zip(ref, got):
+        for x, y in zip(a, b):
+            assert torch.equal(x.cpu(), y.cpu())
