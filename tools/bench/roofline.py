@@ -58,6 +58,13 @@ def profiled_traffic(config, kernel_pattern, rays):
 
 
 
+def shared_source_credit(n, n_chains):
+    """Bytes a scene launch does NOT have to move because its chains read ONE source bundle (57 B per slot: 7 fp64 streams +
+    the alive byte; the weights of a fused read-out are read per chain): the XCD-grouped grid fetches a tile of it once for
+    all chains (csrc/art_kernels.hip scene_wg), so the launch's minimum is one read, not one per chain."""
+    return 57.0 * n * max(0, n_chains - 1)
+
+
 def chain_bytes(live, n, has_w, fused_readout, fused_kernels=True):
     """Bytes the launch(es) of one step must move for ONE chain, from the run's own survivor counts `live` (after every
     element): (algorithmic, compulsory).  Fused kernels read the source once -- 7 fp64 streams + the alive byte = 57 B per
