@@ -1766,7 +1766,8 @@ __global__ __launch_bounds__(64) void k_analysis_place(const ArtAnalysisJob* __r
 // fixed grid of 1024 workgroups offers.  What it gained in round 5: the next slot's nine streams are requested
 // UNCONDITIONALLY (ld_nt, selects instead of the alive-guarded skip) while the current slot is worked on.
 template <bool HAS_W>
-__device__ __forceinline__ void moments_body(const ArtAnalysisJob& jb, const int64_t n, const double* pl, double (&acc)[kAnaMom]) {
+__device__ __forceinline__ void moments_body(const ArtAnalysisJob& jb, const int64_t n, const double* pl, double (&acc)[kAnaMom],
+                                             const unsigned blk, const unsigned nblk) {
   ArtDetectorDesc d;
 #pragma unroll
   for (int k = 0; k < 3; ++k) { d.centre[k] = pl[k]; d.normal[k] = pl[3 + k]; }
@@ -1778,7 +1779,7 @@ __device__ __forceinline__ void moments_body(const ArtAnalysisJob& jb, const int
   const double co = pl[18];
   const ArtBundleView b = jb.b;
   const double* w = jb.w;
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const int64_t stride = (int64_t)nblk * kBlock;
   // Every stream of the slot is requested UNCONDITIONALLY at the top of its iteration (alive is applied by selects: no
   // load waits for another load); buffer descriptors: one 32-bit offset register serves all nine streams (nine 64-bit
   // addresses would not fit beside the accumulators), slots beyond the end read 0 = dead.  A software pipeline (the next
@@ -1789,7 +1790,7 @@ __device__ __forceinline__ void moments_body(const ArtAnalysisJob& jb, const int
   const __amdgpu_buffer_rsrc_t rw = rsrc_of(const_cast<double*>(w), HAS_W ? (unsigned)(n * 8) : 0u);
   const unsigned ustride = (unsigned)stride, un_ = (unsigned)n;
   int cnt = 0;
-  unsigned i = blockIdx.x * kBlock + threadIdx.x;
+  unsigned i = blk * kBlock + threadIdx.x;
   bool l = __builtin_amdgcn_raw_buffer_load_b8(rb.alive, (int)i, 0, ART_LD_AUX) != 0;
   for (; i < un_; i += ustride) {
     // the data of an ALIVE slot only (a dead one is requested out of range: no traffic; its fields read 0 and are selected
@@ -1833,9 +1834,17 @@ __device__ __forceinline__ void moments_body(const ArtAnalysisJob& jb, const int
   acc[0] = (double)cnt;      // (a lane folds < 2^31 slots: the integer count is exact, as the sum of 1.0s was)
 }
 
+// 1-D grid of (P rounded up to a multiple of 8) x J workgroups, XCD-grouped like the scene launches (scene_wg): id = 8 k + xcd,
+// job = k mod J, block = 8 (k / J) + xcd -- the J workgroups that walk the SAME slots of J bundles run on one XCD, so the
+// weights the jobs of a loop list share (one source: one intensity array) are fetched into its L2 once, not J times.
+// Which slots a block folds, and the fold order, do not depend on the mapping.
 __global__ __launch_bounds__(kBlock, 4) void k_analysis_moments(const ArtAnalysisJob* __restrict__ jobs, const int64_t n,
-                                                             const double* place, const double* out, double* scratch) {
-  const int j = blockIdx.y;
+                                                             const double* place, const double* out, double* scratch,
+                                                             const int P, const int J) {
+  const unsigned id = blockIdx.x, k = id >> 3, kq = k / (unsigned)J;
+  const unsigned blk = kq * 8u + (id & 7u);
+  const int j = (int)(k - kq * (unsigned)J);
+  if (blk >= (unsigned)P) return;            // (padding)
   const ArtAnalysisJob& jb = jobs[j];
   double acc[kAnaMom];
 #pragma unroll
@@ -1843,10 +1852,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_analysis_moments(const ArtAnalysi
   acc[34] = 0.0;    // the largest angle of an empty set is 0 (ReturnNumericalAperture's max over nothing never happens)
   const bool active = jb.mode != ART_JOB_SUMS && out[(int64_t)j * ART_ANALYSIS_DOUBLES] > 0.0;
   if (active) {
-    if (jb.w) moments_body<true>(jb, n, place + (int64_t)j * kAnaPlace, acc);
-    else moments_body<false>(jb, n, place + (int64_t)j * kAnaPlace, acc);
+    if (jb.w) moments_body<true>(jb, n, place + (int64_t)j * kAnaPlace, acc, blk, (unsigned)P);
+    else moments_body<false>(jb, n, place + (int64_t)j * kAnaPlace, acc, blk, (unsigned)P);
   }
-  block_reduce_store_f<kAnaMom>(acc, [](int k) { return ana_mom_op(k); }, scratch + ((int64_t)j * gridDim.x + blockIdx.x) * kAnaMom);
+  block_reduce_store_f<kAnaMom>(acc, [](int q) { return ana_mom_op(q); }, scratch + ((int64_t)j * P + blk) * kAnaMom);
 }
 
 // grid (kAnaMom - 1, n_jobs): workgroup (q, j) folds partial q of job j into its output slot
@@ -2944,7 +2953,8 @@ int art_analyse_bundles(const ArtAnalysisJob* jobs_dev, const ArtAnalysisJob* jo
   hipLaunchKernelGGL(k_analysis_sums_fold2, dim3(kSumRows, 1, n_jobs), dim3(direct ? fold_threads(n > 0 ? ntiles : 0) : kBlock), 0, s,
                      jobs_dev, rows, rstride, n > 0 ? ntiles : 0, direct, sums);
   hipLaunchKernelGGL(k_analysis_place, dim3((n_jobs + 63) / 64), dim3(64), 0, s, jobs_dev, (int)n_jobs, sums, place, out);
-  hipLaunchKernelGGL(k_analysis_moments, dim3(P, n_jobs), dim3(kBlock), 0, s, jobs_dev, n, place, out, mom);
+  hipLaunchKernelGGL(k_analysis_moments, dim3((unsigned)((P + 7) / 8 * 8) * (unsigned)n_jobs), dim3(kBlock), 0, s, jobs_dev, n, place, out,
+                     mom, P, (int)n_jobs);
   hipLaunchKernelGGL(k_analysis_fold, dim3(kAnaMom - 1, n_jobs), dim3(kBlock), 0, s, jobs_dev, P, mom, out);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_analyse_bundles launch");
