@@ -1676,6 +1676,11 @@ inline int analysis_blocks(int64_t n) {
   return (int)(b < 1 ? 1 : (b > kAnaBlocks ? kAnaBlocks : b));
 }
 inline int64_t analysis_tiles(int64_t n) { return n < 1 ? 1 : (n + kBlock - 1) / kBlock; }
+// ART_ANALYSIS_ORDER=job: the moments pass in job-major order instead of XCD-grouped (read per call: in-process A/B)
+inline int analysis_job_major() {
+  const char* e = getenv("ART_ANALYSIS_ORDER");
+  return (e && e[0] == 'j') ? 1 : 0;
+}
 __device__ __forceinline__ int ana_mom_op(const int q) {   // operator of moment-pass partial q
   return (q < 32) ? RSUM : ((q == 33 || q == 35 || q == 37 || q == 39) ? RMIN : ((q == 41) ? RSUM : RMAX));
 }
@@ -1840,10 +1845,18 @@ __device__ __forceinline__ void moments_body(const ArtAnalysisJob& jb, const int
 // Which slots a block folds, and the fold order, do not depend on the mapping.
 __global__ __launch_bounds__(kBlock, 4) void k_analysis_moments(const ArtAnalysisJob* __restrict__ jobs, const int64_t n,
                                                              const double* place, const double* out, double* scratch,
-                                                             const int P, const int J) {
-  const unsigned id = blockIdx.x, k = id >> 3, kq = k / (unsigned)J;
-  const unsigned blk = kq * 8u + (id & 7u);
-  const int j = (int)(k - kq * (unsigned)J);
+                                                             const int P, const int J, const int job_major) {
+  const unsigned id = blockIdx.x, P8 = gridDim.x / (unsigned)J;
+  unsigned blk;
+  int j;
+  if (job_major) {                           // (ART_ANALYSIS_ORDER=job: one job's workgroups after the other, for the A/B)
+    j = (int)(id / P8);
+    blk = id - (unsigned)j * P8;
+  } else {
+    const unsigned k = id >> 3, kq = k / (unsigned)J;
+    blk = kq * 8u + (id & 7u);
+    j = (int)(k - kq * (unsigned)J);
+  }
   if (blk >= (unsigned)P) return;            // (padding)
   const ArtAnalysisJob& jb = jobs[j];
   double acc[kAnaMom];
@@ -2954,7 +2967,7 @@ int art_analyse_bundles(const ArtAnalysisJob* jobs_dev, const ArtAnalysisJob* jo
                      jobs_dev, rows, rstride, n > 0 ? ntiles : 0, direct, sums);
   hipLaunchKernelGGL(k_analysis_place, dim3((n_jobs + 63) / 64), dim3(64), 0, s, jobs_dev, (int)n_jobs, sums, place, out);
   hipLaunchKernelGGL(k_analysis_moments, dim3((unsigned)((P + 7) / 8 * 8) * (unsigned)n_jobs), dim3(kBlock), 0, s, jobs_dev, n, place, out,
-                     mom, P, (int)n_jobs);
+                     mom, P, (int)n_jobs, analysis_job_major());
   hipLaunchKernelGGL(k_analysis_fold, dim3(kAnaMom - 1, n_jobs), dim3(kBlock), 0, s, jobs_dev, P, mom, out);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_analyse_bundles launch");

@@ -53,7 +53,12 @@ def main():
     X, Y, O = be.empty(n), be.empty(n), be.empty(n)
     be.detector_readout(det._desc(), b.view(), src.intensity, n, XY=(X, Y), opl=O, to_host=False)
     send = torch.empty(be.survivor_bytes(n, False), dtype=torch.uint8, device=be.device)
-    jobs = [analysis._job(b, _abi.ART_JOB_AUTOPLACE, 100.0) for _ in range(args.jobs)]
+    # the jobs of a list analysis: DIFFERENT bundles (copies here) that share one intensity array, like the chains of a loop
+    # list -- the same bundle ten times would come from the caches
+    others = [b] + [b.copy() for _ in range(args.jobs - 1)]
+    for o in others[1:]:
+        o.intensity = src.intensity
+    jobs = [analysis._job(o, _abi.ART_JOB_AUTOPLACE, 100.0) for o in others]
 
     def timed(fn):
         for _ in range(3):
