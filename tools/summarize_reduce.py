@@ -78,8 +78,14 @@ def main():
     print("|---|---:|---:|---:|---:|---:|---:|---:|---:|")
     # rows: every kernel at its largest grid; the analysis kernels (grid.y = job) once per job count
     gy = collections.defaultdict(set)
+    # (k_analysis_moments runs a 1-D XCD-grouped grid of P8 x jobs workgroups, P8 = min(tiles, 1024) rounded up to 8)
+    p8 = (min((n + 255) // 256, 1024) + 7) // 8 * 8
     for r in rows:
-        gy[short(r["Kernel_Name"])].add((grid_threads(r), int(r.get("Grid_Size_Y", 1) or 1)))
+        nm, g = short(r["Kernel_Name"]), grid_threads(r)
+        y = int(r.get("Grid_Size_Y", 1) or 1)
+        if nm == "k_analysis_moments" and y == 1:
+            y = max(1, g // (p8 * 256))
+        gy[nm].add((g, y))
     names = sorted({k for k, _ in by if k.startswith("k_")})
     for k in names:
         grids = sorted(gy[k])
