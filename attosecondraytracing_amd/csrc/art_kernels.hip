@@ -1845,8 +1845,8 @@ __device__ __forceinline__ void moments_body(const ArtAnalysisJob& jb, const int
 // Which slots a block folds, and the fold order, do not depend on the mapping.
 __global__ __launch_bounds__(kBlock, 4) void k_analysis_moments(const ArtAnalysisJob* __restrict__ jobs, const int64_t n,
                                                              const double* place, const double* out, double* scratch,
-                                                             const int P, const int J, const int job_major) {
-  const unsigned id = blockIdx.x, P8 = gridDim.x / (unsigned)J;
+                                                             const int P, const int job0, const int J, const int job_major) {
+  const unsigned id = blockIdx.x, P8 = gridDim.x / (unsigned)J;     // (jobs job0 .. job0 + J - 1 in this launch)
   unsigned blk;
   int j;
   if (job_major) {                           // (ART_ANALYSIS_ORDER=job: one job's workgroups after the other, for the A/B)
@@ -1858,6 +1858,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_analysis_moments(const ArtAnalysi
     j = (int)(k - kq * (unsigned)J);
   }
   if (blk >= (unsigned)P) return;            // (padding)
+  j += job0;
   const ArtAnalysisJob& jb = jobs[j];
   double acc[kAnaMom];
 #pragma unroll
@@ -2519,7 +2520,8 @@ int art_trace_scene(const void* image_dev, const void* image_host, int64_t n, vo
       // bit 0: interleaved grid; bit 1: the shared input is loaded with the default cache policy (scene_keep)
       int tr = scene_order((flags & art::kFlagSharedIn) != 0 && sg == 0 && n_chains > 1);
       const int tiles8 = (tiles + 7) / 8 * 8;       // (the padding workgroups leave at once: scene_wg)
-      if (tr == 4 && ((int64_t)tiles8 * n_chains > 0x7fffffffLL || n_chains > 0x7fffff)) tr = 1;
+      // (a grid dimension holds fewer than 2^32 work-items: 2^24 workgroups of 256)
+      if (tr == 4 && (int64_t)tiles8 * n_chains >= ((int64_t)1 << 24)) tr = 1;
       if (tr == 1 && tiles > 65535) tr = 0;
       if (tr && scene_keep(cnt, (tr & 4) != 0)) tr |= 2;
       if (tr & 4) tr |= n_chains << 8;
@@ -2966,8 +2968,15 @@ int art_analyse_bundles(const ArtAnalysisJob* jobs_dev, const ArtAnalysisJob* jo
   hipLaunchKernelGGL(k_analysis_sums_fold2, dim3(kSumRows, 1, n_jobs), dim3(direct ? fold_threads(n > 0 ? ntiles : 0) : kBlock), 0, s,
                      jobs_dev, rows, rstride, n > 0 ? ntiles : 0, direct, sums);
   hipLaunchKernelGGL(k_analysis_place, dim3((n_jobs + 63) / 64), dim3(64), 0, s, jobs_dev, (int)n_jobs, sums, place, out);
-  hipLaunchKernelGGL(k_analysis_moments, dim3((unsigned)((P + 7) / 8 * 8) * (unsigned)n_jobs), dim3(kBlock), 0, s, jobs_dev, n, place, out,
-                     mom, P, (int)n_jobs, analysis_job_major());
+  {
+    // (a grid dimension holds fewer than 2^32 work-items = 2^24 workgroups: more than 16 383 jobs go in several launches)
+    const int P8 = (P + 7) / 8 * 8, jmax = ((1 << 24) - 1) / P8, jm = analysis_job_major();
+    for (int j0 = 0; j0 < n_jobs; j0 += jmax) {
+      const int J = (n_jobs - j0 < jmax) ? n_jobs - j0 : jmax;
+      hipLaunchKernelGGL(k_analysis_moments, dim3((unsigned)P8 * (unsigned)J), dim3(kBlock), 0, s, jobs_dev, n, place, out, mom, P,
+                         j0, J, jm);
+    }
+  }
   hipLaunchKernelGGL(k_analysis_fold, dim3(kAnaMom - 1, n_jobs), dim3(kBlock), 0, s, jobs_dev, P, mom, out);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail_hip(err, "art_analyse_bundles launch");

@@ -352,3 +352,30 @@ def test_gpu_scene_grid_shapes_agree_bit_for_bit(hip, monkeypatch, n):
     for a, b in zip(ref, got):
         for x, y in zip(a, b):
             assert torch.equal(x.cpu(), y.cpu())
+
+
+def test_gpu_analysis_of_more_jobs_than_one_launch_holds(hip):
+    """The moments pass runs a 1-D grid (XCD-grouped): 1024 workgroups per job, and a grid dimension holds fewer than 2^24
+    workgroups -- 16 385 jobs go in two launches.  Every row equals the one-job analysis of the same bundle, bit for bit."""
+    import torch
+    import bench
+    from attosecondraytracing_amd import _abi, analysis
+    from attosecondraytracing_amd.bundle import RayBundle
+    n = 262_144                                   # 1024 tiles: the moments pass's full grid per job
+    src = bench.device_source(n, 0, n, hip, ("point", 0.02))
+    b = RayBundle.allocate(n, like=src, backend=hip)
+    b.data.copy_(src.data)
+    b.data[0:3] += 400.0 * src.data[3:6]
+    b.data[6] = 400.0
+    b.alive.fill_(1)
+    b.alive[::7] = 0
+    one = hip.analyse_bundles([analysis._job(b, _abi.ART_JOB_AUTOPLACE, 150.0)], n)[0].cpu().numpy()
+    J = 16_385
+    job = analysis._job(b, _abi.ART_JOB_AUTOPLACE, 150.0)
+    rows = hip.analyse_bundles([job] * J, n).cpu().numpy()
+    assert rows.shape[0] == J and one[0] == n - len(range(0, n, 7))
+    for j in (0, 1, 8191, 16_382, 16_383, 16_384):
+        assert np.array_equal(rows[j].view(np.int64), one.view(np.int64)), j
+    assert (rows.view(np.int64) == one.view(np.int64)[None, :]).all()
+    hip._scratch.pop(("analysis", hip.stream_key()), None)      # (7 GB of scratch: not kept for the rest of the suite)
+    torch.cuda.empty_cache()
