@@ -184,3 +184,24 @@ def test_process_group_timeout_ends_a_rank_that_waits_alone():
               "--time-limit", "120"], ART_BENCH_BACKEND_HOOK="twin_backend:install_sleeping_on_rank_1")
     assert p.returncode == 1, (p.returncode, p.stderr[-2000:])
     assert not [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+
+
+def test_bench_as_torchrun_workers():
+    """The driver's N > 1 launch: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- bench.py is then a WORKER (RANK / WORLD_SIZE set), not the launcher: one JSON
+    line from rank 0, the world size the group really had, the step with the survivor gather as `value`."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                        "--warmup", "1", "--rays", "3000", "--cpu-sample", "0"],
+                       env=_env(OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["world_size_seen"] == 2 and j["scaling"] == "weak"
+    assert j["steps"] == 3 and j["warmup"] == 1
+    assert j["value"] == j["value_full_gather"] > 0 and j["value_stats_exchange"] > 0
