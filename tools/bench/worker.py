@@ -7,7 +7,7 @@ import time
 from .launcher import BoxState, log, ROOT
 from . import workloads, baselines, roofline as rl
 
-SETTLE_SECONDS = 0.25   # device-busy time before the `value_sustained` region
+SETTLE_SECONDS = 2.0    # device-busy time before the `value_sustained` region (long enough for clocks AND power management to settle)
 EVENT_STEPS = 20        # passes whose launches are bracketed by HIP events for roofline.kernel_ms
 
 
