@@ -86,6 +86,10 @@ def main(argv=None):
     ap.add_argument("--placement-tries", type=int, default=1,
                     help="opt-in: let the step's program time its launch into N candidate output allocations and keep the "
                          "fastest (graph.SceneProgram; default 1 = take the first allocation)")
+    ap.add_argument("--preheat-ms", type=float, default=0.0,
+                    help="opt-in (default 0 = the contract's region as it is: W warm-up steps after an idle device): keep the "
+                         "device busy with untimed steps for this long before the W warm-up steps, so that the timed region "
+                         "runs at sustained clocks; reported as `preheat_ms`")
     ap.add_argument("--time-limit", type=float, default=float(os.environ.get("ART_BENCH_TIME_LIMIT", "1500")),
                     help="N > 1 launcher: wall-clock limit in seconds after which all workers are killed (exit code 4)")
     ap.add_argument("--pg-timeout", type=float, default=float(os.environ.get("ART_PG_TIMEOUT", "300")),
